@@ -1,0 +1,134 @@
+"""
+ctypes binding of libgpimhip.so (include/gpimhip.h).
+
+The product path has no CPU fallback: if the shared library cannot be loaded, or no
+MI355X-class device is visible to torch, every entry point raises RuntimeError.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgpimhip.so")
+
+OK, E_BADARG, E_HIP, E_NOT_PD, E_NOMEM = 0, -1, -2, -3, -4
+KERNEL_IDS = {"RBF": 0, "Matern52": 1, "RationalQuadratic": 2}
+ACQ_IDS = {"cb": 0, "ei": 1, "poi": 2}
+MAX_DIM, MAX_PARAMS = 4, 8
+
+c_dp = ctypes.c_void_p      # device pointers travel as plain addresses
+
+
+class ModelStruct(ctypes.Structure):
+    """gpimhip_model_t"""
+    _fields_ = [("kernel", ctypes.c_int32), ("dim", ctypes.c_int32), ("n_ls", ctypes.c_int32),
+                ("reserved", ctypes.c_int32), ("amp_lo", ctypes.c_double), ("amp_hi", ctypes.c_double),
+                ("ls_lo", ctypes.c_double * MAX_DIM), ("ls_hi", ctypes.c_double * MAX_DIM),
+                ("jitter", ctypes.c_double)]
+
+
+_lib = None
+
+_PROTOS = {
+    "gpimhip_create": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_void_p]),
+    "gpimhip_destroy": (ctypes.c_int, [ctypes.c_void_p]),
+    "gpimhip_last_error": (ctypes.c_char_p, []),
+    "gpimhip_version": (ctypes.c_int, []),
+    "gpimhip_workspace_bytes": (ctypes.c_int64, [ctypes.c_void_p]),
+    "gpimhip_sync": (ctypes.c_int, [ctypes.c_void_p]),
+    "gpimhip_kmat": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ModelStruct), c_dp, ctypes.c_int64, c_dp,
+                                    ctypes.c_int64, c_dp, ctypes.c_double, c_dp, ctypes.c_int64]),
+    "gpimhip_potrf": (ctypes.c_int, [ctypes.c_void_p, c_dp, ctypes.c_int64, ctypes.c_int64, c_dp]),
+    "gpimhip_nll_grad": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ModelStruct), c_dp, c_dp, ctypes.c_int64,
+                                        c_dp, c_dp, c_dp]),
+    "gpimhip_fit_exact": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ModelStruct), c_dp, c_dp, ctypes.c_int64,
+                                         c_dp, ctypes.c_double, ctypes.c_int32, c_dp, c_dp]),
+    "gpimhip_predict_exact": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ModelStruct), c_dp, c_dp,
+                                             ctypes.c_int64, c_dp, c_dp, ctypes.c_int64, c_dp, c_dp]),
+    "gpimhip_acq": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, c_dp, c_dp, ctypes.c_int64, ctypes.c_double,
+                                   ctypes.c_double, c_dp, c_dp]),
+    "gpimhip_nanmax": (ctypes.c_int, [ctypes.c_void_p, c_dp, ctypes.c_int64, c_dp]),
+    "gpimhip_topk": (ctypes.c_int, [ctypes.c_void_p, c_dp, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
+                                    c_dp, c_dp, c_dp]),
+}
+EXPORTS = tuple(_PROTOS)
+
+
+def load():
+    """Loads libgpimhip.so (no GPU needed for the load itself) and types its symbols."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "gpim_amd: %s is missing -- build it with `python -m gpim_amd._build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:
+        raise RuntimeError("gpim_amd: cannot load %s: %s. There is no CPU fallback." % (LIB_PATH, e))
+    for name, (res, args) in _PROTOS.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError("gpim_amd: no HIP device visible to torch; the MI355X engine has no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+class NotPositiveDefiniteError(torch.linalg.LinAlgError if hasattr(torch.linalg, "LinAlgError") else RuntimeError):
+    """Raised where torch.linalg.cholesky would raise in the reference (gpr.py:192,248)."""
+
+
+def check(rc):
+    if rc == OK:
+        return
+    msg = load().gpimhip_last_error().decode()
+    if rc == E_NOT_PD:
+        raise NotPositiveDefiniteError("linalg.cholesky: " + msg)
+    if rc == E_BADARG:
+        raise ValueError("gpimhip: bad argument. " + msg)
+    if rc == E_NOMEM:
+        raise MemoryError("gpimhip: " + msg)
+    raise RuntimeError("gpimhip: HIP error. " + msg)
+
+
+class Handle:
+    """Owns one gpimhip_handle bound to torch's current stream on the current device."""
+
+    def __init__(self):
+        self.device = require_gpu()
+        lib = load()
+        h = ctypes.c_void_p()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        check(lib.gpimhip_create(ctypes.byref(h), self.device.index, ctypes.c_void_p(stream)))
+        self._h = h
+        self.lib = lib
+
+    @property
+    def h(self):
+        return self._h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.gpimhip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def ptr(t):
+    """Device address of a contiguous CUDA tensor (or None)."""
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous()
+    return ctypes.c_void_p(t.data_ptr())

@@ -1,0 +1,94 @@
+"""
+acqfunc.py -- acquisition functions over the dense grid, evaluated on the GPU.
+
+Mirror of the reference's gpim/gpbayes/acqfunc.py:11-92: same call
+signatures and return values ``(acq, (mean, sd))`` as numpy arrays.  The element-wise sweep
+(CB / EI / POI, ``Phi`` through erfc) and the incumbent ``nanmax`` run in libgpimhip
+(gpimhip_acq, gpimhip_nanmax).  ``gpmodel`` is normally a ``gpim_amd.reconstructor``; any
+object with ``predict(X, verbose=0) -> (mean, sd)`` works (its arrays are uploaded).
+
+Reference quirk kept on purpose (the golden test_poi.npy depends on it): in
+``probability_of_improvement`` the incumbent is the nanmax over BOTH the posterior means and
+the posterior standard deviations at the observed points (acqfunc.py:86-88).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_F64 = torch.float64
+_handles = {}
+
+
+def _handle_for(gpmodel):
+    h = getattr(gpmodel, "_handle", None)
+    if h is not None:
+        return h
+    dev = _lib.require_gpu()
+    if dev.index not in _handles:
+        _handles[dev.index] = _lib.Handle()
+    return _handles[dev.index]
+
+
+def _device_pred(gpmodel, X, handle):
+    """predict -> numpy results plus device copies (reused from the reconstructor if it has them)."""
+    if hasattr(gpmodel, "_last_pred"):
+        gpmodel._last_pred = None
+    mean, sd = gpmodel.predict(X, verbose=0)
+    last = getattr(gpmodel, "_last_pred", None)
+    if last is not None:
+        return mean, sd, last[0], last[1]
+    md = torch.as_tensor(np.ascontiguousarray(mean), dtype=_F64).reshape(-1).to(handle.device)
+    sdd = torch.as_tensor(np.ascontiguousarray(sd), dtype=_F64).reshape(-1).to(handle.device)
+    return mean, sd, md, sdd
+
+
+def _sweep(handle, kind, md, sdd, p0, p1, shape):
+    out = torch.empty_like(md)
+    _lib.check(handle.lib.gpimhip_acq(handle.h, _lib.ACQ_IDS[kind], _lib.ptr(md), _lib.ptr(sdd), md.numel(),
+                                      float(p0), float(p1), None, _lib.ptr(out)))
+    return out.cpu().numpy().reshape(shape), out
+
+
+def _nanmax(handle, *tensors):
+    t = tensors[0] if len(tensors) == 1 else torch.cat([x.reshape(-1) for x in tensors])
+    t = t.contiguous()
+    out = torch.empty((1,), dtype=_F64, device=t.device)
+    _lib.check(handle.lib.gpimhip_nanmax(handle.h, _lib.ptr(t), t.numel(), _lib.ptr(out)))
+    return out.item()
+
+
+def confidence_bound(gpmodel, X_full, **kwargs):
+    """alpha * mean + beta * sd (defaults 0, 1)."""
+    alpha, beta = kwargs.get("alpha", 0), kwargs.get("beta", 1)
+    handle = _handle_for(gpmodel)
+    mean, sd, md, sdd = _device_pred(gpmodel, X_full, handle)
+    acq, acq_d = _sweep(handle, "cb", md, sdd, alpha, beta, mean.shape)
+    gpmodel._last_acq = acq_d if hasattr(gpmodel, "_last_pred") else None
+    return acq, (mean, sd)
+
+
+def expected_improvement(gpmodel, X_full, X_sparse, **kwargs):
+    """imp * Phi(imp/sd) + sd * phi(imp/sd), imp = mean - max(mean at observed points) - xi."""
+    xi = kwargs.get("xi", 0.01)
+    handle = _handle_for(gpmodel)
+    mean, sd, md, sdd = _device_pred(gpmodel, X_full, handle)
+    _, _, mo, _ = _device_pred(gpmodel, X_sparse, handle)     # NaN rows -> NaN means
+    best = _nanmax(handle, mo)
+    acq, acq_d = _sweep(handle, "ei", md, sdd, best, xi, mean.shape)
+    gpmodel._last_acq = acq_d if hasattr(gpmodel, "_last_pred") else None
+    return acq, (mean, sd)
+
+
+def probability_of_improvement(gpmodel, X_full, X_sparse, **kwargs):
+    """Phi((mean - incumbent - xi) / sd) with the reference's (mean, sd)-tuple incumbent."""
+    xi = kwargs.get("xi", 0.01)
+    handle = _handle_for(gpmodel)
+    mean, sd, md, sdd = _device_pred(gpmodel, X_full, handle)
+    _, _, mo, so = _device_pred(gpmodel, X_sparse, handle)
+    best = _nanmax(handle, mo, so)
+    acq, acq_d = _sweep(handle, "poi", md, sdd, best, xi, mean.shape)
+    gpmodel._last_acq = acq_d if hasattr(gpmodel, "_last_pred") else None
+    return acq, (mean, sd)

@@ -1,0 +1,247 @@
+"""
+boptim.py -- ``boptimizer``: GP-based Bayesian optimisation on a grid.
+
+Host-side mirror of the reference's gpim/gpbayes/boptim.py:22-485 (SURVEY 8(a) rows a14-a15,
+8(b)): same constructor signature and kwargs, same public attributes (``indices_all``,
+``vals_all``, ``target_func_vals``, ``gp_predictions``, ``surrogate_model``) and methods.
+The surrogate is a ``gpim_amd.reconstructor`` (HIP engine); the acquisition sweep and the
+descending top-``batch_size`` ranking run on the GPU (gpimhip_acq / gpimhip_topk); the
+revisit / distance-memory filter, batch thinning and bookkeeping are small host loops as in the
+reference.  Ties in the ranking are resolved "larger flat index first" (the reference inherits
+numpy's unspecified introsort order).
+"""
+import types
+
+import numpy as np
+import torch
+from scipy import spatial
+
+from . import _lib, acqfunc, gprutils
+from .gpr import reconstructor
+
+_F64 = torch.float64
+
+
+class boptimizer:
+    """
+    Args mirror the reference: ``boptimizer(X_seed, y_seed, X_full, target_function,
+    acquisition_function='cb', exploration_steps=10, batch_size=100, batch_update=False,
+    kernel='RBF', lengthscale=None, sparse=False, indpoints=None, gp_iterations=1000, seed=0,
+    **kwargs)`` with kwargs verbose, use_gpu (ignored), learning_rate, jitter (default 1e-6),
+    isotropic, precision, alpha, beta, xi, dscale, batch_dscale, batch_out_max, gamma, memory,
+    exit_strategy, mask, extent, simulate_measurement, y_true, save_checkpoints, filename.
+    """
+
+    def __init__(self, X_seed, y_seed, X_full, target_function, acquisition_function='cb',
+                 exploration_steps=10, batch_size=100, batch_update=False, kernel='RBF',
+                 lengthscale=None, sparse=False, indpoints=None, gp_iterations=1000, seed=0,
+                 **kwargs):
+        self.verbose = kwargs.get("verbose", 1)
+        self.use_gpu = kwargs.get("use_gpu", False)
+        learning_rate = kwargs.get("learning_rate", 5e-2)
+        jitter = kwargs.get("jitter", 1.0e-6)
+        isotropic = kwargs.get("isotropic", False)
+        self.precision = kwargs.get("precision", "double")
+        self.surrogate_model = reconstructor(
+            X_seed, y_seed, X_full, kernel, lengthscale, sparse, indpoints,
+            learning_rate, gp_iterations, self.use_gpu, self.verbose, seed,
+            isotropic=isotropic, precision=self.precision, jitter=jitter)
+        self.X_sparse = X_seed.copy()
+        self.y_sparse = y_seed.copy()
+        self.X_full = X_full
+        self.target_function = target_function
+        self.acquisition_function = acquisition_function
+        self.exploration_steps = exploration_steps
+        self.batch_update = batch_update
+        self.batch_size = batch_size
+        self.simulate_measurement = kwargs.get("simulate_measurement", False)
+        if self.simulate_measurement:
+            self.y_true = kwargs.get("y_true")
+            if self.y_true is None:
+                raise AssertionError("To simulate measurements, add ground truth ('y_true)")
+        self.extent = kwargs.get("extent", None)
+        self.alpha, self.beta = kwargs.get("alpha", 0), kwargs.get("beta", 1)
+        self.xi = kwargs.get("xi", 0.01)
+        self.dscale = kwargs.get("dscale", None)
+        self.batch_dscale = kwargs.get("batch_dscale", None)
+        self.batch_out_max = kwargs.get("batch_out_max", 10)
+        self.gamma = kwargs.get("gamma", 0.8)
+        self.points_mem = kwargs.get("memory", 10)
+        self.exit_strategy = kwargs.get("exit_strategy", 1)
+        self.mask = kwargs.get("mask", None)
+        self.save_checkpoints = kwargs.get("save_checkpoints", False)
+        self.filename = kwargs.get("filename", "./boptim_results")
+        self.indices_all, self.vals_all = [], []
+        self.target_func_vals, self.gp_predictions = [y_seed.copy()], []
+
+    # ------------------------------------------------------------------ posterior update
+    def update_posterior(self):
+        """Swap the training set in place and train again (warm-started hyper-parameters,
+        fresh Adam) -- boptim.py:239-251."""
+        X_new, y_new = gprutils.prepare_training_data(self.X_sparse, self.y_sparse, precision=self.precision)
+        self.surrogate_model.model.X = X_new
+        self.surrogate_model.model.y = y_new
+        self.surrogate_model.train(verbose=self.verbose)
+
+    def evaluate_function(self, indices, y_measured=None):
+        """Evaluate the target at the new point(s) and refresh the sparse grid (boptim.py:253-276)."""
+        indices = [indices] if not self.batch_update else indices
+        for idx in indices:
+            pos = tuple(idx)
+            if self.simulate_measurement:
+                self.y_sparse[pos] = self.y_true[pos]
+            elif y_measured is not None:
+                self.y_sparse[pos] = y_measured[pos]
+            else:
+                arg = pos if self.extent is None else tuple(i + e[0] for i, e in zip(idx, self.extent))
+                self.y_sparse[pos] = self.target_function(arg)
+        self.X_sparse = gprutils.get_sparse_grid(self.y_sparse, self.extent)
+        self.target_func_vals.append(self.y_sparse.copy())
+
+    # ------------------------------------------------------------------ ranking
+    def _rank(self, acq):
+        """Descending top-``batch_size`` of the acquisition map on the GPU.  Without a mask NaNs
+        rank first (np.argsort puts them last, the reference then reverses); with a mask the
+        product mask*acq is ranked and NaNs are dropped (boptim.py:303-315)."""
+        sm = self.surrogate_model
+        handle = sm._handle
+        acq_d = getattr(sm, "_last_acq", None)
+        if acq_d is None or acq_d.numel() != acq.size:
+            acq_d = torch.as_tensor(np.ascontiguousarray(acq), dtype=_F64).reshape(-1).to(handle.device)
+        keep_nan = 1
+        if self.mask is not None:
+            mask_d = torch.as_tensor(np.ascontiguousarray(self.mask), dtype=_F64).reshape(-1).to(handle.device)
+            acq_d = mask_d * acq_d
+            keep_nan = 0
+        sm._last_acq = None
+        k = int(min(self.batch_size, acq_d.numel()))
+        vals = torch.empty((k,), dtype=_F64, device=handle.device)
+        idx = torch.empty((k,), dtype=torch.int64, device=handle.device)
+        cnt = torch.zeros((1,), dtype=torch.int64, device=handle.device)
+        _lib.check(handle.lib.gpimhip_topk(handle.h, _lib.ptr(acq_d.contiguous()), acq_d.numel(), k, keep_nan,
+                                           _lib.ptr(vals), _lib.ptr(idx), _lib.ptr(cnt)))
+        n = int(cnt.item())
+        flat = idx[:n].cpu().numpy()
+        vals_list = vals[:n].cpu().numpy().tolist()
+        indices_list = np.stack(np.unravel_index(flat, acq.shape), axis=-1).tolist()
+        return vals_list, indices_list
+
+    def next_point(self):
+        """Acquisition sweep + ranking (+ batch thinning) -- boptim.py:278-324."""
+        if self.verbose:
+            print("Computing acquisition function...")
+        sm = self.surrogate_model
+        sm._last_acq = None
+        af = self.acquisition_function
+        if af == 'cb':
+            acq, pred = acqfunc.confidence_bound(sm, self.X_full, alpha=self.alpha, beta=self.beta)
+        elif af == 'ei':
+            acq, pred = acqfunc.expected_improvement(sm, self.X_full, self.X_sparse, xi=self.xi)
+        elif af == 'poi':
+            acq, pred = acqfunc.probability_of_improvement(sm, self.X_full, self.X_sparse, xi=self.xi)
+        elif isinstance(af, types.FunctionType):
+            acq, pred = af(sm, self.X_full, self.X_sparse)
+            sm._last_acq = None
+        else:
+            raise NotImplementedError(
+                "Choose between 'cb', 'ei', and 'poi' acquisition functions or define your own")
+        self.gp_predictions.append(pred)
+        vals_list, indices_list = self._rank(np.asarray(acq))
+        if not self.batch_update:
+            return vals_list, indices_list
+        radius = self.batch_dscale
+        if radius is None:
+            radius = sm.model.kernel.lengthscale.mean().item()
+        return self.update_points(vals_list, indices_list, radius)
+
+    def update_points(self, acqfunc_values, indices, dscale):
+        """Thin a ranked batch so that kept points are farther than ``dscale`` apart
+        (cKDTree ball queries), pad with random members of the batch -- boptim.py:326-376."""
+        _, val = self.checkvalues(indices, acqfunc_values)
+        first = np.where(np.array(acqfunc_values) == val)[0][0]
+        vals = np.array(acqfunc_values)[first:]
+        pts = np.vstack(indices)[first:]
+        vals_orig = vals.copy()
+        floor = vals.min()
+        tree = spatial.cKDTree(pts)
+        kept_vals, kept_ids = [], []
+        cur = int(np.argmax(vals))
+        while vals[cur] > floor - 1:
+            kept_vals.append(vals[cur])
+            kept_ids.append(cur)
+            vals[tree.query_ball_point(pts[cur], dscale)] = floor - 1
+            cur = int(np.argmax(vals))
+        kept_vals = kept_vals[:self.batch_out_max]
+        out = pts[kept_ids].tolist()[:self.batch_out_max]
+        if len(out) < self.batch_out_max:
+            if self.verbose == 2:
+                print("Adding {} random indices".format(self.batch_out_max - len(out)))
+            rnd = np.random.randint(0, len(vals), self.batch_out_max - len(out))
+            out.extend(pts[rnd].tolist())
+            kept_vals.extend(vals_orig[rnd].tolist())
+        return kept_vals, out
+
+    def checkvalues(self, idx_list, val_list):
+        """First ranked point that was not queried before and is not within the decaying
+        distance memory of the last ``memory`` queried points -- boptim.py:378-429."""
+        dscale = 0 if self.dscale is None else self.dscale
+
+        def in_memory(idx):
+            recent = self.indices_all[-self.points_mem:]
+            dists = [np.linalg.norm(np.array(idx) - np.array(p)) for p in recent][::-1]
+            limits = [dscale * self.gamma ** i for i in range(len(recent))]
+            return any(not (d > l) for d, l in zip(dists, limits))
+
+        pos = 0
+        if self.verbose == 2:
+            print('Acquisition function max value {} at {}'.format(val_list[pos], idx_list[pos]))
+        if len(self.indices_all) == 0:
+            return idx_list[pos], val_list[pos]
+        while any(p == idx_list[pos] for p in self.indices_all) or in_memory(idx_list[pos]):
+            if self.verbose == 2:
+                print("Finding the next max point...")
+            pos += 1
+            if pos == len(idx_list):
+                pos = np.random.randint(0, len(idx_list)) if self.exit_strategy else -1
+                if self.verbose == 2:
+                    print('Index out of list. Exiting with acquisition function value {} at {}'.format(
+                        val_list[pos], idx_list[pos]))
+                break
+            if self.verbose == 2:
+                print('Acquisition function max value {} at {}'.format(val_list[pos], idx_list[pos]))
+        return idx_list[pos], val_list[pos]
+
+    # ------------------------------------------------------------------ loop
+    def single_step(self, *args):
+        e = args[0]
+        if self.verbose:
+            print("\nExploration step {} / {}".format(e + 1, self.exploration_steps))
+        if e == 0:
+            self.surrogate_model.train()
+        vals, inds = self.next_point()
+        if not self.batch_update:
+            inds, vals = self.checkvalues(inds, vals)
+        self.evaluate_function(inds)
+        self.update_posterior()
+        if isinstance(vals, float):
+            self.indices_all.append(inds)
+            self.vals_all.append(vals)
+        else:
+            self.indices_all.extend(inds)
+            self.vals_all.extend(vals)
+
+    def run(self):
+        for i in range(self.exploration_steps):
+            self.single_step(i)
+            if self.save_checkpoints:
+                self.save_results()
+        self.save_results()
+        if self.verbose:
+            print("\nExploration completed")
+
+    def save_results(self, *args):
+        """np.save of {'gp_pred','func_val','inds_all','vals_all'} (boptim.py:472-485)."""
+        filename = args[0] if args else self.filename
+        results = {'gp_pred': self.gp_predictions, 'func_val': self.target_func_vals,
+                   'inds_all': np.array(self.indices_all), 'vals_all': np.array(self.vals_all)}
+        np.save(filename + ".npy", results)

@@ -1,0 +1,496 @@
+// api.hip -- host side of libgpimhip: workspace, launch plans, blocked-algorithm drivers and the
+// extern "C" entry points declared in include/gpimhip.h.
+#include <math.h>
+#include <string.h>
+#include <algorithm>
+#include "common.hpp"
+
+// kernels implemented in the other translation units
+int launch_theta_raw(gpimhip_ctx* h, const gpimhip_model_t* m, const double* raw);
+int launch_kmat(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X, int64_t N, const double* Z,
+                int64_t M, const ThetaDev* theta, double diag_add, int use_theta_diag, double* out,
+                int64_t ld, int64_t rows_pad, int64_t cols_pad, int sym, int lower_only);
+int launch_potf2(gpimhip_ctx* h, double* A, int64_t ld, int kblk, int32_t* info);
+int launch_pad_copy(gpimhip_ctx* h, const double* src, int64_t n, double* dst, int64_t np);
+int launch_diag_inv_copy(gpimhip_ctx* h, double* A, int64_t ld, int nb);
+int launch_pad_matrix_in(gpimhip_ctx* h, const double* src, int64_t n, int64_t ld, double* dst, int64_t np);
+int launch_pad_matrix_out_lower(gpimhip_ctx* h, const double* src, int64_t np, double* dst, int64_t n, int64_t ld);
+int launch_trmv_lower(gpimhip_ctx* h, const double* L, int64_t ld, int64_t np, const double* y, double* z);
+int launch_gemv_t(gpimhip_ctx* h, const double* A, int64_t ld, int64_t nrows, int64_t ncols, const double* x,
+                  double* out, int tri);
+int launch_grad_reduce(gpimhip_ctx* h, const gpimhip_model_t* m, const double* Kinv, int64_t ld,
+                       const double* X, int64_t N, int nb, const double* alpha);
+int launch_finalize(gpimhip_ctx* h, const gpimhip_model_t* m, int64_t N, int64_t np, double* u, int do_adam,
+                    AdamStep st, double* loss_out, double* grad_out, double* hist_row);
+int launch_predict_var(gpimhip_ctx* h, int64_t ldp, int nb, int64_t m0, int64_t mcount, double* var_out);
+int launch_copy_slice(gpimhip_ctx* h, const double* src, double* dst, int64_t n);
+int launch_acq(gpimhip_ctx* h, int kind, const double* mean, const double* sd, int64_t M, double p0, double p1,
+               const double* mask, double* out);
+int launch_nanmax(gpimhip_ctx* h, const double* x, int64_t n, double* out);
+int launch_topk(gpimhip_ctx* h, const double* x, int64_t M, int k, int keep_nan, double* vals, int64_t* idx,
+                int64_t* count);
+
+static thread_local std::string g_err;
+void gpim_set_error(const std::string& s) { g_err = s; }
+
+#define OUTER_W 4    // outer Cholesky panel = 4 x 128 columns: trailing updates run with k-depth 512
+
+// ------------------------------------------------------------------------------------------
+// workspace
+// ------------------------------------------------------------------------------------------
+template <typename T>
+static int dev_alloc(gpimhip_ctx* h, T** p, int64_t count) {
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, (size_t)count * sizeof(T));
+    if (e != hipSuccess) {
+        gpim_set_error(std::string("hipMalloc failed: ") + hipGetErrorString(e));
+        return GPIMHIP_E_NOMEM;
+    }
+    *p = (T*)q;
+    h->bytes += count * (int64_t)sizeof(T);
+    return GPIMHIP_OK;
+}
+template <typename T>
+static void dev_free(gpimhip_ctx* h, T** p, int64_t count) {
+    if (*p) {
+        hipFree(*p);
+        h->bytes -= count * (int64_t)sizeof(T);
+        *p = nullptr;
+    }
+}
+
+static void ws_release_matrix(gpimhip_ctx* h) {
+    const int64_t np = h->np, nb = np / NB;
+    if (!np) return;
+    dev_free(h, &h->A, np * np);
+    dev_free(h, &h->B, np * np);
+    dev_free(h, &h->Tm, np * np);
+    dev_free(h, &h->dinv, nb * NB * NB);
+    dev_free(h, &h->ypad, np);
+    dev_free(h, &h->z, np);
+    dev_free(h, &h->alpha, np);
+    dev_free(h, &h->logdet_part, nb);
+    dev_free(h, &h->grad_part, nb * (nb + 1) / 2 * 8);
+    h->np = 0;
+}
+
+int ws_ensure(gpimhip_ctx* h, int64_t N) {
+    const int64_t np = pad_to(std::max<int64_t>(N, 1), NB);
+    if (np == h->np) return GPIMHIP_OK;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    ws_release_matrix(h);
+    const int64_t nb = np / NB;
+    GP_TRY(dev_alloc(h, &h->A, np * np));
+    GP_TRY(dev_alloc(h, &h->B, np * np));
+    GP_TRY(dev_alloc(h, &h->Tm, np * np));
+    GP_TRY(dev_alloc(h, &h->dinv, nb * NB * NB));
+    GP_TRY(dev_alloc(h, &h->ypad, np));
+    GP_TRY(dev_alloc(h, &h->z, np));
+    GP_TRY(dev_alloc(h, &h->alpha, np));
+    GP_TRY(dev_alloc(h, &h->logdet_part, nb));
+    GP_TRY(dev_alloc(h, &h->grad_part, nb * (nb + 1) / 2 * 8));
+    h->np = np;
+    return plan_ensure(h, (int)nb);
+}
+
+int ws_ensure_predict(gpimhip_ctx* h, int64_t np, int64_t mc) {
+    if (h->ks_rows == np && h->ks_cols == mc) return GPIMHIP_OK;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    dev_free(h, &h->Ks, h->ks_rows * h->ks_cols);
+    dev_free(h, &h->colpart, (h->ks_rows / NB) * h->ks_cols);
+    dev_free(h, &h->pred_tiles, h->pred_ntiles);
+    dev_free(h, &h->mean_tmp, h->ks_cols);
+    h->ks_rows = h->ks_cols = 0;
+    GP_TRY(dev_alloc(h, &h->Ks, np * mc));
+    GP_TRY(dev_alloc(h, &h->colpart, (np / NB) * mc));
+    GP_TRY(dev_alloc(h, &h->mean_tmp, mc));
+    // tile list of the variance product W = L^-1 K*: 8x8 patches, longest k-ranges first
+    const int nb = (int)(np / NB), nc = (int)(mc / NB);
+    std::vector<TileDesc> tl;
+    tl.reserve((size_t)nb * nc);
+    for (int ig = (nb - 1) / 8; ig >= 0; --ig)
+        for (int jg = 0; jg <= (nc - 1) / 8; ++jg)
+            for (int ci = std::min(nb - 1, ig * 8 + 7); ci >= ig * 8; --ci)
+                for (int cj = jg * 8; cj < std::min(nc, jg * 8 + 8); ++cj) tl.push_back({ci, cj, 0, ci + 1});
+    h->pred_ntiles = (int64_t)tl.size();
+    GP_TRY(dev_alloc(h, &h->pred_tiles, h->pred_ntiles));
+    HIP_TRY(hipMemcpy(h->pred_tiles, tl.data(), tl.size() * sizeof(TileDesc), hipMemcpyHostToDevice));
+    h->ks_rows = np;
+    h->ks_cols = mc;
+    return GPIMHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// launch plans (tile lists) for a matrix of nb x nb blocks
+// ------------------------------------------------------------------------------------------
+static void lower_patch_order(std::vector<TileDesc>& out, int lo, int hi, int kb0, int kb1) {
+    // lower-triangular tile set {(i,j): lo <= j <= i < hi} in 8x8 patches (operand-panel reuse in L2)
+    for (int ig = lo / 8; ig <= (hi - 1) / 8; ++ig)
+        for (int jg = lo / 8; jg <= ig; ++jg)
+            for (int i = std::max(lo, ig * 8); i < std::min(hi, ig * 8 + 8); ++i)
+                for (int j = std::max(lo, jg * 8); j < std::min(hi, jg * 8 + 8); ++j)
+                    if (j <= i) out.push_back({i, j, kb0, kb1});
+}
+
+struct TriNode { int lo, mid, hi; };
+static int tri_build(int lo, int hi, std::vector<std::vector<TriNode>>& levels) {
+    if (hi - lo <= 1) return 0;
+    const int mid = lo + (hi - lo + 1) / 2;
+    const int hl = tri_build(lo, mid, levels), hr = tri_build(mid, hi, levels);
+    const int ht = 1 + std::max(hl, hr);
+    if ((int)levels.size() < ht) levels.resize(ht);
+    levels[ht - 1].push_back({lo, mid, hi});
+    return ht;
+}
+
+int plan_ensure(gpimhip_ctx* h, int nb) {
+    LinalgPlan& P = h->plan;
+    if (P.nb == nb) return GPIMHIP_OK;
+    if (P.d_tiles) { hipFree(P.d_tiles); P.d_tiles = nullptr; }
+    std::vector<TileDesc> tl;
+    auto mark = [&](size_t start) { return PlanRange{(int64_t)start, (int32_t)(tl.size() - start)}; };
+    P.trsm.assign(nb, {0, 0});
+    P.inner.assign(nb, {0, 0});
+    P.trail.assign(nb, {0, 0});
+    P.trail_kb0.assign(nb, 0);
+    for (int k = 0; k < nb; ++k) {
+        const int p0 = (k / OUTER_W) * OUTER_W, p1 = std::min(p0 + OUTER_W, nb);
+        size_t s = tl.size();
+        for (int i = k + 1; i < nb; ++i) tl.push_back({i, k, k, k + 1});
+        P.trsm[k] = mark(s);
+        s = tl.size();
+        for (int i = k + 1; i < nb; ++i)
+            for (int j = k + 1; j < std::min(p1, i + 1); ++j) tl.push_back({i, j, k, k + 1});
+        P.inner[k] = mark(s);
+        if (k == p1 - 1 && p1 < nb) {
+            s = tl.size();
+            lower_patch_order(tl, p1, nb, p0, p1);
+            P.trail[k] = mark(s);
+            P.trail_kb0[k] = p0;
+        }
+    }
+    // triangular inversion, bottom-up by subtree height
+    std::vector<std::vector<TriNode>> levels;
+    tri_build(0, nb, levels);
+    P.tri_t.clear();
+    P.tri_x.clear();
+    for (auto& lv : levels) {
+        size_t s = tl.size();
+        for (auto& nd : lv)
+            for (int ci = nd.mid; ci < nd.hi; ++ci)
+                for (int cj = nd.lo; cj < nd.mid; ++cj) tl.push_back({ci, cj, cj, nd.mid});
+        P.tri_t.push_back(mark(s));
+        s = tl.size();
+        for (auto& nd : lv)
+            for (int ci = nd.hi - 1; ci >= nd.mid; --ci)
+                for (int cj = nd.lo; cj < nd.mid; ++cj) tl.push_back({ci, cj, nd.mid, ci + 1});
+        P.tri_x.push_back(mark(s));
+    }
+    // K^-1 = L^-T L^-1 (lower): k-range [ci, nb), longest first
+    {
+        size_t s = tl.size();
+        for (int ci = 0; ci < nb; ++ci)
+            for (int cj = 0; cj <= ci; ++cj) tl.push_back({ci, cj, ci, nb});
+        P.lauum = mark(s);
+    }
+    P.n_tiles = (int64_t)tl.size();
+    void* q = nullptr;
+    HIP_TRY(hipMalloc(&q, std::max<size_t>(tl.size(), 1) * sizeof(TileDesc)));
+    P.d_tiles = (TileDesc*)q;
+    HIP_TRY(hipMemcpy(P.d_tiles, tl.data(), tl.size() * sizeof(TileDesc), hipMemcpyHostToDevice));
+    P.nb = nb;
+    return GPIMHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// blocked drivers
+// ------------------------------------------------------------------------------------------
+static GemmArgs gemm_args(const double* A, int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc,
+                          double alpha, double beta, const TileDesc* tiles, int n) {
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
+    g.alpha = alpha; g.beta = beta; g.tiles = tiles; g.ntiles = n;
+    return g;
+}
+
+// right-looking blocked Cholesky, lower, in place.  Per 128-column step: potf2 (+inverse) on the
+// diagonal block, panel solve as GEMM with the inverse, update of the remaining columns of the
+// current 512-wide outer panel; after the last column of an outer panel one SYRK-shaped trailing
+// update with k-depth 512 (keeps the update MFMA-bound instead of HBM-bound on the C tiles).
+int launch_potrf(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_t* info) {
+    const int nb = (int)(np / NB);
+    GP_TRY(plan_ensure(h, nb));
+    const LinalgPlan& P = h->plan;
+    for (int k = 0; k < nb; ++k) {
+        GP_TRY(launch_potf2(h, A, ld, k, info));
+        if (P.trsm[k].n) {
+            GemmArgs g = gemm_args(A, ld, h->dinv, NB, A, ld, 1.0, 0.0, P.d_tiles + P.trsm[k].off, P.trsm[k].n);
+            g.b_coff = -k;            // dinv is a (nb*128) x 128 matrix: block (k, 0)
+            GP_TRY(launch_gemm(h, false, false, EPI_STORE, g));
+        }
+        if (P.inner[k].n) {
+            GemmArgs g = gemm_args(A, ld, A, ld, A, ld, -1.0, 1.0, P.d_tiles + P.inner[k].off, P.inner[k].n);
+            GP_TRY(launch_gemm(h, false, false, EPI_STORE, g));
+        }
+        if (P.trail[k].n) {
+            GemmArgs g = gemm_args(A, ld, A, ld, A, ld, -1.0, 1.0, P.d_tiles + P.trail[k].off, P.trail[k].n);
+            GP_TRY(launch_gemm(h, false, false, EPI_STORE, g));
+        }
+    }
+    return GPIMHIP_OK;
+}
+
+// in-place inverse of the lower-triangular factor: recursive halving, all nodes of one subtree
+// height in one launch pair:  T = L21 * X11 ;  X21 = -X22 * T.
+int launch_trtri(gpimhip_ctx* h, double* A, double* Tm, int64_t np, int64_t ld) {
+    const int nb = (int)(np / NB);
+    GP_TRY(plan_ensure(h, nb));
+    const LinalgPlan& P = h->plan;
+    GP_TRY(launch_diag_inv_copy(h, A, ld, nb));
+    for (size_t lv = 0; lv < P.tri_t.size(); ++lv) {
+        GemmArgs g1 = gemm_args(A, ld, A, ld, Tm, ld, 1.0, 0.0, P.d_tiles + P.tri_t[lv].off, P.tri_t[lv].n);
+        GP_TRY(launch_gemm(h, false, true, EPI_STORE, g1));
+        GemmArgs g2 = gemm_args(A, ld, Tm, ld, A, ld, -1.0, 0.0, P.d_tiles + P.tri_x[lv].off, P.tri_x[lv].n);
+        GP_TRY(launch_gemm(h, false, true, EPI_STORE, g2));
+    }
+    return GPIMHIP_OK;
+}
+
+// B(lower) = A^T A for lower-triangular A (= L^-1): K^-1.
+int launch_lauum(gpimhip_ctx* h, const double* A, double* B, int64_t np, int64_t ld) {
+    const int nb = (int)(np / NB);
+    GP_TRY(plan_ensure(h, nb));
+    const LinalgPlan& P = h->plan;
+    GemmArgs g = gemm_args(A, ld, A, ld, B, ld, 1.0, 0.0, P.d_tiles + P.lauum.off, P.lauum.n);
+    return launch_gemm(h, true, true, EPI_STORE, g);
+}
+
+static int check_model(const gpimhip_model_t* m) {
+    if (!m || m->dim < 1 || m->dim > GPIMHIP_MAX_DIM || (m->n_ls != 1 && m->n_ls != m->dim) ||
+        m->kernel < 0 || m->kernel > GPIMHIP_KERNEL_RQ) {
+        gpim_set_error("invalid gpimhip_model_t");
+        return GPIMHIP_E_BADARG;
+    }
+    return GPIMHIP_OK;
+}
+
+// Everything needed at the current u: theta, K, L, L^-1, z, alpha.  (Shared by fit and predict.)
+static int factor_at_u(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X, const double* y, int64_t N,
+                       const double* u) {
+    const int64_t np = h->np;
+    GP_TRY(launch_theta(h, m, u));
+    GP_TRY(launch_kmat(h, m, X, N, nullptr, N, h->theta, 0.0, 1, h->A, np, np, np, 1, 1));
+    GP_TRY(launch_potrf(h, h->A, np, np, h->info));
+    GP_TRY(launch_trtri(h, h->A, h->Tm, np, np));
+    GP_TRY(launch_trmv_lower(h, h->A, np, np, h->ypad, h->z));
+    GP_TRY(launch_gemv_t(h, h->A, np, np, np, h->z, h->alpha, 1));
+    (void)y;
+    return GPIMHIP_OK;
+}
+
+static int loss_grad_at_u(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X, const double* y, int64_t N,
+                          double* u, int do_adam, AdamStep st, double* loss_out, double* grad_out,
+                          double* hist_row) {
+    const int64_t np = h->np;
+    GP_TRY(factor_at_u(h, m, X, y, N, u));
+    GP_TRY(launch_lauum(h, h->A, h->B, np, np));
+    GP_TRY(launch_grad_reduce(h, m, h->B, np, X, N, (int)(np / NB), h->alpha));
+    GP_TRY(launch_finalize(h, m, N, np, u, do_adam, st, loss_out, grad_out, hist_row));
+    return GPIMHIP_OK;
+}
+
+static int finish_and_check(gpimhip_ctx* h) {
+    int32_t info = 0;
+    HIP_TRY(hipMemcpyAsync(&info, h->info, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (info != 0) {
+        gpim_set_error("cholesky: the input is not positive-definite (leading minor of order " +
+                       std::to_string(info) + ")");
+        return GPIMHIP_E_NOT_PD;
+    }
+    return GPIMHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* gpimhip_last_error(void) { return g_err.c_str(); }
+int gpimhip_version(void) { return 100; }
+
+int gpimhip_create(gpimhip_handle* out, int device, void* hip_stream) {
+    if (!out) return GPIMHIP_E_BADARG;
+    HIP_TRY(hipSetDevice(device));
+    gpimhip_ctx* h = new gpimhip_ctx();
+    h->device = device;
+    h->stream = (hipStream_t)hip_stream;     // NULL = the device's default (null) stream
+    int rc = GPIMHIP_OK;
+    if ((rc = dev_alloc(h, &h->theta, 1)) || (rc = dev_alloc(h, &h->adam_m, MAXP)) ||
+        (rc = dev_alloc(h, &h->adam_v, MAXP)) || (rc = dev_alloc(h, &h->scratch, 4 * MAXP)) ||
+        (rc = dev_alloc(h, &h->info, 4))) {
+        delete h;
+        return rc;
+    }
+    hipMemsetAsync(h->info, 0, 4 * sizeof(int32_t), h->stream);
+    *out = h;
+    return GPIMHIP_OK;
+}
+
+int gpimhip_destroy(gpimhip_handle h) {
+    if (!h) return GPIMHIP_OK;
+    hipSetDevice(h->device);
+    hipStreamSynchronize(h->stream);
+    ws_release_matrix(h);
+    dev_free(h, &h->Ks, h->ks_rows * h->ks_cols);
+    dev_free(h, &h->colpart, (h->ks_rows / NB) * h->ks_cols);
+    dev_free(h, &h->pred_tiles, h->pred_ntiles);
+    dev_free(h, &h->mean_tmp, h->ks_cols);
+    dev_free(h, &h->keys, h->keys_cap);
+    dev_free(h, &h->theta, 1);
+    dev_free(h, &h->adam_m, MAXP);
+    dev_free(h, &h->adam_v, MAXP);
+    dev_free(h, &h->scratch, 4 * MAXP);
+    dev_free(h, &h->info, 4);
+    if (h->plan.d_tiles) hipFree(h->plan.d_tiles);
+    delete h;
+    return GPIMHIP_OK;
+}
+
+int64_t gpimhip_workspace_bytes(gpimhip_handle h) { return h ? h->bytes : 0; }
+
+int gpimhip_sync(gpimhip_handle h) {
+    if (!h) return GPIMHIP_E_BADARG;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return GPIMHIP_OK;
+}
+
+int gpimhip_kmat(gpimhip_handle h, const gpimhip_model_t* m, const double* X, int64_t N, const double* Z,
+                 int64_t M, const double* theta, double diag_add, double* out, int64_t ld) {
+    if (!h || !X || !theta || !out || N < 1) return GPIMHIP_E_BADARG;
+    GP_TRY(check_model(m));
+    HIP_TRY(hipSetDevice(h->device));
+    const bool sym = (Z == nullptr);
+    const int64_t Mv = sym ? N : M;
+    if (Mv < 1 || ld < Mv) return GPIMHIP_E_BADARG;
+    GP_TRY(launch_theta_raw(h, m, theta));
+    // tiles are 128x128: build into a padded scratch and copy out the valid part
+    const int64_t rp = pad_to(N, NB), cp = pad_to(Mv, NB);
+    GP_TRY(ws_ensure_predict(h, rp, cp));
+    GP_TRY(launch_kmat(h, m, X, N, sym ? nullptr : Z, Mv, h->theta, diag_add, 0, h->Ks, cp, rp, cp, sym ? 1 : 0, 0));
+    HIP_TRY(hipMemcpy2DAsync(out, (size_t)ld * sizeof(double), h->Ks, (size_t)cp * sizeof(double),
+                             (size_t)Mv * sizeof(double), (size_t)N, hipMemcpyDeviceToDevice, h->stream));
+    return GPIMHIP_OK;
+}
+
+int gpimhip_potrf(gpimhip_handle h, double* A, int64_t n, int64_t ld, int32_t* info) {
+    if (!h || !A || n < 1 || ld < n || !info) return GPIMHIP_E_BADARG;
+    HIP_TRY(hipSetDevice(h->device));
+    GP_TRY(ws_ensure(h, n));
+    const int64_t np = h->np;
+    HIP_TRY(hipMemsetAsync(info, 0, sizeof(int32_t), h->stream));
+    GP_TRY(launch_pad_matrix_in(h, A, n, ld, h->A, np));
+    GP_TRY(launch_potrf(h, h->A, np, np, info));
+    GP_TRY(launch_pad_matrix_out_lower(h, h->A, np, A, n, ld));
+    return GPIMHIP_OK;
+}
+
+int gpimhip_nll_grad(gpimhip_handle h, const gpimhip_model_t* m, const double* X, const double* y, int64_t N,
+                     const double* u, double* loss_out, double* grad_out) {
+    if (!h || !X || !y || !u || N < 1) return GPIMHIP_E_BADARG;
+    GP_TRY(check_model(m));
+    HIP_TRY(hipSetDevice(h->device));
+    GP_TRY(ws_ensure(h, N));
+    HIP_TRY(hipMemsetAsync(h->info, 0, sizeof(int32_t), h->stream));
+    GP_TRY(launch_pad_copy(h, y, N, h->ypad, h->np));
+    AdamStep st;
+    memset(&st, 0, sizeof(st));
+    GP_TRY(loss_grad_at_u(h, m, X, y, N, const_cast<double*>(u), 0, st, loss_out, grad_out, nullptr));
+    return finish_and_check(h);
+}
+
+int gpimhip_fit_exact(gpimhip_handle h, const gpimhip_model_t* m, const double* X, const double* y, int64_t N,
+                      double* u_inout, double lr, int32_t T, double* hist_out, double* loss_out) {
+    if (!h || !X || !y || !u_inout || N < 1 || T < 0) return GPIMHIP_E_BADARG;
+    GP_TRY(check_model(m));
+    HIP_TRY(hipSetDevice(h->device));
+    GP_TRY(ws_ensure(h, N));
+    const int P = 2 + m->n_ls + (m->kernel == GPIMHIP_KERNEL_RQ ? 1 : 0);
+    HIP_TRY(hipMemsetAsync(h->info, 0, sizeof(int32_t), h->stream));
+    HIP_TRY(hipMemsetAsync(h->adam_m, 0, MAXP * sizeof(double), h->stream));
+    HIP_TRY(hipMemsetAsync(h->adam_v, 0, MAXP * sizeof(double), h->stream));
+    GP_TRY(launch_pad_copy(h, y, N, h->ypad, h->np));
+    const double b1 = 0.9, b2 = 0.999;
+    for (int t = 1; t <= T; ++t) {
+        AdamStep st;
+        st.beta1 = b1; st.beta2 = b2; st.eps = 1e-8;
+        st.lr_over_bc1 = lr / (1.0 - pow(b1, (double)t));
+        st.bc2_sqrt = sqrt(1.0 - pow(b2, (double)t));
+        GP_TRY(loss_grad_at_u(h, m, X, y, N, u_inout, 1, st, loss_out ? loss_out + (t - 1) : nullptr, nullptr,
+                              hist_out ? hist_out + (int64_t)(t - 1) * P : nullptr));
+    }
+    return finish_and_check(h);
+}
+
+int gpimhip_predict_exact(gpimhip_handle h, const gpimhip_model_t* m, const double* X, const double* y, int64_t N,
+                          const double* u, const double* Xs, int64_t M, double* mean_out, double* var_out) {
+    if (!h || !X || !y || !u || !Xs || M < 1 || N < 1 || !mean_out || !var_out) return GPIMHIP_E_BADARG;
+    GP_TRY(check_model(m));
+    HIP_TRY(hipSetDevice(h->device));
+    GP_TRY(ws_ensure(h, N));
+    const int64_t np = h->np;
+    const int nb = (int)(np / NB);
+    HIP_TRY(hipMemsetAsync(h->info, 0, sizeof(int32_t), h->stream));
+    GP_TRY(launch_pad_copy(h, y, N, h->ypad, np));
+    GP_TRY(factor_at_u(h, m, X, y, N, u));
+    // chunk the test points so that the K* slab stays <= ~1 GiB
+    int64_t mc = pad_to(M, NB);
+    const int64_t cap = std::max<int64_t>(NB, ((int64_t)1 << 27) / np / NB * NB);
+    mc = std::min(mc, cap);
+    GP_TRY(ws_ensure_predict(h, np, mc));
+    for (int64_t m0 = 0; m0 < M; m0 += mc) {
+        const int64_t cnt = std::min(mc, M - m0);
+        const int64_t cpad = pad_to(cnt, NB);
+        GP_TRY(launch_kmat(h, m, X, N, Xs + m0 * m->dim, cnt, h->theta, 0.0, 0, h->Ks, mc, np, cpad, 0, 0));
+        GP_TRY(launch_gemv_t(h, h->Ks, mc, np, cpad, h->alpha, h->mean_tmp, 0));
+        GP_TRY(launch_copy_slice(h, h->mean_tmp, mean_out + m0, cnt));
+        GemmArgs g = gemm_args(h->A, np, h->Ks, mc, nullptr, 0, 1.0, 0.0, h->pred_tiles, 0);
+        g.colpart = h->colpart;
+        g.ld_colpart = mc;
+        // a ragged last chunk still sweeps all column tiles of the slab (stale columns are ignored)
+        g.ntiles = (int)h->pred_ntiles;
+        GP_TRY(launch_gemm(h, false, true, EPI_COLSUMSQ, g));
+        GP_TRY(launch_predict_var(h, mc, nb, m0, cnt, var_out));
+    }
+    return finish_and_check(h);
+}
+
+int gpimhip_acq(gpimhip_handle h, int32_t kind, const double* mean, const double* sd, int64_t M, double p0,
+                double p1, const double* mask, double* acq_out) {
+    if (!h || !mean || !sd || !acq_out || M < 1 || kind < 0 || kind > GPIMHIP_ACQ_POI) return GPIMHIP_E_BADARG;
+    HIP_TRY(hipSetDevice(h->device));
+    return launch_acq(h, kind, mean, sd, M, p0, p1, mask, acq_out);
+}
+
+int gpimhip_nanmax(gpimhip_handle h, const double* x, int64_t n, double* out) {
+    if (!h || !x || !out || n < 1) return GPIMHIP_E_BADARG;
+    HIP_TRY(hipSetDevice(h->device));
+    return launch_nanmax(h, x, n, out);
+}
+
+int gpimhip_topk(gpimhip_handle h, const double* acq, int64_t M, int32_t k, int32_t keep_nan, double* vals_out,
+                 int64_t* idx_out, int64_t* count_out) {
+    if (!h || !acq || !vals_out || !idx_out || !count_out || M < 1 || k < 1) return GPIMHIP_E_BADARG;
+    HIP_TRY(hipSetDevice(h->device));
+    if (h->keys_cap < M) {
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        dev_free(h, &h->keys, h->keys_cap);
+        h->keys_cap = 0;
+        GP_TRY(dev_alloc(h, &h->keys, M));
+        h->keys_cap = M;
+    }
+    return launch_topk(h, acq, M, k, keep_nan, vals_out, idx_out, count_out);
+}
+
+}  // extern "C"

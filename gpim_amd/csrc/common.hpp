@@ -1,0 +1,126 @@
+// common.hpp -- shared declarations of libgpimhip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/gpimhip.h"
+
+#define NB 128            // block size of every blocked algorithm (rows/cols of one tile)
+#define GEMM_BK 16        // k-depth of one LDS stage of the MFMA GEMM
+#define MAXP GPIMHIP_MAX_PARAMS
+
+void gpim_set_error(const std::string& s);
+
+#define HIP_TRY(expr)                                                              \
+    do {                                                                           \
+        hipError_t _e = (expr);                                                    \
+        if (_e != hipSuccess) {                                                    \
+            gpim_set_error(std::string(#expr) + ": " + hipGetErrorString(_e));     \
+            return GPIMHIP_E_HIP;                                                  \
+        }                                                                          \
+    } while (0)
+
+#define GP_TRY(expr)                      \
+    do {                                  \
+        int _r = (expr);                  \
+        if (_r != GPIMHIP_OK) return _r;  \
+    } while (0)
+
+// One output tile of a blocked GEMM-like launch: C[ci,cj] (op)= sum_{kb in [kb0,kb1)} A(ci,kb) B(kb,cj)
+struct TileDesc {
+    int32_t ci, cj, kb0, kb1;
+};
+
+// Device-resident constants of one model instance, refreshed from u each iteration.
+// Layout shared by host and device code.
+struct ThetaDev {
+    double var;                     // sigma^2
+    double ls[GPIMHIP_MAX_DIM];     // lengthscale per input dim (isotropic: replicated)
+    double inv_ls[GPIMHIP_MAX_DIM];
+    double noise;                   // sigma_n^2
+    double alpha;                   // RationalQuadratic scale_mixture
+    double diag_add;                // jitter + noise
+    // chain-rule factors d theta / d u (0 where the clipped sigmoid saturates)
+    double dvar_du;
+    double dls_du[GPIMHIP_MAX_DIM];
+    double dnoise_du;
+    double dalpha_du;
+};
+
+struct AdamStep {
+    double lr_over_bc1;     // lr / (1 - beta1^t)
+    double bc2_sqrt;        // sqrt(1 - beta2^t)
+    double beta1, beta2, eps;
+};
+
+// A cached launch plan: tile lists for every GEMM-like launch of potrf/trtri/lauum at a given nb.
+struct PlanRange { int64_t off; int32_t n; };
+
+struct LinalgPlan {
+    int nb = 0;
+    TileDesc* d_tiles = nullptr;          // device copy of all tile lists
+    int64_t n_tiles = 0;
+    // potrf
+    std::vector<PlanRange> trsm;          // per inner step k
+    std::vector<PlanRange> inner;         // per inner step k (may be empty)
+    std::vector<PlanRange> trail;         // per inner step k: non-empty only at the last column of an outer panel
+    std::vector<int> trail_kb0;           // first k-block of that outer panel
+    // trtri: per level two launches
+    std::vector<PlanRange> tri_t, tri_x;
+    // lauum
+    PlanRange lauum{0, 0};
+};
+
+struct gpimhip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    // workspace (sized for np = padded N)
+    int64_t np = 0;                 // padded matrix order the buffers are sized for
+    double* A = nullptr;            // np x np : K -> L -> L^-1
+    double* B = nullptr;            // np x np : K^-1 (lower)
+    double* Tm = nullptr;           // np x np : trtri temporary
+    double* dinv = nullptr;         // nb x 128 x 128 inverses of diagonal blocks
+    double* ypad = nullptr;         // np
+    double* z = nullptr;            // np  (L^-1 y)
+    double* alpha = nullptr;        // np  (K^-1 y)
+    double* logdet_part = nullptr;  // nb
+    double* grad_part = nullptr;    // ntiles_lower x 8
+    double* quad_part = nullptr;    // nb
+    ThetaDev* theta = nullptr;
+    double* adam_m = nullptr;       // MAXP
+    double* adam_v = nullptr;       // MAXP
+    double* scratch = nullptr;      // small: loss, grad (MAXP+1)
+    int32_t* info = nullptr;        // potrf status word
+    // prediction workspace
+    int64_t ks_rows = 0, ks_cols = 0;
+    double* Ks = nullptr;           // np x mc chunk of K(X, X*)
+    double* colpart = nullptr;      // nb x mc partial column sums of squares
+    double* mean_tmp = nullptr;     // mc
+    TileDesc* pred_tiles = nullptr; // tile list of the variance product
+    int64_t pred_ntiles = 0;
+    int64_t bytes = 0;
+    LinalgPlan plan;
+    // top-k scratch
+    unsigned long long* keys = nullptr;
+    int64_t keys_cap = 0;
+};
+
+static inline int64_t pad_to(int64_t n, int64_t m) { return (n + m - 1) / m * m; }
+
+// ---- drivers shared between translation units ----
+int ws_ensure(gpimhip_ctx* h, int64_t N);
+int ws_ensure_predict(gpimhip_ctx* h, int64_t np, int64_t mc);
+int plan_ensure(gpimhip_ctx* h, int nb);
+int launch_theta(gpimhip_ctx* h, const gpimhip_model_t* m, const double* u);
+
+enum GemmEpi { EPI_STORE = 0, EPI_COLSUMSQ = 1 };
+struct GemmArgs {
+    const double* A; int64_t lda; int a_roff, a_coff;
+    const double* B; int64_t ldb; int b_roff, b_coff;
+    double* C; int64_t ldc; int c_roff, c_coff;
+    double alpha, beta;
+    const TileDesc* tiles; int ntiles;
+    double* colpart; int64_t ld_colpart;   // EPI_COLSUMSQ: colpart[ci*ld + cj*128 + col]
+};
+int launch_gemm(gpimhip_ctx* h, bool a_km, bool b_km, int epi, const GemmArgs& g);

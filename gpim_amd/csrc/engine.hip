@@ -1,0 +1,660 @@
+// engine.hip -- the non-GEMM device kernels of the exact-GP hot path:
+//   theta_kernel        u -> constrained hyper-parameters + chain-rule factors       (row a4)
+//   kmat_kernel         LDS-tiled pairwise-distance + covariance build               (row a5)
+//   trmv / trmv_t       z = L^-1 y, alpha = L^-T z                                   (row a7)
+//   grad_reduce_kernel  fused  sum_ij (K^-1 - alpha alpha^T)_ij dK_ij/dtheta          (row a8)
+//   finalize_kernel     loss, d loss/du, Adam step, history row                      (rows a7-a10)
+//   predict helpers     mean = K*^T alpha, var = clamp(s2 - colsumsq, 0) + noise     (row a11)
+//   acq / nanmax / topk acquisition sweep and ranking                                (rows a13, a14)
+// Row labels refer to SURVEY.md section 8(a).  All reductions use fixed-shape trees so results are
+// bit-reproducible run to run.
+#include "kfun.hpp"
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+// ------------------------------------------------------------------------------------------
+// u -> theta   (torch.distributions transform_to(interval) = Affine o Sigmoid with clipping;
+//               transform_to(positive) = exp.  SURVEY App. A.2)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void interval_map(double u, double lo, double hi, double& val, double& dval) {
+    const double tiny = 2.2250738585072014e-308, eps = 2.220446049250313e-16;
+    double s = 1.0 / (1.0 + exp(-u));
+    double ds = s * (1.0 - s);
+    if (s < tiny) { s = tiny; ds = 0.0; }
+    if (s > 1.0 - eps) { s = 1.0 - eps; ds = 0.0; }
+    val = lo + (hi - lo) * s;
+    dval = (hi - lo) * ds;
+}
+
+__device__ void theta_from_u(const gpimhip_model_t& m, const double* u, ThetaDev& t) {
+    interval_map(u[0], m.amp_lo, m.amp_hi, t.var, t.dvar_du);
+    for (int k = 0; k < GPIMHIP_MAX_DIM; ++k) {
+        const int src = (m.n_ls == 1) ? 0 : k;
+        if (k < m.dim) {
+            interval_map(u[1 + src], m.ls_lo[src], m.ls_hi[src], t.ls[k], t.dls_du[k]);
+        } else {
+            t.ls[k] = 1.0;
+            t.dls_du[k] = 0.0;
+        }
+        t.inv_ls[k] = 1.0 / t.ls[k];
+    }
+    t.noise = exp(u[1 + m.n_ls]);
+    t.dnoise_du = t.noise;
+    if (m.kernel == GPIMHIP_KERNEL_RQ) {
+        t.alpha = exp(u[2 + m.n_ls]);
+        t.dalpha_du = t.alpha;
+    } else {
+        t.alpha = 1.0;
+        t.dalpha_du = 0.0;
+    }
+    t.diag_add = m.jitter + t.noise;
+}
+
+__global__ void theta_kernel(gpimhip_model_t m, const double* __restrict__ u, ThetaDev* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        ThetaDev t;
+        theta_from_u(m, u, t);
+        *out = t;
+    }
+}
+
+// raw = [s2, l_0.., alpha]  (operator-level gpimhip_kmat)
+__global__ void theta_raw_kernel(gpimhip_model_t m, const double* __restrict__ raw, ThetaDev* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        ThetaDev t;
+        t.var = raw[0];
+        for (int k = 0; k < GPIMHIP_MAX_DIM; ++k) {
+            t.ls[k] = (k < m.dim) ? raw[1 + ((m.n_ls == 1) ? 0 : k)] : 1.0;
+            t.inv_ls[k] = 1.0 / t.ls[k];
+            t.dls_du[k] = 0.0;
+        }
+        t.alpha = (m.kernel == GPIMHIP_KERNEL_RQ) ? raw[1 + m.n_ls] : 1.0;
+        t.noise = 0.0;
+        t.diag_add = 0.0;
+        t.dvar_du = t.dnoise_du = t.dalpha_du = 0.0;
+        *out = t;
+    }
+}
+
+int launch_theta(gpimhip_ctx* h, const gpimhip_model_t* m, const double* u) {
+    hipLaunchKernelGGL(theta_kernel, dim3(1), dim3(64), 0, h->stream, *m, u, h->theta);
+    HIP_TRY(hipGetLastError());
+    return GPIMHIP_OK;
+}
+int launch_theta_raw(gpimhip_ctx* h, const gpimhip_model_t* m, const double* raw) {
+    hipLaunchKernelGGL(theta_raw_kernel, dim3(1), dim3(64), 0, h->stream, *m, raw, h->theta);
+    HIP_TRY(hipGetLastError());
+    return GPIMHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// covariance build.  One workgroup = one 128x128 tile; the 128 + 128 scaled coordinate rows are
+// staged once in LDS, every thread produces an 8x8 patch and stores 16-byte pairs so that each
+// wave writes 4 rows x 256 contiguous bytes.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void lower_tile_from_linear(int q, int& i, int& j) {
+    i = (int)((sqrt(8.0 * (double)q + 1.0) - 1.0) * 0.5);
+    while ((int64_t)i * (i + 1) / 2 > q) --i;
+    while ((int64_t)(i + 1) * (i + 2) / 2 <= q) ++i;
+    j = q - (int)((int64_t)i * (i + 1) / 2);
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void kmat_kernel(const double* __restrict__ X, int64_t N,
+                                                   const double* __restrict__ Z, int64_t M, int d,
+                                                   const ThetaDev* __restrict__ th, double diag_add,
+                                                   int use_theta_diag, double* __restrict__ out, int64_t ld,
+                                                   int ntc, int sym, int lower_only) {
+    __shared__ double xa[128][5];
+    __shared__ double xz[128][5];
+    const int tid = threadIdx.x;
+    int ci, cj;
+    if (lower_only) lower_tile_from_linear(blockIdx.x, ci, cj);
+    else { ci = blockIdx.x / ntc; cj = blockIdx.x % ntc; }
+    const ThetaDev t = *th;
+    {
+        const bool isrow = tid < 128;
+        const int loc = tid & 127;
+        const int64_t g = (int64_t)(isrow ? ci : cj) * 128 + loc;
+        const double* src = isrow ? X : Z;
+        const int64_t lim = isrow ? N : M;
+        double s2 = 0.0;
+        double (*dst)[5] = isrow ? xa : xz;
+        for (int k = 0; k < GPIMHIP_MAX_DIM; ++k) {
+            double a = 0.0;
+            if (k < d && g < lim) a = src[g * d + k] / t.ls[k];
+            dst[loc][k] = a;
+            s2 += a * a;
+        }
+        dst[loc][4] = s2;
+    }
+    __syncthreads();
+    const double dadd = use_theta_diag ? t.diag_add : diag_add;
+    const int ty = tid >> 4, tx = tid & 15;
+#pragma unroll 2
+    for (int rr = 0; rr < 8; ++rr) {
+        const int r = ty + 16 * rr;
+        const int64_t gi = (int64_t)ci * 128 + r;
+        const double a0 = xa[r][0], a1 = xa[r][1], a2 = xa[r][2], a3 = xa[r][3], an = xa[r][4];
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+            d2 v;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int c = tx * 2 + 32 * cc + e;
+                const int64_t gj = (int64_t)cj * 128 + c;
+                double dot = a0 * xz[c][0];
+                dot = fma(a1, xz[c][1], dot);
+                dot = fma(a2, xz[c][2], dot);
+                dot = fma(a3, xz[c][3], dot);
+                double r2 = (an - 2.0 * dot) + xz[c][4];
+                r2 = clamp0_nan(r2);
+                double k = t.var * kfun_value<KIND>(r2, t.alpha);
+                if (gi >= N || gj >= M) k = (sym && gi == gj) ? 1.0 : 0.0;
+                else if (sym && gi == gj) k += dadd;
+                v[e] = k;
+            }
+            *reinterpret_cast<d2*>(out + gi * ld + (int64_t)cj * 128 + tx * 2 + 32 * cc) = v;
+        }
+    }
+}
+
+int launch_kmat(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X, int64_t N, const double* Z,
+                int64_t M, const ThetaDev* theta, double diag_add, int use_theta_diag, double* out,
+                int64_t ld, int64_t rows_pad, int64_t cols_pad, int sym, int lower_only) {
+    const int ntr = (int)(rows_pad / 128), ntc = (int)(cols_pad / 128);
+    const int64_t nblk = lower_only ? (int64_t)ntr * (ntr + 1) / 2 : (int64_t)ntr * ntc;
+    if (nblk <= 0) return GPIMHIP_OK;
+    const double* Zp = Z ? Z : X;
+    dim3 grid((unsigned)nblk), block(256);
+#define KM_LAUNCH(KIND)                                                                              \
+    hipLaunchKernelGGL((kmat_kernel<KIND>), grid, block, 0, h->stream, X, N, Zp, M, m->dim, theta,    \
+                       diag_add, use_theta_diag, out, ld, ntc, sym, lower_only)
+    switch (m->kernel) {
+        case GPIMHIP_KERNEL_RBF: KM_LAUNCH(GPIMHIP_KERNEL_RBF); break;
+        case GPIMHIP_KERNEL_MATERN52: KM_LAUNCH(GPIMHIP_KERNEL_MATERN52); break;
+        case GPIMHIP_KERNEL_RQ: KM_LAUNCH(GPIMHIP_KERNEL_RQ); break;
+        default: gpim_set_error("unknown kernel kind"); return GPIMHIP_E_BADARG;
+    }
+#undef KM_LAUNCH
+    HIP_TRY(hipGetLastError());
+    return GPIMHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// small utilities
+// ------------------------------------------------------------------------------------------
+__global__ void pad_copy_kernel(const double* __restrict__ src, int64_t n, double* __restrict__ dst, int64_t np) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < np) dst[i] = (i < n) ? src[i] : 0.0;
+}
+int launch_pad_copy(gpimhip_ctx* h, const double* src, int64_t n, double* dst, int64_t np) {
+    hipLaunchKernelGGL(pad_copy_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, h->stream, src, n, dst, np);
+    HIP_TRY(hipGetLastError());
+    return GPIMHIP_OK;
+}
+
+// A[k,k] <- dinv[k] for every diagonal block (leaves of the triangular inversion)
+__global__ __launch_bounds__(256) void diag_inv_copy_kernel(double* __restrict__ A, int64_t ld,
+                                                            const double* __restrict__ dinv) {
+    const int k = blockIdx.x;
+    double* dst = A + ((int64_t)k * NB) * ld + (int64_t)k * NB;
+    const double* src = dinv + (int64_t)k * NB * NB;
+    for (int e = threadIdx.x; e < NB * NB / 2; e += 256) {
+        const int r = e >> 6, c2 = (e & 63) * 2;
+        *reinterpret_cast<d2*>(dst + (int64_t)r * ld + c2) = *reinterpret_cast<const d2*>(src + r * NB + c2);
+    }
+}
+int launch_diag_inv_copy(gpimhip_ctx* h, double* A, int64_t ld, int nb) {
+    hipLaunchKernelGGL(diag_inv_copy_kernel, dim3(nb), dim3(256), 0, h->stream, A, ld, h->dinv);
+    HIP_TRY(hipGetLastError());
+    return GPIMHIP_OK;
+}
+
+// copy an n x n user matrix into / out of the padded workspace (identity padding)
+__global__ void pad_matrix_in_kernel(const double* __restrict__ src, int64_t n, int64_t lds_,
+                                     double* __restrict__ dst, int64_t np) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= np * np) return;
+    const int64_t r = idx / np, c = idx % np;
+    double v;
+    if (r < n && c < n) v = src[r * lds_ + c];
+    else v = (r == c) ? 1.0 : 0.0;
+    dst[idx] = v;
+}
+__global__ void pad_matrix_out_lower_kernel(const double* __restrict__ src, int64_t np,
+                                            double* __restrict__ dst, int64_t n, int64_t ldd) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * n) return;
+    const int64_t r = idx / n, c = idx % n;
+    if (c <= r) dst[r * ldd + c] = src[r * np + c];
+}
+int launch_pad_matrix_in(gpimhip_ctx* h, const double* src, int64_t n, int64_t ld, double* dst, int64_t np) {
+    hipLaunchKernelGGL(pad_matrix_in_kernel, dim3((unsigned)((np * np + 255) / 256)), dim3(256), 0, h->stream,
+                       src, n, ld, dst, np);
+    HIP_TRY(hipGetLastError());
+    return GPIMHIP_OK;
+}
+int launch_pad_matrix_out_lower(gpimhip_ctx* h, const double* src, int64_t np, double* dst, int64_t n, int64_t ld) {
+    hipLaunchKernelGGL(pad_matrix_out_lower_kernel, dim3((unsigned)((n * n + 255) / 256)), dim3(256), 0,
+                       h->stream, src, np, dst, n, ld);
+    HIP_TRY(hipGetLastError());
+    return GPIMHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// triangular matrix-vector products with L^-1 (lower, zeros above the diagonal inside blocks)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+    v += __shfl_xor(v, 32);
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 8);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 1);
+    return v;
+}
+
+// z[i] = sum_{j < jend(i)} L[i][j] * y[j];  one wave per row, 4 rows per workgroup
+__global__ __launch_bounds__(256) void trmv_lower_kernel(const double* __restrict__ L, int64_t ld, int64_t np,
+                                                         const double* __restrict__ y, double* __restrict__ z) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 4 + wave;
+    if (i >= np) return;
+    const int64_t jend = (i / NB + 1) * NB;
+    const double* row = L + i * ld;
+    double s = 0.0;
+    for (int64_t j = lane * 2; j < jend; j += 128) {
+        const d2 l = *reinterpret_cast<const d2*>(row + j);
+        const d2 v = *reinterpret_cast<const d2*>(y + j);
+        s = fma(l[0], v[0], s);
+        s = fma(l[1], v[1], s);
+    }
+    s = wave_sum(s);
+    if (lane == 0) z[i] = s;
+}
+
+// out[j] = sum_{i >= i0(j)} A[i][j] * x[i] for 64 columns per workgroup; tri != 0 starts at the
+// diagonal block of the column (A lower triangular), else at row 0.
+__global__ __launch_bounds__(256) void gemv_t_kernel(const double* __restrict__ A, int64_t ld, int64_t nrows,
+                                                     const double* __restrict__ x, double* __restrict__ out,
+                                                     int tri) {
+    __shared__ double red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t j = (int64_t)blockIdx.x * 64 + lane;
+    const int64_t i0 = tri ? ((int64_t)blockIdx.x * 64 / NB) * NB : 0;
+    double s = 0.0;
+    for (int64_t i = i0 + wave; i < nrows; i += 4) s = fma(A[i * ld + j], x[i], s);
+    red[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0) out[j] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+
+int launch_trmv_lower(gpimhip_ctx* h, const double* L, int64_t ld, int64_t np, const double* y, double* z) {
+    hipLaunchKernelGGL(trmv_lower_kernel, dim3((unsigned)((np + 3) / 4)), dim3(256), 0, h->stream, L, ld, np, y, z);
+    HIP_TRY(hipGetLastError());
+    return GPIMHIP_OK;
+}
+int launch_gemv_t(gpimhip_ctx* h, const double* A, int64_t ld, int64_t nrows, int64_t ncols, const double* x,
+                  double* out, int tri) {
+    hipLaunchKernelGGL(gemv_t_kernel, dim3((unsigned)(ncols / 64)), dim3(256), 0, h->stream, A, ld, nrows, x, out, tri);
+    HIP_TRY(hipGetLastError());
+    return GPIMHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// gradient reduction over the lower tiles of K^-1:
+//   w_ij = (2 - delta_ij) * (Kinv_ij - alpha_i alpha_j)
+//   S[0]      += w * k/s2                       -> d/d s2
+//   S[1+k]    += w * s2*h * (a_ik - a_jk)^2     -> d/d l_k  (times 1/l_k later)
+//   S[5]      += delta_ij * (Kinv_ii - alpha_i^2) -> d/d noise
+//   S[6]      += w * s2 * dk/dalpha / s2        -> d/d alpha (RQ)
+// ------------------------------------------------------------------------------------------
+template <int KIND>
+__global__ __launch_bounds__(256) void grad_reduce_kernel(const double* __restrict__ Kinv, int64_t ld,
+                                                          const double* __restrict__ X, int64_t N, int d,
+                                                          const double* __restrict__ alpha,
+                                                          const ThetaDev* __restrict__ th,
+                                                          double* __restrict__ part) {
+    __shared__ double xa[128][5];
+    __shared__ double xz[128][5];
+    __shared__ double al_r[128], al_c[128];
+    __shared__ double red[4][8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int ci, cj;
+    lower_tile_from_linear(blockIdx.x, ci, cj);
+    const ThetaDev t = *th;
+    {
+        const bool isrow = tid < 128;
+        const int loc = tid & 127;
+        const int64_t g = (int64_t)(isrow ? ci : cj) * 128 + loc;
+        double s2 = 0.0;
+        double (*dst)[5] = isrow ? xa : xz;
+        for (int k = 0; k < GPIMHIP_MAX_DIM; ++k) {
+            double a = 0.0;
+            if (k < d && g < N) a = X[g * d + k] / t.ls[k];
+            dst[loc][k] = a;
+            s2 += a * a;
+        }
+        dst[loc][4] = s2;
+        (isrow ? al_r : al_c)[loc] = (g < N) ? alpha[g] : 0.0;
+    }
+    __syncthreads();
+    double S[7] = {0, 0, 0, 0, 0, 0, 0};
+    const int ty = tid >> 4, tx = tid & 15;
+    for (int rr = 0; rr < 8; ++rr) {
+        const int r = ty + 16 * rr;
+        const int64_t gi = (int64_t)ci * 128 + r;
+        const double a0 = xa[r][0], a1 = xa[r][1], a2 = xa[r][2], a3 = xa[r][3], an = xa[r][4];
+        const double ali = al_r[r];
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+            const d2 kv = *reinterpret_cast<const d2*>(Kinv + gi * ld + (int64_t)cj * 128 + tx * 2 + 32 * cc);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int c = tx * 2 + 32 * cc + e;
+                const int64_t gj = (int64_t)cj * 128 + c;
+                if (gi >= N || gj > gi) continue;
+                const double g = kv[e] - ali * al_c[c];
+                const double w = (gi == gj) ? g : 2.0 * g;
+                double dot = a0 * xz[c][0];
+                dot = fma(a1, xz[c][1], dot);
+                dot = fma(a2, xz[c][2], dot);
+                dot = fma(a3, xz[c][3], dot);
+                double r2 = clamp0_nan((an - 2.0 * dot) + xz[c][4]);
+                const KVal kvv = kfun_grad<KIND>(r2, t.alpha);
+                S[0] = fma(w, kvv.e, S[0]);
+                const double wh = w * kvv.h;
+                const double d0 = a0 - xz[c][0], d1 = a1 - xz[c][1], d2_ = a2 - xz[c][2], d3 = a3 - xz[c][3];
+                S[1] = fma(wh, d0 * d0, S[1]);
+                S[2] = fma(wh, d1 * d1, S[2]);
+                S[3] = fma(wh, d2_ * d2_, S[3]);
+                S[4] = fma(wh, d3 * d3, S[4]);
+                if (gi == gj) S[5] += g;
+                if (KIND == GPIMHIP_KERNEL_RQ) S[6] = fma(w, kvv.ga, S[6]);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        const double v = wave_sum(S[k]);
+        if (lane == 0) red[wave][k] = v;
+    }
+    __syncthreads();
+    if (tid < 8) {
+        double v = 0.0;
+        if (tid < 7) v = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+        part[(int64_t)blockIdx.x * 8 + tid] = v;
+    }
+}
+
+int launch_grad_reduce(gpimhip_ctx* h, const gpimhip_model_t* m, const double* Kinv, int64_t ld,
+                       const double* X, int64_t N, int nb, const double* alpha) {
+    const int ntile = nb * (nb + 1) / 2;
+    dim3 grid(ntile), block(256);
+#define GR_LAUNCH(KIND)                                                                                   \
+    hipLaunchKernelGGL((grad_reduce_kernel<KIND>), grid, block, 0, h->stream, Kinv, ld, X, N, m->dim, alpha, \
+                       h->theta, h->grad_part)
+    switch (m->kernel) {
+        case GPIMHIP_KERNEL_RBF: GR_LAUNCH(GPIMHIP_KERNEL_RBF); break;
+        case GPIMHIP_KERNEL_MATERN52: GR_LAUNCH(GPIMHIP_KERNEL_MATERN52); break;
+        case GPIMHIP_KERNEL_RQ: GR_LAUNCH(GPIMHIP_KERNEL_RQ); break;
+        default: gpim_set_error("unknown kernel kind"); return GPIMHIP_E_BADARG;
+    }
+#undef GR_LAUNCH
+    HIP_TRY(hipGetLastError());
+    return GPIMHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// finalize: one workgroup.  Sums the partials in a fixed tree, forms loss and d loss/du, then
+// (fit mode) applies one torch.optim.Adam step to u and records the constrained values.
+// ------------------------------------------------------------------------------------------
+__device__ double block_sum_256(double v, double* red) {
+    const int tid = threadIdx.x;
+    red[tid] = v;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) red[tid] += red[tid + s];
+        __syncthreads();
+    }
+    const double r = red[0];
+    __syncthreads();
+    return r;
+}
+
+__global__ __launch_bounds__(256) void finalize_kernel(gpimhip_model_t m, int64_t N, int64_t np, int nb,
+                                                       int ntile, const double* __restrict__ grad_part,
+                                                       const double* __restrict__ z,
+                                                       const double* __restrict__ logdet_part,
+                                                       const ThetaDev* __restrict__ th, double* __restrict__ u,
+                                                       double* __restrict__ adam_m, double* __restrict__ adam_v,
+                                                       int do_adam, AdamStep st, double* __restrict__ loss_out,
+                                                       double* __restrict__ grad_out,
+                                                       double* __restrict__ hist_row) {
+    __shared__ double red[256];
+    __shared__ double S[8];
+    const int tid = threadIdx.x;
+    for (int k = 0; k < 7; ++k) {
+        double v = 0.0;
+        for (int q = tid; q < ntile; q += 256) v += grad_part[(int64_t)q * 8 + k];
+        v = block_sum_256(v, red);
+        if (tid == 0) S[k] = v;
+    }
+    double q2 = 0.0;
+    for (int64_t i = tid; i < np; i += 256) q2 = fma(z[i], z[i], q2);
+    q2 = block_sum_256(q2, red);
+    double lg = 0.0;
+    for (int k = tid; k < nb; k += 256) lg += logdet_part[k];
+    lg = block_sum_256(lg, red);
+    if (tid != 0) return;
+
+    const ThetaDev t = *th;
+    const int P = 2 + m.n_ls + (m.kernel == GPIMHIP_KERNEL_RQ ? 1 : 0);
+    double prior = log(m.amp_hi - m.amp_lo);
+    for (int k = 0; k < m.n_ls; ++k) prior += log(m.ls_hi[k] - m.ls_lo[k]);
+    const double loss = 0.5 * q2 + lg + 0.5 * (double)N * 1.8378770664093453 + prior;
+    double g[MAXP];
+    g[0] = 0.5 * S[0] * t.dvar_du;
+    if (m.n_ls == 1) {
+        double s = 0.0;
+        for (int k = 0; k < m.dim; ++k) s += S[1 + k];
+        g[1] = 0.5 * s * t.var / t.ls[0] * t.dls_du[0];
+    } else {
+        for (int k = 0; k < m.dim; ++k) g[1 + k] = 0.5 * S[1 + k] * t.var / t.ls[k] * t.dls_du[k];
+    }
+    g[1 + m.n_ls] = 0.5 * S[5] * t.dnoise_du;
+    if (m.kernel == GPIMHIP_KERNEL_RQ) g[2 + m.n_ls] = 0.5 * S[6] * t.var * t.dalpha_du;
+    if (loss_out) *loss_out = loss;
+    if (grad_out)
+        for (int k = 0; k < P; ++k) grad_out[k] = g[k];
+    if (do_adam) {
+        for (int k = 0; k < P; ++k) {
+            double mm = adam_m[k], vv = adam_v[k];
+            mm = mm + (g[k] - mm) * (1.0 - st.beta1);            // exp_avg.lerp_(grad, 1 - beta1)
+            vv = vv * st.beta2 + (1.0 - st.beta2) * g[k] * g[k]; // exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)
+            const double denom = sqrt(vv) / st.bc2_sqrt + st.eps;
+            u[k] = u[k] + (-st.lr_over_bc1) * (mm / denom);      // param.addcdiv_(exp_avg, denom, value=-step_size)
+            adam_m[k] = mm;
+            adam_v[k] = vv;
+        }
+        if (hist_row) {
+            ThetaDev tn;
+            theta_from_u(m, u, tn);
+            hist_row[0] = tn.var;
+            for (int k = 0; k < m.n_ls; ++k) hist_row[1 + k] = tn.ls[k];
+            hist_row[1 + m.n_ls] = tn.noise;
+            if (m.kernel == GPIMHIP_KERNEL_RQ) hist_row[2 + m.n_ls] = tn.alpha;
+        }
+    }
+}
+
+int launch_finalize(gpimhip_ctx* h, const gpimhip_model_t* m, int64_t N, int64_t np, double* u, int do_adam,
+                    AdamStep st, double* loss_out, double* grad_out, double* hist_row) {
+    const int nb = (int)(np / NB);
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, h->stream, *m, N, np, nb, nb * (nb + 1) / 2,
+                       h->grad_part, h->z, h->logdet_part, h->theta, u, h->adam_m, h->adam_v, do_adam, st,
+                       loss_out, grad_out, hist_row);
+    HIP_TRY(hipGetLastError());
+    return GPIMHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// prediction epilogue: var_j = clamp(s2 - sum_ci colpart[ci][j], 0) + noise
+// ------------------------------------------------------------------------------------------
+__global__ void predict_var_kernel(const double* __restrict__ colpart, int64_t ldp, int nb, int64_t m0,
+                                   int64_t mcount, const ThetaDev* __restrict__ th, double* __restrict__ var_out) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= mcount) return;
+    double q = 0.0;
+    for (int ci = 0; ci < nb; ++ci) q += colpart[(int64_t)ci * ldp + j];
+    const double v = clamp0_nan(th->var - q);
+    var_out[m0 + j] = v + th->noise;
+}
+__global__ void copy_slice_kernel(const double* __restrict__ src, double* __restrict__ dst, int64_t n) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) dst[j] = src[j];
+}
+int launch_predict_var(gpimhip_ctx* h, int64_t ldp, int nb, int64_t m0, int64_t mcount, double* var_out) {
+    hipLaunchKernelGGL(predict_var_kernel, dim3((unsigned)((mcount + 255) / 256)), dim3(256), 0, h->stream,
+                       h->colpart, ldp, nb, m0, mcount, h->theta, var_out);
+    HIP_TRY(hipGetLastError());
+    return GPIMHIP_OK;
+}
+int launch_copy_slice(gpimhip_ctx* h, const double* src, double* dst, int64_t n) {
+    hipLaunchKernelGGL(copy_slice_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, src, dst, n);
+    HIP_TRY(hipGetLastError());
+    return GPIMHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// acquisition sweep (acqfunc.py:11-92).  Phi / phi as scipy.stats.norm: ndtr(z) = erfc(-z/sqrt2)/2.
+// ------------------------------------------------------------------------------------------
+__global__ void acq_kernel(int kind, const double* __restrict__ mean, const double* __restrict__ sd, int64_t M,
+                           double p0, double p1, const double* __restrict__ mask, double* __restrict__ out) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= M) return;
+    const double mu = mean[j], s = sd[j];
+    double a;
+    if (kind == GPIMHIP_ACQ_CB) {
+        a = p0 * mu + p1 * s;
+    } else {
+        const double imp = mu - p0 - p1;
+        const double zz = imp / s;
+        const double cdf = 0.5 * erfc(-zz * 0.7071067811865476);
+        if (kind == GPIMHIP_ACQ_EI) {
+            const double pdf = exp(-0.5 * zz * zz) * 0.3989422804014327;
+            a = imp * cdf + s * pdf;
+        } else {
+            a = cdf;
+        }
+    }
+    if (mask) a = mask[j] * a;
+    out[j] = a;
+}
+int launch_acq(gpimhip_ctx* h, int kind, const double* mean, const double* sd, int64_t M, double p0, double p1,
+               const double* mask, double* out) {
+    hipLaunchKernelGGL(acq_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, h->stream, kind, mean, sd, M,
+                       p0, p1, mask, out);
+    HIP_TRY(hipGetLastError());
+    return GPIMHIP_OK;
+}
+
+// nanmax over n values, single workgroup (n is a grid size: <= a few 1e5)
+__global__ __launch_bounds__(1024) void nanmax_kernel(const double* __restrict__ x, int64_t n, double* __restrict__ out) {
+    __shared__ double red[1024];
+    const int tid = threadIdx.x;
+    double best = -INFINITY;
+    bool any = false;
+    for (int64_t i = tid; i < n; i += 1024) {
+        const double v = x[i];
+        if (v == v) { best = fmax(best, v); any = true; }
+    }
+    red[tid] = any ? best : -INFINITY;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if (tid < s) red[tid] = fmax(red[tid], red[tid + s]);
+        __syncthreads();
+    }
+    if (tid == 0) {
+        // all-NaN input: np.nanmax returns NaN (with a warning)
+        out[0] = (red[0] == -INFINITY) ? __builtin_nan("") : red[0];
+    }
+}
+int launch_nanmax(gpimhip_ctx* h, const double* x, int64_t n, double* out) {
+    hipLaunchKernelGGL(nanmax_kernel, dim3(1), dim3(1024), 0, h->stream, x, n, out);
+    HIP_TRY(hipGetLastError());
+    return GPIMHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// descending top-k by repeated arg-max inside one workgroup.  Keys are order-preserving 64-bit
+// images of the doubles; NaN ranks above +inf when keep_nan (np.argsort puts NaN last, the caller
+// reverses), and is excluded otherwise.  Ties: larger flat index first (= reversed stable sort).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long order_key(double v, int keep_nan) {
+    if (v != v) return keep_nan ? 0xFFFFFFFFFFFFFFFFull : 0ull;
+    unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    b = (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);
+    // reserve 0 for "excluded" and all-ones for NaN
+    if (b == 0ull) b = 1ull;
+    if (b == 0xFFFFFFFFFFFFFFFFull) b = 0xFFFFFFFFFFFFFFFEull;
+    return b;
+}
+__global__ void topk_keys_kernel(const double* __restrict__ x, int64_t M, int keep_nan,
+                                 unsigned long long* __restrict__ keys) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < M) keys[j] = order_key(x[j], keep_nan);
+}
+__global__ __launch_bounds__(1024) void topk_select_kernel(const double* __restrict__ x,
+                                                           unsigned long long* __restrict__ keys, int64_t M, int k,
+                                                           double* __restrict__ vals, int64_t* __restrict__ idx,
+                                                           int64_t* __restrict__ count) {
+    __shared__ unsigned long long rk[1024];
+    __shared__ int64_t ri[1024];
+    const int tid = threadIdx.x;
+    int64_t found = 0;
+    for (int r = 0; r < k; ++r) {
+        unsigned long long bk = 0ull;
+        int64_t bi = -1;
+        for (int64_t j = tid; j < M; j += 1024) {
+            const unsigned long long kk = keys[j];
+            if (kk > bk || (kk == bk && kk != 0ull && j > bi)) { bk = kk; bi = j; }
+        }
+        rk[tid] = bk;
+        ri[tid] = bi;
+        __syncthreads();
+        for (int s = 512; s > 0; s >>= 1) {
+            if (tid < s) {
+                const unsigned long long ok = rk[tid + s];
+                const int64_t oi = ri[tid + s];
+                if (ok > rk[tid] || (ok == rk[tid] && oi > ri[tid])) { rk[tid] = ok; ri[tid] = oi; }
+            }
+            __syncthreads();
+        }
+        const unsigned long long wk = rk[0];
+        const int64_t wi = ri[0];
+        __syncthreads();
+        if (wk == 0ull || wi < 0) break;
+        if (tid == 0) {
+            vals[r] = x[wi];
+            idx[r] = wi;
+            keys[wi] = 0ull;
+        }
+        found = r + 1;
+        __threadfence_block();
+        __syncthreads();
+    }
+    if (tid == 0) {
+        *count = found;
+        for (int r = (int)found; r < k; ++r) { vals[r] = __builtin_nan(""); idx[r] = -1; }
+    }
+}
+int launch_topk(gpimhip_ctx* h, const double* x, int64_t M, int k, int keep_nan, double* vals, int64_t* idx,
+                int64_t* count) {
+    hipLaunchKernelGGL(topk_keys_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, h->stream, x, M, keep_nan,
+                       h->keys);
+    hipLaunchKernelGGL(topk_select_kernel, dim3(1), dim3(1024), 0, h->stream, x, h->keys, M, k, vals, idx, count);
+    HIP_TRY(hipGetLastError());
+    return GPIMHIP_OK;
+}

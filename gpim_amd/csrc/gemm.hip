@@ -1,0 +1,186 @@
+// gemm.hip -- the fp64 MFMA tile engine of libgpimhip.
+//
+// One kernel template covers every O(N^3) stage of the exact-GP hot path
+// (SURVEY 8(a) rows a6, a8, a11): Cholesky panel solves and trailing SYRK updates,
+// the triangular inverse, K^-1 = L^-T L^-1 and the predictive-variance product
+// L^-1 K(X, X*).  Work is described by a list of 128x128 output tiles, each with its own
+// k-block range, so triangular operands simply get shorter ranges (no wasted MFMAs on
+// structural zeros) and the host can order the list for XCD/L2 locality.
+//
+// Tile engine: 256 threads = 4 waves (2x2), each wave owns a 64x64 sub-tile = 4x4
+// v_mfma_f64_16x16x4_f64 accumulators (128 VGPRs).  Operand tiles are staged
+// global -> registers -> LDS (double-buffered, one barrier per 16-deep k-step) in the
+// layout of their source so that every global access is a coalesced 16-byte load:
+//   "MK" operand (row-major, k contiguous):  lds[128][16+2]   fragment read is bank-conflict free
+//   "KM" operand (row-major, m contiguous):  lds[16][128+16]  likewise
+// v_mfma_f64_16x16x4_f64 lane maps (cdna_hip_programming.md section 3):
+//   A[l&15][l>>4], B[l>>4][l&15], C/D col = l&15, row = (l>>4) + 4*reg.
+#include "common.hpp"
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+#define LD_MK (GEMM_BK + 2)
+#define LD_KM (NB + 16)
+#define STAGE_ELEMS 2304            // 128*18 == 16*144
+static_assert(NB * LD_MK == STAGE_ELEMS && GEMM_BK * LD_KM == STAGE_ELEMS, "stage size");
+
+template <bool KM>
+__device__ __forceinline__ void stage_load(d2 (&r)[4], const double* __restrict__ base, int64_t ld,
+                                           int64_t mrow0, int64_t kcol0, int tid) {
+    // MK: tile element (m,k) lives at base[(mrow0+m)*ld + kcol0 + k]
+    // KM: tile element (k,m) lives at base[(kcol0+k)*ld + mrow0 + m]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = tid + 256 * i;
+        if (!KM) {
+            const int row = c >> 3, c16 = c & 7;
+            r[i] = *reinterpret_cast<const d2*>(base + (mrow0 + row) * ld + kcol0 + c16 * 2);
+        } else {
+            const int krow = c >> 6, c16 = c & 63;
+            r[i] = *reinterpret_cast<const d2*>(base + (kcol0 + krow) * ld + mrow0 + c16 * 2);
+        }
+    }
+}
+
+template <bool KM>
+__device__ __forceinline__ void stage_store(const d2 (&r)[4], double* lds, int tid) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = tid + 256 * i;
+        if (!KM) {
+            const int row = c >> 3, c16 = c & 7;
+            *reinterpret_cast<d2*>(lds + row * LD_MK + c16 * 2) = r[i];
+        } else {
+            const int krow = c >> 6, c16 = c & 63;
+            *reinterpret_cast<d2*>(lds + krow * LD_KM + c16 * 2) = r[i];
+        }
+    }
+}
+
+template <bool KM>
+__device__ __forceinline__ double frag(const double* lds, int m0, int kk, int lane) {
+    // element (m = m0 + (lane&15), k = kk*4 + (lane>>4)) of the staged tile
+    if (!KM) return lds[(m0 + (lane & 15)) * LD_MK + kk * 4 + (lane >> 4)];
+    return lds[(kk * 4 + (lane >> 4)) * LD_KM + m0 + (lane & 15)];
+}
+
+template <bool A_KM, bool B_KM, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_tiles_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) double smem[4 * STAGE_ELEMS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // XCD-aware bijective remap: block b runs on XCD b%8; give each XCD a contiguous slice of
+    // the tile list so neighbouring tiles (shared operand panels) hit the same L2.
+    const int n = g.ntiles, b = blockIdx.x;
+    const int q = n >> 3, r = n & 7, x = b & 7, yy = b >> 3;
+    const int p = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + yy;
+    const TileDesc t = g.tiles[p];
+    const int nsteps = (t.kb1 - t.kb0) * (NB / GEMM_BK);
+
+    // operand origins (element units)
+    const int64_t a_m0 = (int64_t)(t.ci + (A_KM ? g.a_coff : g.a_roff)) * NB;
+    const int64_t a_k0 = (int64_t)(t.kb0 + (A_KM ? g.a_roff : g.a_coff)) * NB;
+    const int64_t b_n0 = (int64_t)(t.cj + (B_KM ? g.b_coff : g.b_roff)) * NB;
+    const int64_t b_k0 = (int64_t)(t.kb0 + (B_KM ? g.b_roff : g.b_coff)) * NB;
+
+    d4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+
+    d2 ra[4], rb[4];
+    if (nsteps > 0) {
+        stage_load<A_KM>(ra, g.A, g.lda, a_m0, a_k0, tid);
+        stage_load<B_KM>(rb, g.B, g.ldb, b_n0, b_k0, tid);
+        stage_store<A_KM>(ra, smem, tid);
+        stage_store<B_KM>(rb, smem + STAGE_ELEMS, tid);
+    }
+    __syncthreads();
+
+    for (int s = 0; s < nsteps; ++s) {
+        const double* As = smem + (s & 1) * 2 * STAGE_ELEMS;
+        const double* Bs = As + STAGE_ELEMS;
+        const bool more = (s + 1 < nsteps);
+        if (more) {
+            stage_load<A_KM>(ra, g.A, g.lda, a_m0, a_k0 + (int64_t)(s + 1) * GEMM_BK, tid);
+            stage_load<B_KM>(rb, g.B, g.ldb, b_n0, b_k0 + (int64_t)(s + 1) * GEMM_BK, tid);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            double a[4], bb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = frag<A_KM>(As, wm * 64 + i * 16, kk, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bb[j] = frag<B_KM>(Bs, wn * 64 + j * 16, kk, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bb[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) {
+            double* An = smem + ((s + 1) & 1) * 2 * STAGE_ELEMS;
+            stage_store<A_KM>(ra, An, tid);
+            stage_store<B_KM>(rb, An + STAGE_ELEMS, tid);
+        }
+        __syncthreads();
+    }
+
+    if (EPI == EPI_STORE) {
+        const int64_t crow0 = (int64_t)(t.ci + g.c_roff) * NB + wm * 64 + (lane >> 4);
+        const int64_t ccol0 = (int64_t)(t.cj + g.c_coff) * NB + wn * 64 + (lane & 15);
+        const double alpha = g.alpha, beta = g.beta;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    double* cp = g.C + (crow0 + i * 16 + 4 * rg) * g.ldc + ccol0 + j * 16;
+                    double v = alpha * acc[i][j][rg];
+                    if (beta != 0.0) v += beta * (*cp);
+                    *cp = v;
+                }
+    } else {
+        // column sums of squares of the 128x128 product tile -> colpart[ci][cj*128 + col]
+        double* red = smem;      // [2][128]; all waves are past the last barrier of the k-loop
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            double s = 0.0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) s += acc[i][j][rg] * acc[i][j][rg];
+            s += __shfl_xor(s, 16);
+            s += __shfl_xor(s, 32);
+            if (lane < 16) red[wm * 128 + wn * 64 + j * 16 + lane] = s;
+        }
+        __syncthreads();
+        if (tid < 128)
+            g.colpart[(int64_t)t.ci * g.ld_colpart + (int64_t)(t.cj + g.c_coff) * NB + tid] =
+                red[tid] + red[128 + tid];
+    }
+}
+
+template <bool A_KM, bool B_KM, int EPI>
+static int launch_one(gpimhip_ctx* h, const GemmArgs& g) {
+    if (g.ntiles <= 0) return GPIMHIP_OK;
+    hipLaunchKernelGGL((gemm_tiles_kernel<A_KM, B_KM, EPI>), dim3(g.ntiles), dim3(256), 0, h->stream, g);
+    HIP_TRY(hipGetLastError());
+    return GPIMHIP_OK;
+}
+
+int launch_gemm(gpimhip_ctx* h, bool a_km, bool b_km, int epi, const GemmArgs& g) {
+    if (epi == EPI_STORE) {
+        if (!a_km && !b_km) return launch_one<false, false, EPI_STORE>(h, g);   // NT
+        if (!a_km && b_km) return launch_one<false, true, EPI_STORE>(h, g);     // NN
+        if (a_km && b_km) return launch_one<true, true, EPI_STORE>(h, g);       // TN
+    } else {
+        if (!a_km && b_km) return launch_one<false, true, EPI_COLSUMSQ>(h, g);
+    }
+    gpim_set_error("launch_gemm: unsupported operand layout combination");
+    return GPIMHIP_E_BADARG;
+}

@@ -1,0 +1,55 @@
+// kfun.hpp -- the covariance functions and their parameter derivatives (device side).
+//
+// Restates pyro.contrib.gp.kernels.{RBF,Matern52,RationalQuadratic} as used through
+// gpim/kernels/pyro_kernels.py:59-67 (formulas: SURVEY App. A.3) with the SAME algebraic form
+// as the reference so that round-off behaves alike:
+//   a = x / l, b = z / l;  r2 = max((|a|^2 - 2 a.b) + |b|^2, 0)   (NaN propagates like torch.clamp)
+//   RBF       k = s2 * exp(-r2/2)
+//   Matern52  r = sqrt(r2 + 1e-12);  k = s2 * (1 + sqrt5*r + (5/3) r^2) * exp(-sqrt5*r)
+//   RQ        k = s2 * (1 + r2/(2*alpha))^(-alpha)
+#pragma once
+#include "common.hpp"
+
+#define SQRT5 2.23606797749979
+
+struct KVal {
+    double e;      // k / s2
+    double h;      // (dk/dl_k) = s2 * h * (a_k - b_k)^2 / l_k       (per-dimension factor)
+    double ga;     // (dk/dalpha) / s2                                 (RQ only)
+};
+
+template <int KIND>
+__device__ __forceinline__ double kfun_value(double r2, double alpha) {
+    if (KIND == GPIMHIP_KERNEL_RBF) return exp(-0.5 * r2);
+    if (KIND == GPIMHIP_KERNEL_MATERN52) {
+        const double r = sqrt(r2 + 1e-12);
+        const double s5r = SQRT5 * r;
+        return (1.0 + s5r + (5.0 / 3.0) * (r * r)) * exp(-s5r);
+    }
+    return pow(1.0 + (0.5 / alpha) * r2, -alpha);
+}
+
+template <int KIND>
+__device__ __forceinline__ KVal kfun_grad(double r2, double alpha) {
+    KVal v;
+    v.ga = 0.0;
+    if (KIND == GPIMHIP_KERNEL_RBF) {
+        v.e = exp(-0.5 * r2);
+        v.h = v.e;
+    } else if (KIND == GPIMHIP_KERNEL_MATERN52) {
+        const double r = sqrt(r2 + 1e-12);
+        const double s5r = SQRT5 * r;
+        const double ex = exp(-s5r);
+        v.e = (1.0 + s5r + (5.0 / 3.0) * (r * r)) * ex;
+        v.h = (5.0 / 3.0) * (1.0 + s5r) * ex;
+    } else {
+        const double t = (0.5 / alpha) * r2;
+        const double base = 1.0 + t;
+        v.e = pow(base, -alpha);
+        v.h = v.e / base;
+        v.ga = v.e * (t / base - log1p(t));
+    }
+    return v;
+}
+
+__device__ __forceinline__ double clamp0_nan(double v) { return (v < 0.0) ? 0.0 : v; }

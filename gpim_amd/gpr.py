@@ -1,0 +1,269 @@
+"""
+gpr.py -- ``reconstructor``: exact Gaussian-process regression on image / hyperspectral grids,
+computed by the MI355X engine (libgpimhip.so).
+
+Host-side mirror of the reference's gpim/gpreg/gpr.py:22-283:
+same constructor signature, same ``train`` / ``predict`` / ``run`` methods and return values,
+same ``hyperparams`` dictionary.  What the reference delegates to pyro.contrib.gp / torch
+(kernel matrix, Cholesky, marginal log-likelihood and its gradient, Adam, posterior) runs as
+hand-written HIP kernels behind the C ABI of include/gpimhip.h.
+
+Deliberate differences from the reference, all on the outside of the numerics:
+  * the engine is GPU-only.  ``use_gpu`` is accepted for signature compatibility and ignored;
+    without a HIP device or without libgpimhip.so every call raises RuntimeError.
+  * the initial hyper-parameters are always drawn with torch's CPU generator (the reference does
+    that on its CPU path; its CUDA path uses the CUDA generator and is not reproducible).
+  * no process-global side effects: torch's default tensor type is left alone.
+  * a non-positive-definite covariance is reported at the end of ``train``/``predict`` (the
+    device loop runs without host synchronisation) instead of at the failing iteration.
+  * ``precision='single'`` and ``sparse=True`` are not implemented yet and raise.
+"""
+import ctypes
+import time
+import warnings
+
+import numpy as np
+import torch
+
+from . import _lib, gprutils
+from .kernels import get_kernel
+
+_F64 = torch.float64
+
+
+class _KernelView:
+    """``model.kernel`` facade: constrained values as tensors (boptim.py:319 reads
+    ``model.kernel.lengthscale.mean().item()``)."""
+
+    def __init__(self, owner):
+        self._o = owner
+
+    @property
+    def variance(self):
+        return self._o._spec.constrained(self._o._u)[0]
+
+    @property
+    def lengthscale(self):
+        ls = self._o._spec.constrained(self._o._u)[1]
+        return ls.reshape(()) if self._o._spec.isotropic else ls
+
+    variance_map = variance
+    lengthscale_map = lengthscale
+
+
+class _ModelView:
+    """``reconstructor.model`` facade with settable training data (boptim.py:248-249 swaps
+    ``model.X`` / ``model.y`` in place between trainings)."""
+
+    def __init__(self, owner):
+        self._o = owner
+        self.kernel = _KernelView(owner)
+
+    @property
+    def X(self):
+        return self._o._Xd
+
+    @X.setter
+    def X(self, value):
+        self._o._Xd = self._o._to_device(value)
+
+    @property
+    def y(self):
+        return self._o._yd
+
+    @y.setter
+    def y(self, value):
+        self._o._yd = self._o._to_device(value)
+
+    @property
+    def noise(self):
+        return self._o._spec.constrained(self._o._u)[2]
+
+    @property
+    def jitter(self):
+        return self._o._spec.jitter
+
+    def parameters(self):
+        yield self._o._u
+
+
+class reconstructor:
+    """
+    Gaussian-process reconstruction of sparse 2D images and 3D/4D hyperspectral data.
+
+    Args:
+        X (ndarray): grid indices, :math:`c \\times N \\times M (\\times L ...)`; NaN = missing
+        y (ndarray): observations, :math:`N \\times M (\\times L ...)`; NaN = missing
+        Xtest (ndarray): grid on which to predict (same layout as X)
+        kernel (str): 'RBF', 'Matern52' or 'RationalQuadratic'
+        lengthscale: ``[lo, hi]`` (one shared lengthscale) or ``[[lo...], [hi...]]`` bounds;
+            default ``[[0]*d, [mean(y.shape)/2]*d]``
+        sparse, indpoints: inducing-point GP (not implemented yet)
+        learning_rate (float), iterations (int): Adam settings
+        use_gpu: ignored (always on the GPU)
+        verbose (int): 0, 1 or 2
+        seed (int): seeds the CPU generator used for the initial hyper-parameter draw
+        **amplitude, **precision, **jitter, **isotropic: as in the reference
+    """
+
+    def __init__(self, X, y, Xtest=None, kernel='RBF', lengthscale=None, sparse=False,
+                 indpoints=None, learning_rate=5e-2, iterations=1000, use_gpu=False,
+                 verbose=1, seed=0, **kwargs):
+        self.precision = kwargs.get("precision", "double")
+        if self.precision != "double":
+            raise NotImplementedError("gpim_amd: only precision='double' is implemented")
+        if sparse:
+            raise NotImplementedError("gpim_amd: sparse (inducing-point) GP regression is not implemented yet")
+        self._handle = _lib.Handle()          # raises if there is no GPU / no library
+        self._dev = self._handle.device
+        self.verbose = verbose
+        torch.manual_seed(seed)
+        input_dim = np.ndim(y)
+        self.X, self.y = gprutils.prepare_training_data(X, y, precision=self.precision)
+        self.do_sparse = False
+        if lengthscale is None and not kwargs.get("isotropic"):
+            lmean = float(np.mean(y.shape) / 2)
+            lengthscale = [[0. for _ in range(input_dim)], [lmean for _ in range(input_dim)]]
+        elif lengthscale is None and kwargs.get("isotropic"):
+            lengthscale = [0., float(np.mean(y.shape) / 2)]
+        self._spec = get_kernel(kernel, input_dim, lengthscale, use_gpu,
+                                amplitude=kwargs.get('amplitude'), precision=self.precision,
+                                jitter=kwargs.get("jitter", 1.0e-5))
+        self._u = self._spec.draw_initial_u().to(self._dev)
+        self._mstruct = self._spec.struct()
+        self.fulldims = Xtest.shape[1:] if Xtest is not None else X.shape[1:]
+        self.Xtest = gprutils.prepare_test_data(Xtest, precision=self.precision) if Xtest is not None else None
+        self._Xd = self._to_device(self.X)
+        self._yd = self._to_device(self.y)
+        self._Xtest_d = self._to_device(self.Xtest) if self.Xtest is not None else None
+        self.model = _ModelView(self)
+        self.learning_rate = learning_rate
+        self.iterations = iterations
+        self.indpoints_all = []
+        self.lscales, self.noise_all, self.amp_all = [], [], []
+        self.loss_all = []
+        self.hyperparams = {
+            "lengthscale": self.lscales,
+            "noise": self.noise_all,
+            "variance": self.amp_all,
+            "inducing_points": self.indpoints_all
+        }
+        self._last_pred = None       # (mean, sd) device tensors of the latest predict()
+
+    # ------------------------------------------------------------------ helpers
+    def _to_device(self, t):
+        if isinstance(t, np.ndarray):
+            t = torch.from_numpy(t)
+        return t.detach().to(self._dev, _F64).contiguous()
+
+    def _check_data(self):
+        X, y = self._Xd, self._yd
+        if X.dim() != 2 or X.shape[1] != self._spec.dim or y.dim() != 1 or y.shape[0] != X.shape[0]:
+            raise ValueError("training data must be X:(N,%d), y:(N,); got %s and %s"
+                             % (self._spec.dim, tuple(X.shape), tuple(y.shape)))
+        if X.shape[0] < 1:
+            raise ValueError("no observations (all NaN)")
+
+    # ------------------------------------------------------------------ training
+    def train(self, **kwargs):
+        """Adam on the negative log marginal likelihood; every call starts a fresh optimiser
+        while the hyper-parameters persist (warm start), like gpr.py:170-217."""
+        if kwargs.get("learning_rate") is not None:
+            self.learning_rate = kwargs.get("learning_rate")
+        if kwargs.get("iterations") is not None:
+            self.iterations = kwargs.get("iterations")
+        if kwargs.get("verbose") is not None:
+            self.verbose = kwargs.get("verbose")
+        self._check_data()
+        T, P = int(self.iterations), self._spec.n_params
+        start_time = time.time()
+        if self.verbose:
+            print('Model training...')
+        hist = torch.empty((max(T, 1), P), dtype=_F64, device=self._dev)
+        loss = torch.empty((max(T, 1),), dtype=_F64, device=self._dev)
+        rc = self._handle.lib.gpimhip_fit_exact(
+            self._handle.h, ctypes.byref(self._mstruct), _lib.ptr(self._Xd), _lib.ptr(self._yd),
+            self._Xd.shape[0], _lib.ptr(self._u), float(self.learning_rate), T,
+            _lib.ptr(hist), _lib.ptr(loss))
+        _lib.check(rc)
+        hist_h = hist[:T].cpu().numpy()
+        loss_h = loss[:T].cpu().numpy()
+        n_ls = self._spec.n_ls
+        for i in range(T):
+            row = hist_h[i]
+            self.lscales.append(float(row[1]) if self._spec.isotropic else row[1:1 + n_ls].tolist())
+            self.amp_all.append(float(row[0]))
+            self.noise_all.append(float(row[1 + n_ls]))
+            self.loss_all.append(float(loss_h[i]))
+            if self.verbose == 2 and (i % 100 == 0 or i == T - 1):
+                print('iter: {} ...'.format(i),
+                      'loss: {} ...'.format(np.around(loss_h[i], 4)),
+                      'amp: {} ...'.format(np.around(self.amp_all[-1], 4)),
+                      'length: {} ...'.format(np.around(self.lscales[-1], 4)),
+                      'noise: {} ...'.format(np.around(self.noise_all[-1], 7)))
+        if self.verbose:
+            dt = time.time() - start_time
+            if T > 0:
+                print('average time per iteration: {} s'.format(np.round(dt / T, 6)))
+            print('training completed in {} s'.format(np.round(dt, 2)))
+            var, ls, noise = self._spec.constrained(self._u)
+            print('Final parameter values:\n',
+                  'amp: {}, lengthscale: {}, noise: {}'.format(
+                      np.around(var.item(), 4), np.around(ls.tolist(), 4), np.around(noise.item(), 7)))
+        return
+
+    # ------------------------------------------------------------------ prediction
+    def predict(self, Xtest=None, **kwargs):
+        """Posterior mean and standard deviation (noise included) on the test grid;
+        returns numpy arrays shaped like the grid (gpr.py:219-255)."""
+        if Xtest is None and self.Xtest is None:
+            warnings.warn("No test data provided. Using training data for prediction", UserWarning)
+            self.Xtest = self.X
+            self._Xtest_d = self._Xd
+        elif Xtest is not None:
+            self.Xtest = gprutils.prepare_test_data(Xtest, precision=self.precision)
+            self._Xtest_d = self._to_device(self.Xtest)
+            self.fulldims = Xtest.shape[1:]
+        if kwargs.get("verbose") is not None:
+            self.verbose = kwargs.get("verbose")
+        if self.verbose:
+            print("Calculating predictive mean and variance...", end=" ")
+        self._check_data()
+        M = self._Xtest_d.shape[0]
+        mean = torch.empty((M,), dtype=_F64, device=self._dev)
+        var = torch.empty((M,), dtype=_F64, device=self._dev)
+        rc = self._handle.lib.gpimhip_predict_exact(
+            self._handle.h, ctypes.byref(self._mstruct), _lib.ptr(self._Xd), _lib.ptr(self._yd),
+            self._Xd.shape[0], _lib.ptr(self._u), _lib.ptr(self._Xtest_d), M, _lib.ptr(mean), _lib.ptr(var))
+        _lib.check(rc)
+        sd = var.sqrt()
+        self._last_pred = (mean, sd)
+        mean_h = mean.cpu().numpy().reshape(self.fulldims)
+        sd_h = sd.cpu().numpy().reshape(self.fulldims)
+        if self.verbose:
+            print("Done")
+        return mean_h, sd_h
+
+    def run(self, **kwargs):
+        """train + predict; returns (mean, sd, hyperparams) (gpr.py:257-283)."""
+        if kwargs.get("learning_rate") is not None:
+            self.learning_rate = kwargs.get("learning_rate")
+        if kwargs.get("iterations") is not None:
+            self.iterations = kwargs.get("iterations")
+        self.train(learning_rate=self.learning_rate, iterations=self.iterations)
+        mean, sd = self.predict()
+        return mean, sd, self.hyperparams
+
+    # ------------------------------------------------------------------ operator-level hooks
+    def loss_and_grad(self):
+        """(loss, d loss/du) at the current hyper-parameters; used by the parity tests."""
+        self._check_data()
+        P = self._spec.n_params
+        out = torch.empty((1 + P,), dtype=_F64, device=self._dev)
+        rc = self._handle.lib.gpimhip_nll_grad(
+            self._handle.h, ctypes.byref(self._mstruct), _lib.ptr(self._Xd), _lib.ptr(self._yd),
+            self._Xd.shape[0], _lib.ptr(self._u), ctypes.c_void_p(out.data_ptr()),
+            ctypes.c_void_p(out.data_ptr() + 8))
+        _lib.check(rc)
+        o = out.cpu()
+        return o[0].item(), o[1:].clone()

@@ -1,0 +1,157 @@
+/*
+ * gpimhip.h -- C ABI of libgpimhip.so, the MI355X (gfx950) engine behind
+ * gpim_amd.reconstructor / gpim_amd.boptimizer.
+ *
+ * The reference (ziatdinovmax/GPim, /root/reference) has no native boundary: its hot
+ * path is Python calling pyro.contrib.gp / torch.  Each entry point below replaces the
+ * group of third-party calls made at the cited reference call site; the Python host
+ * code in gpim_amd/ binds them with ctypes.
+ *
+ * Conventions
+ *   - every data pointer is a DEVICE pointer (HBM) borrowed for the duration of the
+ *     call; outputs are caller-allocated; the library owns only its workspace.
+ *   - all work is enqueued on the handle's HIP stream; calls return without
+ *     synchronising unless stated.  Nothing here allocates per call once the
+ *     workspace for a problem size exists.
+ *   - matrices are row-major doubles; "lower" means the i >= j part is meaningful.
+ *   - return value: 0 = ok, <0 = error (see GPIMHIP_E_*), message via
+ *     gpimhip_last_error().  Non-positive-definite detection is asynchronous: the
+ *     factorisation records the first failing column in a device word that
+ *     gpimhip_fit_exact / gpimhip_predict_exact read back at their final sync and
+ *     report as GPIMHIP_E_NOT_PD (torch.linalg.cholesky raises at gpr.py:192,248).
+ *   - parameter vector u (unconstrained, the thing Adam updates), length
+ *     P = 2 + n_ls (+1 for RationalQuadratic):
+ *         u[0]            variance      sigma^2 = amp_lo + (amp_hi-amp_lo)*sigmoid(u)
+ *         u[1..n_ls]      lengthscale   l_k     = ls_lo_k + (ls_hi_k-ls_lo_k)*sigmoid(u)
+ *         u[1+n_ls]       noise         s_n^2   = exp(u)
+ *         u[2+n_ls]       scale_mixture alpha   = exp(u)      (RationalQuadratic only)
+ *     (pyro_kernels.py:81-94 Uniform priors -> interval constraints)
+ */
+#ifndef GPIMHIP_H
+#define GPIMHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPIMHIP_OK            0
+#define GPIMHIP_E_BADARG     -1
+#define GPIMHIP_E_HIP        -2
+#define GPIMHIP_E_NOT_PD     -3
+#define GPIMHIP_E_NOMEM      -4
+
+#define GPIMHIP_KERNEL_RBF       0
+#define GPIMHIP_KERNEL_MATERN52  1
+#define GPIMHIP_KERNEL_RQ        2
+
+#define GPIMHIP_ACQ_CB   0
+#define GPIMHIP_ACQ_EI   1
+#define GPIMHIP_ACQ_POI  2
+
+#define GPIMHIP_MAX_DIM  4
+#define GPIMHIP_MAX_PARAMS 8
+
+typedef struct gpimhip_ctx* gpimhip_handle;
+
+/* Model description: kernel family + parameterisation.
+ * Replaces gpim/kernels/pyro_kernels.py:14-96 (get_kernel) and the jitter argument of
+ * gp.models.GPRegression at gpim/gpreg/gpr.py:141-144. */
+typedef struct {
+    int32_t kernel;                     /* GPIMHIP_KERNEL_*                                  */
+    int32_t dim;                        /* d, 1..4                                           */
+    int32_t n_ls;                       /* 1 (isotropic) or dim                              */
+    int32_t reserved;
+    double  amp_lo, amp_hi;             /* variance prior bounds (default 1e-4, 10)          */
+    double  ls_lo[GPIMHIP_MAX_DIM];     /* lengthscale prior bounds                          */
+    double  ls_hi[GPIMHIP_MAX_DIM];
+    double  jitter;                     /* added to diag(K) with the noise (gpr.py:141)      */
+} gpimhip_model_t;
+
+/* ---- lifetime ------------------------------------------------------------------- */
+/* hip_stream: the hipStream_t every call is enqueued on; NULL selects the device's default
+ * (null) stream, so work is ordered with the caller's own default-stream work. */
+int  gpimhip_create(gpimhip_handle* out, int device, void* hip_stream);
+int  gpimhip_destroy(gpimhip_handle h);
+const char* gpimhip_last_error(void);
+int  gpimhip_version(void);
+/* bytes of device workspace currently held by the handle */
+int64_t gpimhip_workspace_bytes(gpimhip_handle h);
+
+/* ---- operator-level entry points (parity hooks; each is also a stage of fit/predict) -- */
+
+/* K = k(X, Z) (+ diag_add on the diagonal when Z == NULL, i.e. the symmetric case).
+ * Replaces the Pyro kernel forward called from GPRegression.model/forward
+ * (call sites gpim/gpreg/gpr.py:192,248; formulas SURVEY App. A.3).
+ * theta (device, doubles): [sigma^2, l_0..l_{n_ls-1}, alpha_rq].  out: (N x M) row-major,
+ * leading dimension ld >= M.  Symmetric case writes the full square. */
+int gpimhip_kmat(gpimhip_handle h, const gpimhip_model_t* m,
+                 const double* X, int64_t N, const double* Z, int64_t M,
+                 const double* theta, double diag_add, double* out, int64_t ld);
+
+/* In-place lower Cholesky of the n x n matrix A (row-major, ld), n any size >= 1;
+ * the strict upper triangle is left untouched.  info (device int32): 0, or 1 + first
+ * failing column.  Replaces torch.linalg.cholesky inside Pyro (gpr.py:192,248). */
+int gpimhip_potrf(gpimhip_handle h, double* A, int64_t n, int64_t ld, int32_t* info);
+
+/* loss (negative log marginal likelihood + prior constant) and d loss / d u at u.
+ * Replaces Trace_ELBO().differentiable_loss + loss.backward() (gpr.py:186,192-193).
+ * loss_out: 1 double, grad_out: P doubles (device). */
+int gpimhip_nll_grad(gpimhip_handle h, const gpimhip_model_t* m,
+                     const double* X, const double* y, int64_t N,
+                     const double* u, double* loss_out, double* grad_out);
+
+/* ---- the hot path ------------------------------------------------------------------ */
+
+/* T Adam iterations on u, entirely on device (no host sync inside the loop).
+ * Replaces the training loop reconstructor.train (gpr.py:185-199): fresh Adam state
+ * (t=0, m=v=0), lr, betas (0.9, 0.999), eps 1e-8.
+ *   u_inout   P doubles (device), updated in place
+ *   hist_out  T x (P) doubles (device): constrained values AFTER each step, in the
+ *             order [sigma^2, l_*, s_n^2(, alpha)]  (what gpr.py:195-197 appends)
+ *   loss_out  T doubles (device) or NULL: loss evaluated BEFORE each step
+ * Synchronises the stream once at the end; returns GPIMHIP_E_NOT_PD if any
+ * factorisation failed (info of the first failure via gpimhip_last_error). */
+int gpimhip_fit_exact(gpimhip_handle h, const gpimhip_model_t* m,
+                      const double* X, const double* y, int64_t N,
+                      double* u_inout, double lr, int32_t T,
+                      double* hist_out, double* loss_out);
+
+/* Posterior mean and variance (full_cov=False, noiseless=False) at Xs (M x d), NaN rows
+ * allowed (they produce NaN outputs).  Replaces GPRegression.forward -> conditional
+ * (gpr.py:247-248): K and L are recomputed at u.
+ *   mean_out, var_out: M doubles (device); var includes the noise, excludes jitter.
+ * Synchronises at the end (to report NOT_PD). */
+int gpimhip_predict_exact(gpimhip_handle h, const gpimhip_model_t* m,
+                          const double* X, const double* y, int64_t N,
+                          const double* u, const double* Xs, int64_t M,
+                          double* mean_out, double* var_out);
+
+/* Acquisition sweep over the dense grid (gpim/gpbayes/acqfunc.py:11-92):
+ *   CB : p0*mean + p1*sd                                  (alpha, beta)
+ *   EI : imp*Phi(imp/sd) + sd*phi(imp/sd), imp = mean - p0 - p1     (best, xi)
+ *   POI: Phi((mean - p0 - p1)/sd)
+ * mask (M doubles of 1/NaN, or NULL) is multiplied in as boptim.py:307-308 does.
+ * mean, sd, acq_out: M doubles (device). */
+int gpimhip_acq(gpimhip_handle h, int32_t kind, const double* mean, const double* sd,
+                int64_t M, double p0, double p1, const double* mask, double* acq_out);
+
+/* nanmax over n doubles (device) -> out (1 double, device): the incumbent
+ * "np.nanmax(mean_sample)" of acqfunc.py:59,88. */
+int gpimhip_nanmax(gpimhip_handle h, const double* x, int64_t n, double* out);
+
+/* Descending top-k of acq (NaNs ranked first when keep_nan != 0, exactly like
+ * np.argsort(...)[::-1] at boptim.py:303-306; dropped otherwise, boptim.py:310-315).
+ * vals_out: k doubles, idx_out: k int64 flat indices (device).  count_out (device
+ * int64): number of valid entries written (< k when fewer non-NaN values exist). */
+int gpimhip_topk(gpimhip_handle h, const double* acq, int64_t M, int32_t k, int32_t keep_nan,
+                 double* vals_out, int64_t* idx_out, int64_t* count_out);
+
+/* Block until everything enqueued on the handle's stream has finished. */
+int gpimhip_sync(gpimhip_handle h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPIMHIP_H */

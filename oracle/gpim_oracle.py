@@ -1,0 +1,525 @@
+"""
+gpim_oracle.py -- CPU restatement of GPim's exact-GP + Bayesian-optimisation hot path.
+
+THIS FILE IS TEST INFRASTRUCTURE.  It is the checker that the HIP path is compared
+against; it is never imported by the product package ``gpim_amd``.  Only ``tests/``,
+``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may import it.
+
+What it restates (reference paths are relative to /root/reference, v0.3.9):
+
+* ``gpim/gpreg/gpr.py:22-283``      reconstructor.__init__/train/predict/run
+* ``gpim/kernels/pyro_kernels.py``   kernel family, Uniform priors => interval-constrained
+                                     MAP parameters initialised by one draw from each prior
+* ``gpim/gpbayes/acqfunc.py``        confidence_bound / expected_improvement /
+                                     probability_of_improvement (incl. the POI tuple quirk)
+* ``gpim/gpbayes/boptim.py``         next_point / checkvalues / update_points /
+                                     evaluate_function / update_posterior / single_step / run
+* ``gpim/gprutils.py:23-210``        prepare_training_data / prepare_test_data /
+                                     get_full_grid / get_sparse_grid
+
+The arithmetic itself lives in third-party packages that are NOT vendored in the
+reference tree: ``pyro-ppl`` (declared ``>=0.4.1`` in setup.py:30, no pin; behaviour
+restated from pyro 1.8.x ``pyro.contrib.gp.{models.GPRegression,kernels.isotropic,
+util.conditional,parameterized.Parameterized}``) and ``torch`` (``optim.Adam``,
+``linalg.cholesky``, ``linalg.solve_triangular``, autograd).  Pyro cannot be imported in
+this image, so the restatement is pinned against the reference's own known answers:
+
+* ``test/test_data/test_{ei,poi,cb}.npy`` through ``test/test_boptim.py:42-58``
+  (tests/test_oracle_golden.py::test_bo_golden),
+* the printed hyper-parameter trace of
+  ``examples/notebooks/GP_based_exploration_exploitation.ipynb`` (tests/golden/
+  notebook_trace.json, tests/test_oracle_golden.py::test_notebook_trace).
+
+Parity status: PINNED for RBF exact GP + EI/POI/CB BO (fp64, CPU generator).
+Matern52 / RationalQuadratic / isotropic lengthscale / mask / batch_update / dscale are
+parity-UNPINNED by the reference's own tests (shape/NaN smoke only,
+test/test_gpreg.py:24-36); for those this file follows Pyro's documented formulas.
+"""
+
+import math
+import types
+import warnings
+
+import numpy as np
+import torch
+from scipy import spatial
+from scipy.stats import norm
+
+_F64 = torch.float64
+_FINFO = torch.finfo(_F64)
+KERNELS = ("RBF", "Matern52", "RationalQuadratic")
+
+
+# --------------------------------------------------------------------------------------
+# grids and data preparation (gpim/gprutils.py:23-210)
+# --------------------------------------------------------------------------------------
+def get_full_grid(R, extent=None, dense_x=1.0):
+    """np.mgrid index coordinates of a 2D-4D array, shape (ndim, *dims)
+    (gprutils.py:108-172; only the extent=None and 2D-extent branches are usable in
+    the reference, the 3D/4D extent branches mis-unpack at :147-149,:164-166)."""
+    nd = np.ndim(R)
+    if nd < 2 or nd > 4:
+        raise NotImplementedError("Currently works only for 2D-4D sets")
+    dense_x = np.float64(dense_x)
+    if extent:
+        if nd != 2:
+            raise NotImplementedError("extent is only usable for 2D data")
+        steps = []
+        for e, (lo, hi) in zip(R.shape, extent):
+            steps.append(dense_x / (e // (hi - lo)))
+        sl = tuple(slice(lo, hi, st) for (lo, hi), st in zip(extent, steps))
+        return np.array(np.mgrid[sl])
+    sl = tuple(slice(None, e, dense_x) for e in R.shape)
+    return np.array(np.mgrid[sl])
+
+
+def get_sparse_grid(R, extent=None):
+    """Full grid with NaN coordinates wherever R is NaN (gprutils.py:175-210)."""
+    if not np.isnan(R).any():
+        raise NotImplementedError(
+            "Missing values in sparse data must be represented as NaNs")
+    full = get_full_grid(R, extent)
+    if np.ndim(R) == 2:
+        X = full.copy().reshape(2, -1)
+        X[:, np.isnan(R.ravel())] = np.nan
+        return X.reshape(full.shape)
+    if np.ndim(R) == 3:
+        e1, e2, e3 = R.shape
+        if not np.isnan(R[..., -1]).any():
+            # sparsity in xy only: a NaN anywhere along the spectrum kills the column
+            X = full.copy().reshape(3, e1 * e2, e3)
+            rows = np.where(np.isnan(R.reshape(e1 * e2, e3)))[0]
+            X[:, rows] = np.nan
+        else:
+            X = full.copy().reshape(3, -1)
+            X[:, np.isnan(R.ravel())] = np.nan
+        return X.reshape(full.shape)
+    raise NotImplementedError(
+        "Currently supports only 2D and 3D sets with sparsity in xy and xyz dims")
+
+
+def prepare_training_data(X, y=None):
+    """(c,*dims) grid -> (P,c) rows with any NaN dropped; y flattened, NaNs dropped
+    (gprutils.py:23-59).  Row-major order is preserved."""
+    Xr = X.reshape(X.shape[0], -1).T
+    Xr = Xr[~np.isnan(Xr).any(axis=1)]
+    Xt = torch.from_numpy(np.ascontiguousarray(Xr)).to(_F64)
+    if y is None:
+        return Xt, None
+    yf = y.ravel()
+    yt = torch.from_numpy(np.ascontiguousarray(yf[~np.isnan(yf)])).to(_F64)
+    return Xt, yt
+
+
+def prepare_test_data(X):
+    """(c,*dims) -> (M,c), no NaN filtering (gprutils.py:62-85)."""
+    return torch.from_numpy(
+        np.ascontiguousarray(X.reshape(X.shape[0], -1).T)).to(_F64)
+
+
+# --------------------------------------------------------------------------------------
+# kernel parameterisation (pyro_kernels.py:14-96 + pyro Parameterized.set_prior)
+# --------------------------------------------------------------------------------------
+def _clipped_sigmoid(u):
+    # torch.distributions.transforms.SigmoidTransform._call
+    return torch.clamp(torch.sigmoid(u), min=_FINFO.tiny, max=1.0 - _FINFO.eps)
+
+
+def _logit_clipped(p):
+    # SigmoidTransform._inverse
+    p = p.clamp(min=_FINFO.tiny, max=1.0 - _FINFO.eps)
+    return p.log() - (-p).log1p()
+
+
+class KernelParams:
+    """Unconstrained trainable scalars u_v, u_l[n_ls], u_n (+u_a for RationalQuadratic)
+    and their constrained images.  Initial variance/lengthscale are ONE DRAW from the
+    Uniform priors with the torch CPU generator, variance first."""
+
+    def __init__(self, kind, dim, lengthscale, amplitude=None):
+        if kind not in KERNELS:
+            print('Select one of the currently available kernels:',
+                  '"RBF", "RationalQuadratic", "Matern52"')
+            raise KeyError(kind)
+        self.kind = kind
+        self.dim = dim
+        amp = [1e-4, 10.0] if amplitude is None else amplitude
+        self.amp_lo = torch.tensor(float(amp[0]), dtype=_F64)
+        self.amp_hi = torch.tensor(float(amp[1]), dtype=_F64)
+        self.ls_lo = torch.tensor(lengthscale[0], dtype=_F64)
+        self.ls_hi = torch.tensor(lengthscale[1], dtype=_F64)
+        # the two prior draws (Uniform.rsample = low + rand*(high-low))
+        v0 = self.amp_lo + torch.rand(self.amp_lo.shape, dtype=_F64) * (self.amp_hi - self.amp_lo)
+        l0 = self.ls_lo + torch.rand(self.ls_lo.shape, dtype=_F64) * (self.ls_hi - self.ls_lo)
+        self.u_var = _logit_clipped((v0 - self.amp_lo) / (self.amp_hi - self.amp_lo)).requires_grad_()
+        self.u_ls = _logit_clipped((l0 - self.ls_lo) / (self.ls_hi - self.ls_lo)).requires_grad_()
+        self.u_noise = torch.zeros((), dtype=_F64, requires_grad=True)      # noise = exp(0) = 1
+        self.u_alpha = torch.zeros((), dtype=_F64, requires_grad=True) if kind == "RationalQuadratic" else None
+
+    def parameters(self):
+        ps = [self.u_var, self.u_ls, self.u_noise]
+        if self.u_alpha is not None:
+            ps.append(self.u_alpha)
+        return ps
+
+    @property
+    def variance(self):
+        return self.amp_lo + (self.amp_hi - self.amp_lo) * _clipped_sigmoid(self.u_var)
+
+    @property
+    def lengthscale(self):
+        return self.ls_lo + (self.ls_hi - self.ls_lo) * _clipped_sigmoid(self.u_ls)
+
+    @property
+    def noise(self):
+        return self.u_noise.exp()
+
+    @property
+    def scale_mixture(self):
+        return self.u_alpha.exp()
+
+    def neg_log_prior(self):
+        # Uniform log_prob is the constant -log(hi-lo) inside the support
+        c = torch.log(self.amp_hi - self.amp_lo) + torch.log(self.ls_hi - self.ls_lo).sum()
+        return c
+
+    # ---- kernel evaluation (pyro.contrib.gp.kernels.isotropic) ----
+    def _r2(self, X, Z):
+        a = X / self.lengthscale
+        b = Z / self.lengthscale
+        a2 = (a ** 2).sum(1, keepdim=True)
+        b2 = (b ** 2).sum(1, keepdim=True)
+        return (a2 - 2.0 * a.matmul(b.t()) + b2.t()).clamp(min=0)
+
+    def K(self, X, Z=None):
+        Z = X if Z is None else Z
+        r2 = self._r2(X, Z)
+        if self.kind == "RBF":
+            return self.variance * torch.exp(-0.5 * r2)
+        if self.kind == "Matern52":
+            r = (r2 + 1e-12).sqrt()
+            s5r = 5 ** 0.5 * r
+            return self.variance * (1 + s5r + (5.0 / 3) * r ** 2) * torch.exp(-s5r)
+        a = self.scale_mixture
+        return self.variance * (1 + (0.5 / a) * r2).pow(-a)
+
+    def Kdiag(self, X):
+        return self.variance.expand(X.size(0))
+
+
+class ExactGP:
+    """pyro.contrib.gp.models.GPRegression restated: zero mean, MAP kernel parameters,
+    loss = -log N(y; 0, K + (jitter+noise) I) - log prior."""
+
+    def __init__(self, X, y, kernel, jitter):
+        self.X, self.y, self.kernel, self.jitter = X, y, kernel, jitter
+
+    def _chol(self):
+        N = self.X.size(0)
+        K = self.kernel.K(self.X).contiguous()
+        K.view(-1)[::N + 1] += self.jitter + self.kernel.noise
+        return torch.linalg.cholesky(K)
+
+    def loss(self):
+        L = self._chol()
+        N = self.X.size(0)
+        z = torch.linalg.solve_triangular(L, self.y.unsqueeze(-1), upper=False).squeeze(-1)
+        nll = 0.5 * (z * z).sum() + L.diagonal().log().sum() + 0.5 * N * math.log(2 * math.pi)
+        return nll + self.kernel.neg_log_prior()
+
+    def loss_and_grad(self):
+        """Returns (loss, [dloss/du ...]) in the order u_var, u_ls[...], u_noise(, u_alpha)."""
+        ps = self.kernel.parameters()
+        for p in ps:
+            p.grad = None
+        loss = self.loss()
+        loss.backward()
+        g = torch.cat([p.grad.reshape(-1) for p in ps])
+        return loss.detach(), g
+
+    @torch.no_grad()
+    def predict(self, Xnew):
+        """full_cov=False, noiseless=False (gpr.py:247-248)."""
+        L = self._chol()
+        Kfs = self.kernel.K(self.X, Xnew)
+        pack = torch.cat((self.y.unsqueeze(-1), Kfs), dim=1)
+        S = torch.linalg.solve_triangular(L, pack, upper=False)
+        v = S[:, :1]
+        W = S[:, 1:].t()
+        loc = W.matmul(v).squeeze(-1)
+        var = (self.kernel.Kdiag(Xnew) - W.pow(2).sum(-1)).clamp(min=0)
+        return loc, var + self.kernel.noise
+
+
+class _KernelFacade:
+    """``model.kernel.lengthscale`` as read by boptim.py:319."""
+    def __init__(self, kp):
+        self._kp = kp
+
+    @property
+    def lengthscale(self):
+        return self._kp.lengthscale.detach()
+
+    @property
+    def variance(self):
+        return self._kp.variance.detach()
+
+
+class reconstructor:
+    """Exact-GP part of gpim.reconstructor (gpr.py:22-283); sparse=True is not restated
+    here (SURVEY 8(a) row a16 is a later stage)."""
+
+    def __init__(self, X, y, Xtest=None, kernel='RBF', lengthscale=None, sparse=False,
+                 indpoints=None, learning_rate=5e-2, iterations=1000, use_gpu=False,
+                 verbose=1, seed=0, **kwargs):
+        if kwargs.get("precision", "double") != "double":
+            raise NotImplementedError("oracle restates the double-precision path only")
+        if sparse:
+            raise NotImplementedError("oracle restates the exact GP only")
+        self.verbose = verbose
+        torch.manual_seed(seed)
+        input_dim = np.ndim(y)
+        self.X, self.y = prepare_training_data(X, y)
+        if lengthscale is None and not kwargs.get("isotropic"):
+            lmean = float(np.mean(y.shape) / 2)
+            lengthscale = [[0.0] * input_dim, [lmean] * input_dim]
+        elif lengthscale is None:
+            lengthscale = [0.0, float(np.mean(y.shape) / 2)]
+        self.kernel = KernelParams(kernel, input_dim, lengthscale,
+                                   amplitude=kwargs.get("amplitude"))
+        self.fulldims = Xtest.shape[1:] if Xtest is not None else X.shape[1:]
+        self.Xtest = prepare_test_data(Xtest) if Xtest is not None else None
+        self.jitter = kwargs.get("jitter", 1.0e-5)
+        self.model = ExactGP(self.X, self.y, self.kernel, self.jitter)
+        self.model.kernel_facade = _KernelFacade(self.kernel)
+        self.learning_rate = learning_rate
+        self.iterations = iterations
+        self.lscales, self.noise_all, self.amp_all, self.indpoints_all = [], [], [], []
+        self.loss_all = []
+        self.hyperparams = {"lengthscale": self.lscales, "noise": self.noise_all,
+                            "variance": self.amp_all, "inducing_points": self.indpoints_all}
+
+    def train(self, **kwargs):
+        if kwargs.get("learning_rate") is not None:
+            self.learning_rate = kwargs.get("learning_rate")
+        if kwargs.get("iterations") is not None:
+            self.iterations = kwargs.get("iterations")
+        if kwargs.get("verbose") is not None:
+            self.verbose = kwargs.get("verbose")
+        # a NEW Adam (t=0, m=v=0) on every call; parameters persist (gpr.py:185)
+        opt = torch.optim.Adam(self.kernel.parameters(), lr=self.learning_rate)
+        for _ in range(self.iterations):
+            opt.zero_grad()
+            loss = self.model.loss()
+            loss.backward()
+            opt.step()
+            self.loss_all.append(loss.item())
+            self.lscales.append(self.kernel.lengthscale.tolist())
+            self.amp_all.append(self.kernel.variance.item())
+            self.noise_all.append(self.kernel.noise.item())
+
+    def predict(self, Xtest=None, **kwargs):
+        if Xtest is None and self.Xtest is None:
+            warnings.warn("No test data provided. Using training data for prediction",
+                          UserWarning)
+            self.Xtest = self.X
+        elif Xtest is not None:
+            self.Xtest = prepare_test_data(Xtest)
+            self.fulldims = Xtest.shape[1:]
+        if kwargs.get("verbose") is not None:
+            self.verbose = kwargs.get("verbose")
+        mean, var = self.model.predict(self.Xtest)
+        return (mean.numpy().reshape(self.fulldims),
+                var.sqrt().numpy().reshape(self.fulldims))
+
+    def run(self, **kwargs):
+        if kwargs.get("learning_rate") is not None:
+            self.learning_rate = kwargs.get("learning_rate")
+        if kwargs.get("iterations") is not None:
+            self.iterations = kwargs.get("iterations")
+        self.train(learning_rate=self.learning_rate, iterations=self.iterations)
+        mean, sd = self.predict()
+        return mean, sd, self.hyperparams
+
+
+# --------------------------------------------------------------------------------------
+# acquisition functions (gpim/gpbayes/acqfunc.py)
+# --------------------------------------------------------------------------------------
+def confidence_bound(gpmodel, X_full, **kwargs):
+    alpha, beta = kwargs.get("alpha", 0), kwargs.get("beta", 1)
+    mean, sd = gpmodel.predict(X_full, verbose=0)
+    return alpha * mean + beta * sd, (mean, sd)
+
+
+def expected_improvement(gpmodel, X_full, X_sparse, **kwargs):
+    xi = kwargs.get("xi", 0.01)
+    mean, sd = gpmodel.predict(X_full, verbose=0)
+    mean_obs, _ = gpmodel.predict(X_sparse, verbose=0)   # NaN rows -> NaN means
+    best = np.nanmax(mean_obs)
+    imp = mean - best - xi
+    z = imp / sd
+    return imp * norm.cdf(z) + sd * norm.pdf(z), (mean, sd)
+
+
+def probability_of_improvement(gpmodel, X_full, X_sparse, **kwargs):
+    xi = kwargs.get("xi", 0.01)
+    mean, sd = gpmodel.predict(X_full, verbose=0)
+    both = gpmodel.predict(X_sparse, verbose=0)          # quirk: (mean, sd) tuple, acqfunc.py:86-88
+    best = np.nanmax(both)
+    z = (mean - best - xi) / sd
+    return norm.cdf(z), (mean, sd)
+
+
+# --------------------------------------------------------------------------------------
+# Bayesian optimisation driver (gpim/gpbayes/boptim.py)
+# --------------------------------------------------------------------------------------
+class boptimizer:
+    def __init__(self, X_seed, y_seed, X_full, target_function,
+                 acquisition_function='cb', exploration_steps=10, batch_size=100,
+                 batch_update=False, kernel='RBF', lengthscale=None, sparse=False,
+                 indpoints=None, gp_iterations=1000, seed=0, **kwargs):
+        self.verbose = kwargs.get("verbose", 1)
+        self.surrogate_model = reconstructor(
+            X_seed, y_seed, X_full, kernel, lengthscale, sparse, indpoints,
+            kwargs.get("learning_rate", 5e-2), gp_iterations, False, self.verbose, seed,
+            isotropic=kwargs.get("isotropic", False),
+            precision=kwargs.get("precision", "double"),
+            jitter=kwargs.get("jitter", 1.0e-6))
+        self.X_sparse, self.y_sparse, self.X_full = X_seed.copy(), y_seed.copy(), X_full
+        self.target_function = target_function
+        self.acquisition_function = acquisition_function
+        self.exploration_steps = exploration_steps
+        self.batch_update, self.batch_size = batch_update, batch_size
+        self.simulate_measurement = kwargs.get("simulate_measurement", False)
+        if self.simulate_measurement:
+            self.y_true = kwargs.get("y_true")
+            if self.y_true is None:
+                raise AssertionError("To simulate measurements, add ground truth ('y_true)")
+        self.extent = kwargs.get("extent", None)
+        self.alpha, self.beta = kwargs.get("alpha", 0), kwargs.get("beta", 1)
+        self.xi = kwargs.get("xi", 0.01)
+        self.dscale = kwargs.get("dscale", None)
+        self.batch_dscale = kwargs.get("batch_dscale", None)
+        self.batch_out_max = kwargs.get("batch_out_max", 10)
+        self.gamma = kwargs.get("gamma", 0.8)
+        self.points_mem = kwargs.get("memory", 10)
+        self.exit_strategy = kwargs.get("exit_strategy", 1)
+        self.mask = kwargs.get("mask", None)
+        self.indices_all, self.vals_all = [], []
+        self.target_func_vals, self.gp_predictions = [y_seed.copy()], []
+
+    def update_posterior(self):
+        Xn, yn = prepare_training_data(self.X_sparse, self.y_sparse)
+        self.surrogate_model.model.X = Xn
+        self.surrogate_model.model.y = yn
+        self.surrogate_model.train(verbose=self.verbose)
+
+    def evaluate_function(self, indices, y_measured=None):
+        indices = [indices] if not self.batch_update else indices
+        for idx in indices:
+            t = tuple(idx)
+            if self.simulate_measurement:
+                self.y_sparse[t] = self.y_true[t]
+            elif y_measured is not None:
+                self.y_sparse[t] = y_measured[t]
+            else:
+                arg = t if self.extent is None else tuple(
+                    i + e[0] for i, e in zip(idx, self.extent))
+                self.y_sparse[t] = self.target_function(arg)
+        self.X_sparse = get_sparse_grid(self.y_sparse, self.extent)
+        self.target_func_vals.append(self.y_sparse.copy())
+
+    def next_point(self):
+        af = self.acquisition_function
+        if af == 'cb':
+            acq, pred = confidence_bound(self.surrogate_model, self.X_full,
+                                         alpha=self.alpha, beta=self.beta)
+        elif af == 'ei':
+            acq, pred = expected_improvement(self.surrogate_model, self.X_full,
+                                             self.X_sparse, xi=self.xi)
+        elif af == 'poi':
+            acq, pred = probability_of_improvement(self.surrogate_model, self.X_full,
+                                                   self.X_sparse, xi=self.xi)
+        elif isinstance(af, types.FunctionType):
+            acq, pred = af(self.surrogate_model, self.X_full, self.X_sparse)
+        else:
+            raise NotImplementedError(
+                "Choose between 'cb', 'ei', and 'poi' acquisition functions or define your own")
+        self.gp_predictions.append(pred)
+        if self.mask is not None:
+            acq = self.mask * acq
+        order = np.argsort(acq.ravel())           # ascending; NaNs last
+        vals = acq.ravel()[order]
+        if self.mask is not None:
+            keep = ~np.isnan(vals)
+            order, vals = order[:keep.sum()], vals[keep]
+        order, vals = order[::-1][:self.batch_size], vals[::-1][:self.batch_size]
+        idx = np.stack(np.unravel_index(order, acq.shape), axis=-1)
+        vals_list, indices_list = vals.tolist(), idx.tolist()
+        if not self.batch_update:
+            return vals_list, indices_list
+        ds = self.batch_dscale
+        if ds is None:
+            ds = self.surrogate_model.kernel.lengthscale.mean().item()
+        return self.update_points(vals_list, indices_list, ds)
+
+    def update_points(self, acqfunc_values, indices, dscale):
+        _, val = self.checkvalues(indices, acqfunc_values)
+        start = np.where(np.array(acqfunc_values) == val)[0][0]
+        vals = np.array(acqfunc_values)[start:]
+        inds = np.vstack(indices)[start:]
+        vals0 = vals.copy()
+        floor = vals.min()
+        tree = spatial.cKDTree(inds)
+        picked_v, picked_i = [], []
+        cur = int(np.argmax(vals))
+        while vals[cur] > floor - 1:
+            picked_v.append(vals[cur])
+            picked_i.append(cur)
+            vals[tree.query_ball_point(inds[cur], dscale)] = floor - 1
+            cur = int(np.argmax(vals))
+        picked_v = picked_v[:self.batch_out_max]
+        out_i = inds[picked_i].tolist()[:self.batch_out_max]
+        if len(out_i) < self.batch_out_max:
+            rnd = np.random.randint(0, len(vals), self.batch_out_max - len(out_i))
+            out_i.extend(inds[rnd].tolist())
+            picked_v.extend(vals0[rnd].tolist())
+        return picked_v, out_i
+
+    def checkvalues(self, idx_list, val_list):
+        dscale = 0 if self.dscale is None else self.dscale
+
+        def too_close(idx):
+            prev = self.indices_all[-self.points_mem:]
+            d = [np.linalg.norm(np.array(idx) - np.array(p)) for p in prev][::-1]
+            lim = [dscale * self.gamma ** i for i in range(len(prev))]
+            return any(not (di > li) for di, li in zip(d, lim))
+
+        k = 0
+        if len(self.indices_all) == 0:
+            return idx_list[k], val_list[k]
+        while any(a == idx_list[k] for a in self.indices_all) or too_close(idx_list[k]):
+            k += 1
+            if k == len(idx_list):
+                k = np.random.randint(0, len(idx_list)) if self.exit_strategy else -1
+                break
+        return idx_list[k], val_list[k]
+
+    def single_step(self, e):
+        if e == 0:
+            self.surrogate_model.train()
+        vals, inds = self.next_point()
+        if not self.batch_update:
+            inds, vals = self.checkvalues(inds, vals)
+        self.evaluate_function(inds)
+        self.update_posterior()
+        if isinstance(vals, float):
+            self.indices_all.append(inds)
+            self.vals_all.append(vals)
+        else:
+            self.indices_all.extend(inds)
+            self.vals_all.extend(vals)
+
+    def run(self):
+        for i in range(self.exploration_steps):
+            self.single_step(i)

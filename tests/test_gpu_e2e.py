@@ -1,0 +1,141 @@
+"""
+End-to-end parity on the MI355X through the drop-in Python surface: the reference's own tests
+(test/test_gpreg.py, test/test_boptim.py) re-run on gpim_amd, the notebook trace, and
+reconstructor.run() against the oracle at sizes the oracle finishes in seconds.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+from numpy.testing import assert_, assert_allclose
+
+pytestmark = pytest.mark.gpu
+
+from oracle import gpim_oracle as O
+from problems import bo_test_problem, gpr_dummy_data, spiral_image
+from test_oracle_golden import ORDER, check_rows, run_notebook
+
+
+@pytest.fixture(scope="module")
+def gpim(ensure_built):
+    import gpim_amd
+    return gpim_amd
+
+
+@pytest.mark.parametrize('kernel', ['RBF', 'Matern52'])
+def test_gpr_2d(gpim, kernel):
+    """reference test/test_gpreg.py:24-36, plus numbers against the oracle."""
+    R = gpr_dummy_data()
+    X = gpim.utils.get_sparse_grid(R)
+    X_true = gpim.utils.get_full_grid(R)
+    mean, sd, hyper = gpim.reconstructor(X, R, X_true, kernel=kernel, learning_rate=0.1, iterations=2,
+                                         use_gpu=False, verbose=False).run()
+    assert_(mean.shape == sd.shape == R.shape)
+    assert_(not np.isnan(mean).any())
+    assert_(not np.isnan(sd).any())
+    mo, so, ho = O.reconstructor(X, R, X_true, kernel=kernel, learning_rate=0.1, iterations=2, verbose=0).run()
+    assert_allclose(mean, mo, rtol=0, atol=1e-9)
+    assert_allclose(sd, so, rtol=0, atol=1e-9)
+    assert_allclose(hyper["lengthscale"], ho["lengthscale"], rtol=1e-11)
+    assert_allclose(hyper["variance"], ho["variance"], rtol=1e-11)
+    assert_allclose(hyper["noise"], ho["noise"], rtol=1e-11)
+
+
+@pytest.mark.parametrize("acqf", ["ei", "poi", "cb"])
+def test_boptim_golden(gpim, acqf, golden_dir, tmp_path):
+    """reference test/test_boptim.py:42-58 on the HIP engine: 21 trainings x 1000 iterations,
+    20 acquisition sweeps; the queried set must reproduce the reference's golden vector."""
+    trial_func, Z_sparse = bo_test_problem()
+    X_full = gpim.utils.get_full_grid(Z_sparse)
+    X_sparse = gpim.utils.get_sparse_grid(Z_sparse)
+    bo = gpim.boptimizer(X_sparse, Z_sparse, X_full, trial_func, acquisition_function=acqf,
+                         exploration_steps=20, use_gpu=False, verbose=0,
+                         filename=str(tmp_path / "bo"))
+    bo.run()
+    expected = np.load(os.path.join(golden_dir, "test_%s.npy" % acqf))
+    assert_allclose(bo.target_func_vals[-1], expected)
+    assert [tuple(i) for i in bo.indices_all] == ORDER[acqf]
+    saved = np.load(str(tmp_path / "bo.npy"), allow_pickle=True).item()
+    assert set(saved) == {"gp_pred", "func_val", "inds_all", "vals_all"}
+
+
+@pytest.mark.parametrize("which,nsteps", [("ei", 50), ("ei_mask", 50), ("ei_dscale", 20), ("custom", 20)])
+def test_notebook_trace(gpim, which, nsteps, golden_dir, tmp_path):
+    trace = json.load(open(os.path.join(golden_dir, "notebook_trace.json")))["runs"][which]
+
+    def factory(Z_sparse, trial_func, af, n, kw):
+        bo = gpim.boptimizer(gpim.utils.get_sparse_grid(Z_sparse), Z_sparse, gpim.utils.get_full_grid(Z_sparse),
+                             trial_func, acquisition_function=af, exploration_steps=n, use_gpu=False, verbose=0,
+                             filename=str(tmp_path / "nb"), **kw)
+
+        def getter(b):
+            k = b.surrogate_model.model
+            return [np.around(k.kernel.variance.item(), 4), *np.around(k.kernel.lengthscale.tolist(), 4),
+                    np.around(k.noise.item(), 7)]
+        return bo, getter
+    rows, bo = run_notebook(which, nsteps, factory)
+    assert len(rows) == nsteps + 1
+    check_rows(rows, trace)
+
+
+def test_run_medium_vs_oracle(gpim):
+    """64x64 spiral image (N ~ 1000, M = 4096), 30 Adam steps, RBF: outputs vs the oracle."""
+    R, _ = spiral_image(size=64, keep=0.25, seed=5)
+    X, Xf = gpim.utils.get_sparse_grid(R), gpim.utils.get_full_grid(R)
+    kw = dict(kernel="RBF", lengthscale=[[1., 1.], [4., 4.]], learning_rate=0.1, iterations=30, verbose=0)
+    mean, sd, hyper = gpim.reconstructor(X, R, Xf, **kw).run()
+    torch.set_num_threads(8)
+    mo, so, ho = O.reconstructor(X, R, Xf, **kw).run()
+    torch.set_num_threads(1)
+    assert_allclose(hyper["lengthscale"][-1], ho["lengthscale"][-1], rtol=1e-8)
+    assert_allclose(hyper["noise"][-1], ho["noise"][-1], rtol=1e-8)
+    rmse_m = np.sqrt(np.mean((mean - mo) ** 2))
+    rmse_s = np.sqrt(np.mean((sd - so) ** 2))
+    assert rmse_m < 1e-9 and rmse_s < 1e-9, (rmse_m, rmse_s)
+
+
+def test_predict_semantics(gpim):
+    """predict() replaces Xtest/fulldims; Xtest=None falls back to the training points with a
+    warning; hyperparams lists grow across train() calls."""
+    R = gpr_dummy_data(1)
+    X, Xf = gpim.utils.get_sparse_grid(R), gpim.utils.get_full_grid(R)
+    rec = gpim.reconstructor(X, R, None, iterations=3, verbose=0)
+    rec.train()
+    rec.train(iterations=2)
+    assert len(rec.hyperparams["noise"]) == 5 and len(rec.hyperparams["lengthscale"][0]) == 2
+    with pytest.warns(UserWarning):
+        rec.fulldims = (rec.X.shape[0],)
+        m, s = rec.predict()
+    assert m.shape == (rec.X.shape[0],)
+    m2, s2 = rec.predict(Xf[:, :5, :7])
+    assert m2.shape == (5, 7) and rec.fulldims == (5, 7)
+    with pytest.raises(KeyError):
+        gpim.reconstructor(X, R, Xf, kernel="Linear", verbose=0)
+    iso = gpim.reconstructor(X, R, Xf, isotropic=True, iterations=2, verbose=0)
+    iso.train()
+    assert isinstance(iso.hyperparams["lengthscale"][0], float)
+
+
+def test_3d_and_4d_inputs(gpim):
+    """d = 3 and d = 4 coordinate grids run and agree with the oracle."""
+    rng = np.random.default_rng(0)
+    R3 = rng.standard_normal((6, 7, 5))
+    R3[rng.random((6, 7)) < 0.5] = np.nan
+    X3, X3f = gpim.utils.get_sparse_grid(R3), gpim.utils.get_full_grid(R3)
+    kw = dict(kernel="Matern52", learning_rate=0.1, iterations=5, verbose=0)
+    mean, sd, _ = gpim.reconstructor(X3, R3, X3f, **kw).run()
+    mo, so, _ = O.reconstructor(X3, R3, X3f, **kw).run()
+    assert mean.shape == R3.shape
+    assert_allclose(mean, mo, atol=1e-10)
+    assert_allclose(sd, so, atol=1e-10)
+    R4 = rng.standard_normal((4, 3, 5, 2))
+    X4f = gpim.utils.get_full_grid(R4)
+    obs = rng.random(R4.shape) < 0.5
+    X4 = X4f.copy(); X4[:, ~obs] = np.nan
+    R4s = np.where(obs, R4, np.nan)
+    mean, sd, _ = gpim.reconstructor(X4, R4s, X4f, **kw).run()
+    mo, so, _ = O.reconstructor(X4, R4s, X4f, **kw).run()
+    assert_allclose(mean, mo, atol=1e-10)
+    assert_allclose(sd, so, atol=1e-10)
