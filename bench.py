@@ -1,0 +1,190 @@
+#!/usr/bin/env python
+"""
+bench.py -- GP fit + predict throughput of the exact-GP hot path on MI355X.
+
+Workload (BASELINE.json configs[1], made concrete in SURVEY 8(d) "Config 2"): a synthetic
+256x256 twisted-bilayer lattice image, 25 % of the pixels observed (N = 16384 training points,
+M = 65536 grid points, d = 2), Matern52 kernel, lengthscale bounds [[1,1],[20,20]], lr 0.1,
+T = 100 Adam iterations, fp64, exact GP.  One STEP = one complete reconstructor fit + predict
+(the work of ``gpim_amd.reconstructor(...).run()``) with the inputs already resident in HBM and
+the hyper-parameters reset to their seeded initial draw, so every step does identical work.
+
+metric  : "GP fit+predict grid-points/sec" = (M * steps * n_gpus) / wall time.
+N > 1   : one process per GPU (torchrun contract); every rank reconstructs its own image of the
+          stack (seed = rank) -- independent units, no collective on the data path -- and the
+          (mean, sd) maps are gathered to rank 0 over RCCL inside the timed region.  Weak scaling.
+roofline: the dominant kernel is the fp64 MFMA tile engine; the instance timed live with HIP
+          events is the K^-1 = L^-T L^-1 launch (gemm_tiles_kernel<true,true,0>, exactly one
+          launch per Adam iteration, algorithmic N^3/3 flop), priced against the fp64 matrix
+          peak of 78.6 TFLOP/s.
+cpu_baseline: the CPU oracle (torch fp64 + autograd restatement of the reference, kind "port")
+          timed on rank 0's host cores on a bounded sample and extrapolated (see "sample").
+"""
+import argparse
+import ctypes
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+FP64_MFMA_PEAK_TFLOPS = 78.6      # MI355X fp64 matrix peak (vendor spec; = vector fp64 rate)
+
+WORKLOAD = dict(size=256, frac=0.25, kernel="Matern52", lengthscale=[[1., 1.], [20., 20.]],
+                learning_rate=0.1, iterations=100)
+
+
+def cpu_baseline(N, M, T, budget_s=25.0):
+    """Times the oracle's Adam iteration (loss + backward + step) and prediction on growing
+    sub-problems of the same workload until ~budget_s is spent, then extrapolates by the
+    O(N^3) / O(N^2 M) cost model to the full size."""
+    from oracle import gpim_oracle as O
+    from problems import lattice_image
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    spent, n, last = 0.0, 512, None
+    while n <= N:
+        size = int(round(math.sqrt(n / WORKLOAD["frac"])))
+        R, _ = lattice_image(size=size, frac=WORKLOAD["frac"], seed=1)
+        X, Xf = O.get_sparse_grid(R), O.get_full_grid(R)
+        rec = O.reconstructor(X, R, Xf, kernel=WORKLOAD["kernel"], lengthscale=WORKLOAD["lengthscale"],
+                              learning_rate=WORKLOAD["learning_rate"], iterations=1, verbose=0)
+        t0 = time.time()
+        rec.train()
+        t_it = time.time() - t0
+        t0 = time.time()
+        rec.predict()
+        t_pr = time.time() - t0
+        n_eff, m_eff = rec.X.shape[0], size * size
+        last = (n_eff, m_eff, t_it, t_pr)
+        spent += t_it + t_pr
+        # next size costs ~8x; stop when it would blow the budget
+        if spent + 8 * (t_it + t_pr) > budget_s:
+            break
+        n *= 2
+    n_eff, m_eff, t_it, t_pr = last
+    t_full = T * t_it * (N / n_eff) ** 3 + t_pr * (N / n_eff) ** 2 * (M / m_eff)
+    sample = ("oracle (torch CPU fp64, autograd) timed at N=%d, M=%d: 1 Adam iteration %.2f s, "
+              "1 predict %.2f s; extrapolated to N=%d, M=%d, T=%d by N^3 (fit) and N^2*M (predict)"
+              % (n_eff, m_eff, t_it, t_pr, N, M, T))
+    return {"value": M / t_full, "unit": "grid-points/s", "cores": threads, "kind": "port",
+            "sample": sample}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--iterations", type=int, default=WORKLOAD["iterations"],
+                    help="Adam iterations per step (the named workload uses 100)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    import gpim_amd
+    from gpim_amd import _lib, dist as gdist
+    from problems import lattice_image
+
+    rank, world, local_rank = gdist.init_from_env()
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    # ---- build this rank's unit and move it to HBM (untimed)
+    R, _ = lattice_image(size=WORKLOAD["size"], frac=WORKLOAD["frac"], seed=1 + 10 * rank)
+    X, Xf = gpim_amd.utils.get_sparse_grid(R), gpim_amd.utils.get_full_grid(R)
+    rec = gpim_amd.reconstructor(X, R, Xf, kernel=WORKLOAD["kernel"], lengthscale=WORKLOAD["lengthscale"],
+                                 learning_rate=WORKLOAD["learning_rate"], iterations=args.iterations,
+                                 verbose=0, seed=0)
+    N, M = rec.X.shape[0], rec.Xtest.shape[0]
+    u0 = rec._u.clone()
+    lib, h = rec._handle.lib, rec._handle.h
+
+    def step():
+        rec._u.copy_(u0)
+        rec.train()
+        rec.predict()
+        mean_d, sd_d = rec._last_pred
+        if world > 1:
+            res = gdist.gather_to_root({rank: torch.stack([mean_d, sd_d])}, world, (2, M), device=dev)
+        else:
+            res = torch.stack([mean_d, sd_d]).unsqueeze(0)
+        return res
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    lib.gpimhip_timing_enable(h, 1)
+    tot, cnt = ctypes.c_double(), ctypes.c_int64()
+    for s in range(4):
+        lib.gpimhip_timing_read(h, s, ctypes.byref(tot), ctypes.byref(cnt))     # clear
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    lib.gpimhip_timing_enable(h, 0)
+    stage_ms = {}
+    for s, name in enumerate(["potrf", "trtri", "lauum", "predict_var"]):
+        lib.gpimhip_timing_read(h, s, ctypes.byref(tot), ctypes.byref(cnt))
+        stage_ms[name] = (tot.value, cnt.value)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    if rank == 0:
+        # sanity: the timed output is finite and shaped (units, 2, M)
+        assert res.shape == (world, 2, M) and bool(torch.isfinite(res).all())
+        lau_ms, lau_n = stage_ms["lauum"]
+        flops_launch = N ** 3 / 3.0
+        achieved = flops_launch / (lau_ms / max(lau_n, 1) * 1e-3) / 1e12 if lau_n else None
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_lauum.json")
+        if os.path.exists(pmc):
+            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+        out = {
+            "metric": "GP fit+predict grid-points/sec",
+            "value": M * args.steps * world / elapsed,
+            "unit": "grid-points/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": ("C2: 256x256 synthetic twisted-lattice image, 25%% observed "
+                                   "(N=%d, M=%d, d=2), Matern52 exact GP, T=%d Adam its (lr 0.1) + predict; "
+                                   "one image per GPU") % (N, M, args.iterations),
+                       "N": N, "M": M, "iterations": args.iterations, "kernel": WORKLOAD["kernel"]},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": (achieved / FP64_MFMA_PEAK_TFLOPS) if achieved else None,
+                         "traffic": traffic,
+                         "kernel": "gemm_tiles_kernel<true,true,0> (K^-1 = L^-T L^-1, N^3/3 flop per launch)",
+                         "launches": lau_n, "avg_launch_ms": lau_ms / max(lau_n, 1)},
+            "stages_ms_per_call": {k: (v[0] / v[1] if v[1] else None) for k, v in stage_ms.items()},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(N, M, args.iterations)
+        elif world == 1:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

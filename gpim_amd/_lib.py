@@ -37,6 +37,9 @@ _PROTOS = {
     "gpimhip_version": (ctypes.c_int, []),
     "gpimhip_workspace_bytes": (ctypes.c_int64, [ctypes.c_void_p]),
     "gpimhip_sync": (ctypes.c_int, [ctypes.c_void_p]),
+    "gpimhip_timing_enable": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "gpimhip_timing_read": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_double),
+                                           ctypes.POINTER(ctypes.c_int64)]),
     "gpimhip_kmat": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ModelStruct), c_dp, ctypes.c_int64, c_dp,
                                     ctypes.c_int64, c_dp, ctypes.c_double, c_dp, ctypes.c_int64]),
     "gpimhip_potrf": (ctypes.c_int, [ctypes.c_void_p, c_dp, ctypes.c_int64, ctypes.c_int64, c_dp]),

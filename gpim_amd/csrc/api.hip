@@ -132,6 +132,25 @@ static void lower_patch_order(std::vector<TileDesc>& out, int lo, int hi, int kb
                     if (j <= i) out.push_back({i, j, kb0, kb1});
 }
 
+// rectangular tile set rows [r0,r1) x cols [c0,c1) in 8x8 patches; krange(ci,cj) -> {kb0,kb1}
+template <typename F>
+static void rect_patch_order(std::vector<TileDesc>& out, int r0, int r1, int c0, int c1, bool rows_desc,
+                             bool cols_desc, F krange) {
+    const int nrg = (r1 - r0 + 7) / 8, ncg = (c1 - c0 + 7) / 8;
+    for (int a = 0; a < nrg; ++a) {
+        const int ig = rows_desc ? nrg - 1 - a : a;
+        for (int bq = 0; bq < ncg; ++bq) {
+            const int jg = cols_desc ? ncg - 1 - bq : bq;
+            for (int i = r0 + ig * 8; i < std::min(r1, r0 + ig * 8 + 8); ++i)
+                for (int j = c0 + jg * 8; j < std::min(c1, c0 + jg * 8 + 8); ++j) {
+                    int k0, k1;
+                    krange(i, j, k0, k1);
+                    out.push_back({i, j, k0, k1});
+                }
+        }
+    }
+}
+
 struct TriNode { int lo, mid, hi; };
 static int tri_build(int lo, int hi, std::vector<std::vector<TriNode>>& levels) {
     if (hi - lo <= 1) return 0;
@@ -176,21 +195,26 @@ int plan_ensure(gpimhip_ctx* h, int nb) {
     P.tri_x.clear();
     for (auto& lv : levels) {
         size_t s = tl.size();
+        // T = L21 * X11: k-range [cj, mid) -- longest for the leftmost columns
         for (auto& nd : lv)
-            for (int ci = nd.mid; ci < nd.hi; ++ci)
-                for (int cj = nd.lo; cj < nd.mid; ++cj) tl.push_back({ci, cj, cj, nd.mid});
+            rect_patch_order(tl, nd.mid, nd.hi, nd.lo, nd.mid, false, false,
+                             [&](int, int cj, int& k0, int& k1) { k0 = cj; k1 = nd.mid; });
         P.tri_t.push_back(mark(s));
         s = tl.size();
+        // X21 = -X22 * T: k-range [mid, ci] -- longest for the bottom rows
         for (auto& nd : lv)
-            for (int ci = nd.hi - 1; ci >= nd.mid; --ci)
-                for (int cj = nd.lo; cj < nd.mid; ++cj) tl.push_back({ci, cj, nd.mid, ci + 1});
+            rect_patch_order(tl, nd.mid, nd.hi, nd.lo, nd.mid, true, false,
+                             [&](int ci, int, int& k0, int& k1) { k0 = nd.mid; k1 = ci + 1; });
         P.tri_x.push_back(mark(s));
     }
-    // K^-1 = L^-T L^-1 (lower): k-range [ci, nb), longest first
+    // K^-1 = L^-T L^-1 (lower): k-range [ci, nb), longest first, 8x8 patches
     {
         size_t s = tl.size();
-        for (int ci = 0; ci < nb; ++ci)
-            for (int cj = 0; cj <= ci; ++cj) tl.push_back({ci, cj, ci, nb});
+        for (int ig = 0; ig <= (nb - 1) / 8; ++ig)
+            for (int jg = 0; jg <= ig; ++jg)
+                for (int i = ig * 8; i < std::min(nb, ig * 8 + 8); ++i)
+                    for (int j = jg * 8; j < std::min(nb, jg * 8 + 8); ++j)
+                        if (j <= i) tl.push_back({i, j, i, nb});
         P.lauum = mark(s);
     }
     P.n_tiles = (int64_t)tl.size();
@@ -250,8 +274,10 @@ int launch_trtri(gpimhip_ctx* h, double* A, double* Tm, int64_t np, int64_t ld) 
     GP_TRY(launch_diag_inv_copy(h, A, ld, nb));
     for (size_t lv = 0; lv < P.tri_t.size(); ++lv) {
         GemmArgs g1 = gemm_args(A, ld, A, ld, Tm, ld, 1.0, 0.0, P.d_tiles + P.tri_t[lv].off, P.tri_t[lv].n);
+        g1.chunk = 64;
         GP_TRY(launch_gemm(h, false, true, EPI_STORE, g1));
         GemmArgs g2 = gemm_args(A, ld, Tm, ld, A, ld, -1.0, 0.0, P.d_tiles + P.tri_x[lv].off, P.tri_x[lv].n);
+        g2.chunk = 64;
         GP_TRY(launch_gemm(h, false, true, EPI_STORE, g2));
     }
     return GPIMHIP_OK;
@@ -263,8 +289,22 @@ int launch_lauum(gpimhip_ctx* h, const double* A, double* B, int64_t np, int64_t
     GP_TRY(plan_ensure(h, nb));
     const LinalgPlan& P = h->plan;
     GemmArgs g = gemm_args(A, ld, A, ld, B, ld, 1.0, 0.0, P.d_tiles + P.lauum.off, P.lauum.n);
+    g.chunk = 64;
     return launch_gemm(h, true, true, EPI_STORE, g);
 }
+
+// stage timers: 0 potrf, 1 trtri, 2 lauum (one gemm launch), 3 predictive-variance product
+struct StageTimer {
+    gpimhip_ctx* h; int stage; hipEvent_t e1 = nullptr;
+    StageTimer(gpimhip_ctx* h_, int s) : h(h_), stage(s) {
+        if (!h->timing) return;
+        hipEvent_t e0;
+        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { e1 = nullptr; return; }
+        hipEventRecord(e0, h->stream);
+        h->ev[stage].push_back({e0, e1});
+    }
+    ~StageTimer() { if (e1) hipEventRecord(e1, h->stream); }
+};
 
 static int check_model(const gpimhip_model_t* m) {
     if (!m || m->dim < 1 || m->dim > GPIMHIP_MAX_DIM || (m->n_ls != 1 && m->n_ls != m->dim) ||
@@ -281,8 +321,8 @@ static int factor_at_u(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X
     const int64_t np = h->np;
     GP_TRY(launch_theta(h, m, u));
     GP_TRY(launch_kmat(h, m, X, N, nullptr, N, h->theta, 0.0, 1, h->A, np, np, np, 1, 1));
-    GP_TRY(launch_potrf(h, h->A, np, np, h->info));
-    GP_TRY(launch_trtri(h, h->A, h->Tm, np, np));
+    { StageTimer t(h, 0); GP_TRY(launch_potrf(h, h->A, np, np, h->info)); }
+    { StageTimer t(h, 1); GP_TRY(launch_trtri(h, h->A, h->Tm, np, np)); }
     GP_TRY(launch_trmv_lower(h, h->A, np, np, h->ypad, h->z));
     GP_TRY(launch_gemv_t(h, h->A, np, np, np, h->z, h->alpha, 1));
     (void)y;
@@ -294,7 +334,7 @@ static int loss_grad_at_u(gpimhip_ctx* h, const gpimhip_model_t* m, const double
                           double* hist_row) {
     const int64_t np = h->np;
     GP_TRY(factor_at_u(h, m, X, y, N, u));
-    GP_TRY(launch_lauum(h, h->A, h->B, np, np));
+    { StageTimer t(h, 2); GP_TRY(launch_lauum(h, h->A, h->B, np, np)); }
     GP_TRY(launch_grad_reduce(h, m, h->B, np, X, N, (int)(np / NB), h->alpha));
     GP_TRY(launch_finalize(h, m, N, np, u, do_adam, st, loss_out, grad_out, hist_row));
     return GPIMHIP_OK;
@@ -359,6 +399,29 @@ int gpimhip_destroy(gpimhip_handle h) {
 }
 
 int64_t gpimhip_workspace_bytes(gpimhip_handle h) { return h ? h->bytes : 0; }
+
+int gpimhip_timing_enable(gpimhip_handle h, int enable) {
+    if (!h) return GPIMHIP_E_BADARG;
+    h->timing = enable != 0;
+    return GPIMHIP_OK;
+}
+
+int gpimhip_timing_read(gpimhip_handle h, int stage, double* total_ms, int64_t* count) {
+    if (!h || stage < 0 || stage > 3 || !total_ms || !count) return GPIMHIP_E_BADARG;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    double tot = 0.0;
+    for (auto& pr : h->ev[stage]) {
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, pr.first, pr.second);
+        tot += ms;
+        hipEventDestroy(pr.first);
+        hipEventDestroy(pr.second);
+    }
+    *total_ms = tot;
+    *count = (int64_t)h->ev[stage].size();
+    h->ev[stage].clear();
+    return GPIMHIP_OK;
+}
 
 int gpimhip_sync(gpimhip_handle h) {
     if (!h) return GPIMHIP_E_BADARG;
@@ -456,11 +519,12 @@ int gpimhip_predict_exact(gpimhip_handle h, const gpimhip_model_t* m, const doub
         GP_TRY(launch_gemv_t(h, h->Ks, mc, np, cpad, h->alpha, h->mean_tmp, 0));
         GP_TRY(launch_copy_slice(h, h->mean_tmp, mean_out + m0, cnt));
         GemmArgs g = gemm_args(h->A, np, h->Ks, mc, nullptr, 0, 1.0, 0.0, h->pred_tiles, 0);
+        g.chunk = 64;
         g.colpart = h->colpart;
         g.ld_colpart = mc;
         // a ragged last chunk still sweeps all column tiles of the slab (stale columns are ignored)
         g.ntiles = (int)h->pred_ntiles;
-        GP_TRY(launch_gemm(h, false, true, EPI_COLSUMSQ, g));
+        { StageTimer t(h, 3); GP_TRY(launch_gemm(h, false, true, EPI_COLSUMSQ, g)); }
         GP_TRY(launch_predict_var(h, mc, nb, m0, cnt, var_out));
     }
     return finish_and_check(h);

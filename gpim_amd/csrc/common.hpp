@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <string>
 #include <vector>
+#include <utility>
 #include "../../include/gpimhip.h"
 
 #define NB 128            // block size of every blocked algorithm (rows/cols of one tile)
@@ -101,6 +102,9 @@ struct gpimhip_ctx {
     int64_t pred_ntiles = 0;
     int64_t bytes = 0;
     LinalgPlan plan;
+    // optional stage timing (bench.py): HIP event pairs on the handle's stream
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[4];
     // top-k scratch
     unsigned long long* keys = nullptr;
     int64_t keys_cap = 0;
@@ -121,6 +125,7 @@ struct GemmArgs {
     double* C; int64_t ldc; int c_roff, c_coff;
     double alpha, beta;
     const TileDesc* tiles; int ntiles;
+    int chunk;                             // XCD dealing: 0 = contiguous slices, >0 = round-robin chunks
     double* colpart; int64_t ld_colpart;   // EPI_COLSUMSQ: colpart[ci*ld + cj*128 + col]
 };
 int launch_gemm(gpimhip_ctx* h, bool a_km, bool b_km, int epi, const GemmArgs& g);

@@ -71,11 +71,25 @@ __global__ __launch_bounds__(256, 2) void gemm_tiles_kernel(GemmArgs g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
 
-    // XCD-aware bijective remap: block b runs on XCD b%8; give each XCD a contiguous slice of
-    // the tile list so neighbouring tiles (shared operand panels) hit the same L2.
+    // XCD-aware bijective remap (block b runs on XCD b%8, in order b/8 on that XCD).
+    //  chunk == 0: every XCD gets one contiguous slice of the tile list -- best L2 reuse when all
+    //              tiles cost the same (SYRK-shaped trailing updates).
+    //  chunk  > 0: the list is dealt to the XCDs round-robin in chunks of that many tiles (one 8x8
+    //              patch), so lists sorted by decreasing k-range stay balanced across XCDs.
     const int n = g.ntiles, b = blockIdx.x;
-    const int q = n >> 3, r = n & 7, x = b & 7, yy = b >> 3;
-    const int p = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + yy;
+    int p;
+    if (g.chunk == 0) {
+        const int q = n >> 3, r = n & 7, x = b & 7, yy = b >> 3;
+        p = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + yy;
+    } else {
+        const int C = g.chunk, full = (n / (8 * C)) * (8 * C);
+        if (b < full) {
+            const int x = b & 7, y = b >> 3;
+            p = ((y / C) * 8 + x) * C + (y % C);
+        } else {
+            p = b;
+        }
+    }
     const TileDesc t = g.tiles[p];
     const int nsteps = (t.kb1 - t.kb0) * (NB / GEMM_BK);
 

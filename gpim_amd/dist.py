@@ -1,0 +1,145 @@
+"""
+dist.py -- multi-GPU sharding of independent GP work units (one process per GPU, RCCL over xGMI).
+
+The reference is single-process (no distributed backend).  The exact-GP hot path
+shards in two embarrassingly parallel ways:
+  * independent units -- spectral slices of a cube, frames of an image stack -- each a complete
+    ``reconstructor(...).run()``; units are dealt round-robin to ranks, there is no collective on
+    the data path, and one ``gather`` at the end brings (mean, sd) to rank 0;
+  * acquisition candidates -- every rank sweeps a contiguous block of the test grid and an
+    ``all_gather`` of (value, flat index) pairs yields the global arg-max / top-k on every rank.
+Messages are a few KB to a few MB, so the collectives are latency-bound; nothing here depends
+on xGMI link bandwidth.  Backend "nccl" is RCCL on ROCm; "gloo" is used by the CPU tests.
+"""
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun contract).
+    Returns (rank, world_size, local_rank).  Single-process runs need no initialisation."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local_rank
+
+
+def world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard_units(n_units, rank=None, world_size=None):
+    """Indices of the work units owned by `rank` (round-robin, so ragged costs average out)."""
+    if rank is None or world_size is None:
+        rank, world_size = world()
+    return list(range(rank, n_units, world_size))
+
+
+def gather_to_root(local, n_units, unit_shape, device=None, dtype=torch.float64):
+    """local: {unit index: tensor of shape unit_shape}.  Returns on rank 0 a tensor
+    (n_units, *unit_shape) with every unit in place (None on other ranks).  One gather of a
+    fixed-size slab per rank; ranks owning fewer units pad with NaN."""
+    rank, ws = world()
+    per = (n_units + ws - 1) // ws
+    if device is None:
+        device = next(iter(local.values())).device if local else torch.device("cpu")
+    slab = torch.full((per,) + tuple(unit_shape), float("nan"), dtype=dtype, device=device)
+    for slot, idx in enumerate(shard_units(n_units, rank, ws)):
+        slab[slot] = local[idx].to(device=device, dtype=dtype)
+    if ws == 1:
+        out = slab
+        parts = [slab]
+    else:
+        parts = [torch.empty_like(slab) for _ in range(ws)] if rank == 0 else None
+        dist.gather(slab, parts, dst=0)
+        if rank != 0:
+            return None
+    full = torch.empty((n_units,) + tuple(unit_shape), dtype=dtype, device=device)
+    for r in range(ws):
+        for slot, idx in enumerate(shard_units(n_units, r, ws)):
+            full[idx] = parts[r][slot]
+    return full
+
+
+def run_units(units, unit_fn, out_shape, device=None):
+    """Deal `units` over the ranks, run ``unit_fn(unit) -> (mean, sd)`` on the owned ones and
+    gather; returns (mean_all, sd_all) of shape (len(units), *out_shape) on rank 0, else None."""
+    rank, ws = world()
+    mine = {}
+    for idx in shard_units(len(units), rank, ws):
+        mean, sd = unit_fn(units[idx])
+        mean, sd = torch.as_tensor(mean), torch.as_tensor(sd)
+        mine[idx] = torch.stack([mean.reshape(out_shape), sd.reshape(out_shape)])
+    if device is None and mine:
+        device = next(iter(mine.values())).device
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if (
+            dist.is_initialized() and dist.get_backend() == "nccl") else torch.device("cpu")
+    full = gather_to_root(mine, len(units), (2,) + tuple(out_shape), device=device)
+    if full is None:
+        return None
+    return full[:, 0], full[:, 1]
+
+
+def reconstruct_slices(cube, axis=-1, **recon_kwargs):
+    """Independent 2D GP reconstruction of every slice of a 3D cube along `axis` (config C3 of
+    SURVEY 8(d)), slices sharded over the ranks.  Returns (mean, sd) cubes on rank 0."""
+    from . import gprutils
+    from .gpr import reconstructor
+    cube = np.moveaxis(np.asarray(cube), axis, 0)
+    units = [cube[i] for i in range(cube.shape[0])]
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    def fit(R):
+        X, Xf = gprutils.get_sparse_grid(R), gprutils.get_full_grid(R)
+        rec = reconstructor(X, R, Xf, **recon_kwargs)
+        rec.train()
+        rec.predict()
+        return rec._last_pred
+
+    res = run_units(units, fit, cube.shape[1:], device=dev)
+    if res is None:
+        return None
+    mean, sd = res
+    return (np.moveaxis(mean.cpu().numpy(), 0, axis), np.moveaxis(sd.cpu().numpy(), 0, axis))
+
+
+def candidate_block(M, rank=None, world_size=None):
+    """Contiguous [start, stop) block of the M test-grid candidates owned by `rank`."""
+    if rank is None or world_size is None:
+        rank, world_size = world()
+    per = (M + world_size - 1) // world_size
+    return min(rank * per, M), min((rank + 1) * per, M)
+
+
+def global_topk(local_vals, local_idx, k):
+    """local_vals / local_idx: this rank's descending top-k (values, GLOBAL flat indices), padded
+    with -inf / -1 to length k.  All-gathers the 2*k*world numbers and returns the global
+    descending top-k on every rank (ties: larger flat index first, as gpimhip_topk)."""
+    rank, ws = world()
+    vals = torch.as_tensor(local_vals, dtype=torch.float64).reshape(-1)
+    idx = torch.as_tensor(local_idx, dtype=torch.int64).reshape(-1).to(vals.device)
+    if ws > 1:
+        vs = [torch.empty_like(vals) for _ in range(ws)]
+        ix = [torch.empty_like(idx) for _ in range(ws)]
+        dist.all_gather(vs, vals)
+        dist.all_gather(ix, idx)
+        vals, idx = torch.cat(vs), torch.cat(ix)
+    keep = idx >= 0
+    vals, idx = vals[keep], idx[keep]
+    order = sorted(range(len(vals)), key=lambda i: (vals[i].item(), idx[i].item()), reverse=True)[:k]
+    order = torch.as_tensor(order, dtype=torch.int64, device=vals.device)
+    return vals[order], idx[order]

@@ -148,6 +148,15 @@ int gpimhip_nanmax(gpimhip_handle h, const double* x, int64_t n, double* out);
 int gpimhip_topk(gpimhip_handle h, const double* acq, int64_t M, int32_t k, int32_t keep_nan,
                  double* vals_out, int64_t* idx_out, int64_t* count_out);
 
+/* Stage timing for bench.py (HIP events on the handle's stream, recorded only while enabled).
+ * stage: 0 = Cholesky (all launches of one factorisation), 1 = triangular inverse,
+ *        2 = K^-1 = L^-T L^-1 (exactly one gemm_tiles_kernel<true,true,0> launch, N^3/3 flop),
+ *        3 = predictive-variance product L^-1 K(X,X*) (one launch per test-point slab).
+ * gpimhip_timing_read synchronises, returns the summed milliseconds and the number of timed
+ * intervals since the last read, and clears them. */
+int gpimhip_timing_enable(gpimhip_handle h, int enable);
+int gpimhip_timing_read(gpimhip_handle h, int stage, double* total_ms, int64_t* count);
+
 /* Block until everything enqueued on the handle's stream has finished. */
 int gpimhip_sync(gpimhip_handle h);
 

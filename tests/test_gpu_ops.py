@@ -216,19 +216,28 @@ def test_acquisition_sweep(eng, kind, ref):
     p0, p1 = (0.3, 1.7) if kind == "cb" else (0.35, 0.01)
     if kind == "cb":
         expect = p0 * mean + p1 * sd
+        scale = np.abs(p0 * mean) + np.abs(p1 * sd)
     else:
-        z = (mean - p0 - p1) / sd
-        expect = (mean - p0 - p1) * norm.cdf(z) + sd * norm.pdf(z) if kind == "ei" else norm.cdf(z)
+        imp = mean - p0 - p1
+        z = imp / sd
+        expect = imp * norm.cdf(z) + sd * norm.pdf(z) if kind == "ei" else norm.cdf(z)
+        # EI cancels catastrophically in the lower tail: bound the error by the size of its terms
+        # and exp(-z^2/2) carries the rounding of its argument (relative error ~ eps * z^2 / 2)
+        scale = np.abs(imp) * norm.cdf(z) + sd * norm.pdf(z) if kind == "ei" else norm.cdf(z)
+        scale = scale * (1.0 + 0.02 * z * z)
     md, sdd = torch.from_numpy(mean).cuda(), torch.from_numpy(sd).cuda()
     out = torch.empty(M, dtype=torch.float64, device="cuda")
     _lib.check(H.lib.gpimhip_acq(H.h, _lib.ACQ_IDS[kind], _lib.ptr(md), _lib.ptr(sdd), M, p0, p1, None, _lib.ptr(out)))
-    assert_allclose(out.cpu().numpy(), expect, rtol=1e-13, atol=1e-300)
+    assert np.all(np.abs(out.cpu().numpy() - expect) <= 2e-14 * scale + 1e-300)
     mask = np.ones(M)
     mask[::3] = np.nan
     maskd = torch.from_numpy(mask).cuda()
     _lib.check(H.lib.gpimhip_acq(H.h, _lib.ACQ_IDS[kind], _lib.ptr(md), _lib.ptr(sdd), M, p0, p1, _lib.ptr(maskd),
                                  _lib.ptr(out)))
-    assert_allclose(out.cpu().numpy(), mask * expect, rtol=1e-13, atol=1e-300)
+    got = out.cpu().numpy()
+    assert np.array_equal(np.isnan(got), np.isnan(mask))
+    ok = ~np.isnan(mask)
+    assert np.all(np.abs(got[ok] - expect[ok]) <= 2e-14 * scale[ok] + 1e-300)
 
 
 def test_nanmax_and_topk(eng):
