@@ -135,12 +135,16 @@ static void lower_patch_order(std::vector<TileDesc>& out, int lo, int hi, int kb
 // rectangular tile set rows [r0,r1) x cols [c0,c1) in 8x8 patches; krange(ci,cj) -> {kb0,kb1}
 template <typename F>
 static void rect_patch_order(std::vector<TileDesc>& out, int r0, int r1, int c0, int c1, bool rows_desc,
-                             bool cols_desc, F krange) {
+                             bool col_major, F krange) {
+    // col_major: walk patch columns in the outer loop (use when the k-range depends on cj), else
+    // patch rows (k-range depends on ci).  Either way consecutive patches cost about the same, so
+    // dealing them round-robin to the 8 XCDs stays balanced.
     const int nrg = (r1 - r0 + 7) / 8, ncg = (c1 - c0 + 7) / 8;
-    for (int a = 0; a < nrg; ++a) {
-        const int ig = rows_desc ? nrg - 1 - a : a;
-        for (int bq = 0; bq < ncg; ++bq) {
-            const int jg = cols_desc ? ncg - 1 - bq : bq;
+    const int nouter = col_major ? ncg : nrg, ninner = col_major ? nrg : ncg;
+    for (int a = 0; a < nouter; ++a)
+        for (int bq = 0; bq < ninner; ++bq) {
+            int ig = col_major ? bq : a, jg = col_major ? a : bq;
+            if (rows_desc) ig = nrg - 1 - ig;
             for (int i = r0 + ig * 8; i < std::min(r1, r0 + ig * 8 + 8); ++i)
                 for (int j = c0 + jg * 8; j < std::min(c1, c0 + jg * 8 + 8); ++j) {
                     int k0, k1;
@@ -148,7 +152,6 @@ static void rect_patch_order(std::vector<TileDesc>& out, int r0, int r1, int c0,
                     out.push_back({i, j, k0, k1});
                 }
         }
-    }
 }
 
 struct TriNode { int lo, mid, hi; };
@@ -171,7 +174,7 @@ int plan_ensure(gpimhip_ctx* h, int nb) {
     P.trsm.assign(nb, {0, 0});
     P.inner.assign(nb, {0, 0});
     P.trail.assign(nb, {0, 0});
-    P.trail_kb0.assign(nb, 0);
+    P.trail_next.assign(nb, {0, 0});
     for (int k = 0; k < nb; ++k) {
         const int p0 = (k / OUTER_W) * OUTER_W, p1 = std::min(p0 + OUTER_W, nb);
         size_t s = tl.size();
@@ -182,10 +185,16 @@ int plan_ensure(gpimhip_ctx* h, int nb) {
             for (int j = k + 1; j < std::min(p1, i + 1); ++j) tl.push_back({i, j, k, k + 1});
         P.inner[k] = mark(s);
         if (k == p1 - 1 && p1 < nb) {
+            // trailing update split for look-ahead: the columns of the NEXT outer panel first ...
+            const int q1 = std::min(p1 + OUTER_W, nb);
             s = tl.size();
-            lower_patch_order(tl, p1, nb, p0, p1);
+            for (int i = p1; i < nb; ++i)
+                for (int j = p1; j < std::min(q1, i + 1); ++j) tl.push_back({i, j, p0, p1});
+            P.trail_next[k] = mark(s);
+            // ... then everything to the right of it (the bulk), 8x8-patch ordered
+            s = tl.size();
+            if (q1 < nb) lower_patch_order(tl, q1, nb, p0, p1);
             P.trail[k] = mark(s);
-            P.trail_kb0[k] = p0;
         }
     }
     // triangular inversion, bottom-up by subtree height
@@ -197,7 +206,7 @@ int plan_ensure(gpimhip_ctx* h, int nb) {
         size_t s = tl.size();
         // T = L21 * X11: k-range [cj, mid) -- longest for the leftmost columns
         for (auto& nd : lv)
-            rect_patch_order(tl, nd.mid, nd.hi, nd.lo, nd.mid, false, false,
+            rect_patch_order(tl, nd.mid, nd.hi, nd.lo, nd.mid, false, true,
                              [&](int, int cj, int& k0, int& k1) { k0 = cj; k1 = nd.mid; });
         P.tri_t.push_back(mark(s));
         s = tl.size();
@@ -242,11 +251,17 @@ static GemmArgs gemm_args(const double* A, int64_t lda, const double* B, int64_t
 // diagonal block, panel solve as GEMM with the inverse, update of the remaining columns of the
 // current 512-wide outer panel; after the last column of an outer panel one SYRK-shaped trailing
 // update with k-depth 512 (keeps the update MFMA-bound instead of HBM-bound on the C tiles).
-int launch_potrf(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_t* info) {
-    const int nb = (int)(np / NB);
-    GP_TRY(plan_ensure(h, nb));
+//
+// Look-ahead: the panel chain (potf2 -> solve -> in-panel update, 3 small launches per column) is
+// latency-bound and would leave the chip idle, so it runs on a second, high-priority stream
+// concurrently with the bulk of the previous panel's trailing update:
+//   main  : trail_next(p) . E_p . trail_rest(p) ............ wait F_{p+1} . trail_next(p+1) ...
+//   panel :                 wait E_p . panel(p+1) . F_{p+1}
+// trail_next(p) touches exactly the columns panel(p+1) factors; trail_rest(p) touches the columns
+// to the right of them, so the two streams never write the same tile.
+static int panel_steps(gpimhip_ctx* h, double* A, int64_t ld, int32_t* info, int p0, int p1) {
     const LinalgPlan& P = h->plan;
-    for (int k = 0; k < nb; ++k) {
+    for (int k = p0; k < p1; ++k) {
         GP_TRY(launch_potf2(h, A, ld, k, info));
         if (P.trsm[k].n) {
             GemmArgs g = gemm_args(A, ld, h->dinv, NB, A, ld, 1.0, 0.0, P.d_tiles + P.trsm[k].off, P.trsm[k].n);
@@ -257,10 +272,52 @@ int launch_potrf(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_t* inf
             GemmArgs g = gemm_args(A, ld, A, ld, A, ld, -1.0, 1.0, P.d_tiles + P.inner[k].off, P.inner[k].n);
             GP_TRY(launch_gemm(h, false, false, EPI_STORE, g));
         }
-        if (P.trail[k].n) {
-            GemmArgs g = gemm_args(A, ld, A, ld, A, ld, -1.0, 1.0, P.d_tiles + P.trail[k].off, P.trail[k].n);
+    }
+    return GPIMHIP_OK;
+}
+
+int launch_potrf(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_t* info) {
+    const int nb = (int)(np / NB);
+    GP_TRY(plan_ensure(h, nb));
+    const LinalgPlan& P = h->plan;
+    const int npanel = (nb + OUTER_W - 1) / OUTER_W;
+    hipStream_t main_s = h->stream;
+    const bool ahead = (h->panel_stream != nullptr) && npanel > 1;
+    if ((int)h->ev_pool.size() < 2 * npanel + 1) {
+        while ((int)h->ev_pool.size() < 2 * npanel + 1) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            h->ev_pool.push_back(e);
+        }
+    }
+    auto evE = [&](int p) { return h->ev_pool[2 * p]; };
+    auto evF = [&](int p) { return h->ev_pool[2 * p + 1]; };
+    int rc = GPIMHIP_OK;
+    // panel 0 has nothing to overlap with
+    GP_TRY(panel_steps(h, A, ld, info, 0, std::min(OUTER_W, nb)));
+    for (int p = 0; p + 1 < npanel; ++p) {
+        const int klast = std::min((p + 1) * OUTER_W, nb) - 1;      // last column of panel p
+        const int q0 = (p + 1) * OUTER_W, q1 = std::min(q0 + OUTER_W, nb);
+        if (P.trail_next[klast].n) {
+            GemmArgs g = gemm_args(A, ld, A, ld, A, ld, -1.0, 1.0, P.d_tiles + P.trail_next[klast].off,
+                                   P.trail_next[klast].n);
             GP_TRY(launch_gemm(h, false, false, EPI_STORE, g));
         }
+        if (ahead) {
+            HIP_TRY(hipEventRecord(evE(p), main_s));
+            HIP_TRY(hipStreamWaitEvent(h->panel_stream, evE(p), 0));
+            h->stream = h->panel_stream;
+            rc = panel_steps(h, A, ld, info, q0, q1);
+            h->stream = main_s;
+            GP_TRY(rc);
+            HIP_TRY(hipEventRecord(evF(p), h->panel_stream));
+        }
+        if (P.trail[klast].n) {
+            GemmArgs g = gemm_args(A, ld, A, ld, A, ld, -1.0, 1.0, P.d_tiles + P.trail[klast].off, P.trail[klast].n);
+            GP_TRY(launch_gemm(h, false, false, EPI_STORE, g));
+        }
+        if (ahead) HIP_TRY(hipStreamWaitEvent(main_s, evF(p), 0));
+        else GP_TRY(panel_steps(h, A, ld, info, q0, q1));
     }
     return GPIMHIP_OK;
 }
@@ -366,6 +423,12 @@ int gpimhip_create(gpimhip_handle* out, int device, void* hip_stream) {
     gpimhip_ctx* h = new gpimhip_ctx();
     h->device = device;
     h->stream = (hipStream_t)hip_stream;     // NULL = the device's default (null) stream
+    {
+        int lo = 0, hi = 0;
+        hipDeviceGetStreamPriorityRange(&lo, &hi);   // hi = numerically lowest = highest priority
+        if (hipStreamCreateWithPriority(&h->panel_stream, hipStreamNonBlocking, hi) != hipSuccess)
+            h->panel_stream = nullptr;               // fall back to the in-order schedule
+    }
     int rc = GPIMHIP_OK;
     if ((rc = dev_alloc(h, &h->theta, 1)) || (rc = dev_alloc(h, &h->adam_m, MAXP)) ||
         (rc = dev_alloc(h, &h->adam_v, MAXP)) || (rc = dev_alloc(h, &h->scratch, 4 * MAXP)) ||
@@ -394,6 +457,8 @@ int gpimhip_destroy(gpimhip_handle h) {
     dev_free(h, &h->scratch, 4 * MAXP);
     dev_free(h, &h->info, 4);
     if (h->plan.d_tiles) hipFree(h->plan.d_tiles);
+    for (auto e : h->ev_pool) hipEventDestroy(e);
+    if (h->panel_stream) hipStreamDestroy(h->panel_stream);
     delete h;
     return GPIMHIP_OK;
 }

@@ -66,7 +66,7 @@ struct LinalgPlan {
     std::vector<PlanRange> trsm;          // per inner step k
     std::vector<PlanRange> inner;         // per inner step k (may be empty)
     std::vector<PlanRange> trail;         // per inner step k: non-empty only at the last column of an outer panel
-    std::vector<int> trail_kb0;           // first k-block of that outer panel
+    std::vector<PlanRange> trail_next;    // ditto: the part of that update that feeds the next panel
     // trtri: per level two launches
     std::vector<PlanRange> tri_t, tri_x;
     // lauum
@@ -76,6 +76,8 @@ struct LinalgPlan {
 struct gpimhip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t panel_stream = nullptr;   // high-priority side stream for the Cholesky panel chain
+    std::vector<hipEvent_t> ev_pool;      // cross-stream ordering events (no timing)
     // workspace (sized for np = padded N)
     int64_t np = 0;                 // padded matrix order the buffers are sized for
     double* A = nullptr;            // np x np : K -> L -> L^-1

@@ -25,14 +25,14 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 #define STAGE_ELEMS 2304            // 128*18 == 16*144
 static_assert(NB * LD_MK == STAGE_ELEMS && GEMM_BK * LD_KM == STAGE_ELEMS, "stage size");
 
-template <bool KM>
-__device__ __forceinline__ void stage_load(d2 (&r)[4], const double* __restrict__ base, int64_t ld,
+template <bool KM, int NT>
+__device__ __forceinline__ void stage_load(d2 (&r)[1024 / NT], const double* __restrict__ base, int64_t ld,
                                            int64_t mrow0, int64_t kcol0, int tid) {
     // MK: tile element (m,k) lives at base[(mrow0+m)*ld + kcol0 + k]
     // KM: tile element (k,m) lives at base[(kcol0+k)*ld + mrow0 + m]
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = tid + 256 * i;
+    for (int i = 0; i < 1024 / NT; ++i) {
+        const int c = tid + NT * i;
         if (!KM) {
             const int row = c >> 3, c16 = c & 7;
             r[i] = *reinterpret_cast<const d2*>(base + (mrow0 + row) * ld + kcol0 + c16 * 2);
@@ -43,11 +43,11 @@ __device__ __forceinline__ void stage_load(d2 (&r)[4], const double* __restrict_
     }
 }
 
-template <bool KM>
-__device__ __forceinline__ void stage_store(const d2 (&r)[4], double* lds, int tid) {
+template <bool KM, int NT>
+__device__ __forceinline__ void stage_store(const d2 (&r)[1024 / NT], double* lds, int tid) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = tid + 256 * i;
+    for (int i = 0; i < 1024 / NT; ++i) {
+        const int c = tid + NT * i;
         if (!KM) {
             const int row = c >> 3, c16 = c & 7;
             *reinterpret_cast<d2*>(lds + row * LD_MK + c16 * 2) = r[i];
@@ -65,8 +65,14 @@ __device__ __forceinline__ double frag(const double* lds, int m0, int kk, int la
     return lds[(kk * 4 + (lane >> 4)) * LD_KM + m0 + (lane & 15)];
 }
 
-template <bool A_KM, bool B_KM, int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_tiles_kernel(GemmArgs g) {
+// NW = waves per workgroup: 4 (2x2 waves of 64x64, bulk launches: two workgroups share a CU) or
+// 8 (4x2 waves of 32x64, for launches with at most one tile per CU: puts 2 waves on every SIMD,
+// which a single fp64-MFMA wave cannot saturate on its own).
+template <bool A_KM, bool B_KM, int EPI, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void gemm_tiles_kernel(GemmArgs g) {
+    constexpr int NT = NW * 64;          // threads
+    constexpr int MT = 16 / NW;          // 16x16 row-tiles per wave: 4 or 2
+    constexpr int WROWS = MT * 16;       // rows per wave: 64 or 32
     __shared__ __attribute__((aligned(16))) double smem[4 * STAGE_ELEMS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -99,18 +105,18 @@ __global__ __launch_bounds__(256, 2) void gemm_tiles_kernel(GemmArgs g) {
     const int64_t b_n0 = (int64_t)(t.cj + (B_KM ? g.b_coff : g.b_roff)) * NB;
     const int64_t b_k0 = (int64_t)(t.kb0 + (B_KM ? g.b_roff : g.b_coff)) * NB;
 
-    d4 acc[4][4];
+    d4 acc[MT][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
 
-    d2 ra[4], rb[4];
+    d2 ra[1024 / NT], rb[1024 / NT];
     if (nsteps > 0) {
-        stage_load<A_KM>(ra, g.A, g.lda, a_m0, a_k0, tid);
-        stage_load<B_KM>(rb, g.B, g.ldb, b_n0, b_k0, tid);
-        stage_store<A_KM>(ra, smem, tid);
-        stage_store<B_KM>(rb, smem + STAGE_ELEMS, tid);
+        stage_load<A_KM, NT>(ra, g.A, g.lda, a_m0, a_k0, tid);
+        stage_load<B_KM, NT>(rb, g.B, g.ldb, b_n0, b_k0, tid);
+        stage_store<A_KM, NT>(ra, smem, tid);
+        stage_store<B_KM, NT>(rb, smem + STAGE_ELEMS, tid);
     }
     __syncthreads();
 
@@ -119,36 +125,36 @@ __global__ __launch_bounds__(256, 2) void gemm_tiles_kernel(GemmArgs g) {
         const double* Bs = As + STAGE_ELEMS;
         const bool more = (s + 1 < nsteps);
         if (more) {
-            stage_load<A_KM>(ra, g.A, g.lda, a_m0, a_k0 + (int64_t)(s + 1) * GEMM_BK, tid);
-            stage_load<B_KM>(rb, g.B, g.ldb, b_n0, b_k0 + (int64_t)(s + 1) * GEMM_BK, tid);
+            stage_load<A_KM, NT>(ra, g.A, g.lda, a_m0, a_k0 + (int64_t)(s + 1) * GEMM_BK, tid);
+            stage_load<B_KM, NT>(rb, g.B, g.ldb, b_n0, b_k0 + (int64_t)(s + 1) * GEMM_BK, tid);
         }
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            double a[4], bb[4];
+            double a[MT], bb[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = frag<A_KM>(As, wm * 64 + i * 16, kk, lane);
+            for (int i = 0; i < MT; ++i) a[i] = frag<A_KM>(As, wm * WROWS + i * 16, kk, lane);
 #pragma unroll
             for (int j = 0; j < 4; ++j) bb[j] = frag<B_KM>(Bs, wn * 64 + j * 16, kk, lane);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bb[j], acc[i][j], 0, 0, 0);
         }
         if (more) {
             double* An = smem + ((s + 1) & 1) * 2 * STAGE_ELEMS;
-            stage_store<A_KM>(ra, An, tid);
-            stage_store<B_KM>(rb, An + STAGE_ELEMS, tid);
+            stage_store<A_KM, NT>(ra, An, tid);
+            stage_store<B_KM, NT>(rb, An + STAGE_ELEMS, tid);
         }
         __syncthreads();
     }
 
     if (EPI == EPI_STORE) {
-        const int64_t crow0 = (int64_t)(t.ci + g.c_roff) * NB + wm * 64 + (lane >> 4);
+        const int64_t crow0 = (int64_t)(t.ci + g.c_roff) * NB + wm * WROWS + (lane >> 4);
         const int64_t ccol0 = (int64_t)(t.cj + g.c_coff) * NB + wn * 64 + (lane & 15);
         const double alpha = g.alpha, beta = g.beta;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -160,12 +166,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tiles_kernel(GemmArgs g) {
                 }
     } else {
         // column sums of squares of the 128x128 product tile -> colpart[ci][cj*128 + col]
-        double* red = smem;      // [2][128]; all waves are past the last barrier of the k-loop
+        double* red = smem;      // [NW/2][128]; all waves are past the last barrier of the k-loop
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             double s = 0.0;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int rg = 0; rg < 4; ++rg) s += acc[i][j][rg] * acc[i][j][rg];
             s += __shfl_xor(s, 16);
@@ -173,16 +179,23 @@ __global__ __launch_bounds__(256, 2) void gemm_tiles_kernel(GemmArgs g) {
             if (lane < 16) red[wm * 128 + wn * 64 + j * 16 + lane] = s;
         }
         __syncthreads();
-        if (tid < 128)
-            g.colpart[(int64_t)t.ci * g.ld_colpart + (int64_t)(t.cj + g.c_coff) * NB + tid] =
-                red[tid] + red[128 + tid];
+        if (tid < 128) {
+            double tot = 0.0;
+#pragma unroll
+            for (int w = 0; w < NW / 2; ++w) tot += red[w * 128 + tid];
+            g.colpart[(int64_t)t.ci * g.ld_colpart + (int64_t)(t.cj + g.c_coff) * NB + tid] = tot;
+        }
     }
 }
 
 template <bool A_KM, bool B_KM, int EPI>
 static int launch_one(gpimhip_ctx* h, const GemmArgs& g) {
     if (g.ntiles <= 0) return GPIMHIP_OK;
-    hipLaunchKernelGGL((gemm_tiles_kernel<A_KM, B_KM, EPI>), dim3(g.ntiles), dim3(256), 0, h->stream, g);
+    // at most one tile per CU: use the 8-wave workgroup so every SIMD still holds two MFMA waves
+    if (g.ntiles <= 256)
+        hipLaunchKernelGGL((gemm_tiles_kernel<A_KM, B_KM, EPI, 8>), dim3(g.ntiles), dim3(512), 0, h->stream, g);
+    else
+        hipLaunchKernelGGL((gemm_tiles_kernel<A_KM, B_KM, EPI, 4>), dim3(g.ntiles), dim3(256), 0, h->stream, g);
     HIP_TRY(hipGetLastError());
     return GPIMHIP_OK;
 }

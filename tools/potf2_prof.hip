@@ -1,0 +1,43 @@
+// potf2_prof.hip -- phase-by-phase cycle counts of potf2_inv_kernel (development aid).
+#define POTF2_PROFILE
+#include "../gpim_amd/csrc/potf2.hip"
+#include <stdio.h>
+#include <vector>
+void gpim_set_error(const std::string&) {}
+int main() {
+    const int n = 128;
+    std::vector<double> A(n * n);
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) A[i * n + j] = (i == j ? 2.0 : 0.0) + 1.0 / (1 + abs(i - j));
+    double *dA, *dinv, *ld; int* info; long long* prof;
+    hipMalloc(&dA, n * n * 8); hipMalloc(&dinv, n * n * 8); hipMalloc(&ld, 8); hipMalloc(&info, 4); hipMalloc(&prof, 32 * 8);
+    hipMemset(info, 0, 4);
+    long long hp[32];
+    for (int rep = 0; rep < 3; ++rep) {
+        hipMemcpy(dA, A.data(), n * n * 8, hipMemcpyHostToDevice);
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(potf2_inv_kernel, dim3(1), dim3(256), 0, 0, dA, (int64_t)n, 0, dinv, ld, info, prof);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        hipMemcpy(hp, prof, 32 * 8, hipMemcpyDeviceToHost);
+        printf("rep %d: %.1f us total; cycles: load %lld", rep, ms * 1e3, hp[1] - hp[0]);
+        long long chol = 0, solve = 0, trail = 0;
+        for (int p = 0; p < 8; ++p) {
+            chol += hp[3 + 3 * p] - hp[2 + 3 * p];
+            solve += hp[4 + 3 * p] - hp[3 + 3 * p];
+            trail += (p < 7 ? hp[5 + 3 * p] : hp[26]) - hp[4 + 3 * p];
+        }
+        printf(" | chol16 %lld solve %lld trail %lld | writeL+logdet %lld | inverse %lld | write dinv %lld | all %lld\n",
+               chol, solve, trail, hp[27] - hp[26], hp[28] - hp[27], hp[29] - hp[28], hp[29] - hp[0]);
+        printf("   chol16 per panel:"); for (int p = 0; p < 8; ++p) printf(" %lld", hp[3 + 3 * p] - hp[2 + 3 * p]);
+        printf("\n   trail per panel:"); for (int p = 0; p < 8; ++p) printf(" %lld", (p < 7 ? hp[5 + 3 * p] : hp[26]) - hp[4 + 3 * p]);
+        printf("\n");
+    }
+    std::vector<double> L(n * n);
+    hipMemcpy(L.data(), dA, n * n * 8, hipMemcpyDeviceToHost);
+    // residual check L L^T - A
+    double err = 0;
+    for (int i = 0; i < n; ++i) for (int j = 0; j <= i; ++j) { double s = 0; for (int k = 0; k <= j; ++k) s += L[i * n + k] * L[j * n + k]; err = fmax(err, fabs(s - A[i * n + j])); }
+    printf("max |LL^T - A| = %.3e\n", err);
+    return 0;
+}
