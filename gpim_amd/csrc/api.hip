@@ -2,6 +2,7 @@
 // extern "C" entry points declared in include/gpimhip.h.
 #include <math.h>
 #include <string.h>
+#include <stdlib.h>
 #include <algorithm>
 #include "common.hpp"
 
@@ -33,6 +34,7 @@ int launch_topk(gpimhip_ctx* h, const double* x, int64_t M, int k, int keep_nan,
 static thread_local std::string g_err;
 void gpim_set_error(const std::string& s) { g_err = s; }
 
+#define RESERVED_CUS 16
 #define OUTER_W 4    // outer Cholesky panel = 4 x 128 columns: trailing updates run with k-depth 512
 
 // ------------------------------------------------------------------------------------------
@@ -66,6 +68,7 @@ static void ws_release_matrix(gpimhip_ctx* h) {
     dev_free(h, &h->B, np * np);
     dev_free(h, &h->Tm, np * np);
     dev_free(h, &h->dinv, nb * NB * NB);
+    dev_free(h, &h->linv16, nb * 8 * 256);
     dev_free(h, &h->ypad, np);
     dev_free(h, &h->z, np);
     dev_free(h, &h->alpha, np);
@@ -84,6 +87,7 @@ int ws_ensure(gpimhip_ctx* h, int64_t N) {
     GP_TRY(dev_alloc(h, &h->B, np * np));
     GP_TRY(dev_alloc(h, &h->Tm, np * np));
     GP_TRY(dev_alloc(h, &h->dinv, nb * NB * NB));
+    GP_TRY(dev_alloc(h, &h->linv16, nb * 8 * 256));
     GP_TRY(dev_alloc(h, &h->ypad, np));
     GP_TRY(dev_alloc(h, &h->z, np));
     GP_TRY(dev_alloc(h, &h->alpha, np));
@@ -282,7 +286,9 @@ int launch_potrf(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_t* inf
     const LinalgPlan& P = h->plan;
     const int npanel = (nb + OUTER_W - 1) / OUTER_W;
     hipStream_t main_s = h->stream;
-    const bool ahead = (h->panel_stream != nullptr) && npanel > 1;
+    // below ~12k unknowns the trailing updates are too short to hide a panel chain behind them and
+    // the extra cross-stream traffic costs more than it saves
+    const bool ahead = (h->panel_stream != nullptr) && npanel >= 24;
     if ((int)h->ev_pool.size() < 2 * npanel + 1) {
         while ((int)h->ev_pool.size() < 2 * npanel + 1) {
             hipEvent_t e;
@@ -314,7 +320,17 @@ int launch_potrf(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_t* inf
         }
         if (P.trail[klast].n) {
             GemmArgs g = gemm_args(A, ld, A, ld, A, ld, -1.0, 1.0, P.d_tiles + P.trail[klast].off, P.trail[klast].n);
-            GP_TRY(launch_gemm(h, false, false, EPI_STORE, g));
+            if (ahead && h->bulk_stream) {
+                HIP_TRY(hipStreamWaitEvent(h->bulk_stream, evE(p), 0));
+                h->stream = h->bulk_stream;
+                rc = launch_gemm(h, false, false, EPI_STORE, g);
+                h->stream = main_s;
+                GP_TRY(rc);
+                HIP_TRY(hipEventRecord(h->ev_pool[2 * npanel], h->bulk_stream));
+                HIP_TRY(hipStreamWaitEvent(main_s, h->ev_pool[2 * npanel], 0));
+            } else {
+                GP_TRY(launch_gemm(h, false, false, EPI_STORE, g));
+            }
         }
         if (ahead) HIP_TRY(hipStreamWaitEvent(main_s, evF(p), 0));
         else GP_TRY(panel_steps(h, A, ld, info, q0, q1));
@@ -428,6 +444,17 @@ int gpimhip_create(gpimhip_handle* out, int device, void* hip_stream) {
         hipDeviceGetStreamPriorityRange(&lo, &hi);   // hi = numerically lowest = highest priority
         if (hipStreamCreateWithPriority(&h->panel_stream, hipStreamNonBlocking, hi) != hipSuccess)
             h->panel_stream = nullptr;               // fall back to the in-order schedule
+        // The bulk trailing updates run on a stream whose CU mask leaves RESERVED_CUS compute units
+        // free: potf2 needs ~150 KB of LDS, i.e. a whole CU, and would otherwise wait until the bulk
+        // kernel (2 x 74 KB per CU, thousands of workgroups queued) has drained.
+        hipDeviceProp_t prop;
+        if (h->panel_stream && hipGetDeviceProperties(&prop, device) == hipSuccess && !getenv("GPIMHIP_NO_CUMASK")) {
+            const int ncu = prop.multiProcessorCount;
+            std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+            for (int c = RESERVED_CUS; c < ncu; ++c) mask[c / 32] |= (1u << (c % 32));
+            if (hipExtStreamCreateWithCUMask(&h->bulk_stream, (uint32_t)mask.size(), mask.data()) != hipSuccess)
+                h->bulk_stream = nullptr;
+        }
     }
     int rc = GPIMHIP_OK;
     if ((rc = dev_alloc(h, &h->theta, 1)) || (rc = dev_alloc(h, &h->adam_m, MAXP)) ||
@@ -459,6 +486,7 @@ int gpimhip_destroy(gpimhip_handle h) {
     if (h->plan.d_tiles) hipFree(h->plan.d_tiles);
     for (auto e : h->ev_pool) hipEventDestroy(e);
     if (h->panel_stream) hipStreamDestroy(h->panel_stream);
+    if (h->bulk_stream) hipStreamDestroy(h->bulk_stream);
     delete h;
     return GPIMHIP_OK;
 }

@@ -77,6 +77,7 @@ struct gpimhip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t panel_stream = nullptr;   // high-priority side stream for the Cholesky panel chain
+    hipStream_t bulk_stream = nullptr;    // CU-masked stream for the bulk trailing updates (look-ahead)
     std::vector<hipEvent_t> ev_pool;      // cross-stream ordering events (no timing)
     // workspace (sized for np = padded N)
     int64_t np = 0;                 // padded matrix order the buffers are sized for
@@ -84,6 +85,7 @@ struct gpimhip_ctx {
     double* B = nullptr;            // np x np : K^-1 (lower)
     double* Tm = nullptr;           // np x np : trtri temporary
     double* dinv = nullptr;         // nb x 128 x 128 inverses of diagonal blocks
+    double* linv16 = nullptr;       // nb x 8 x 16 x 16 inverses of the 16x16 diagonal sub-blocks
     double* ypad = nullptr;         // np
     double* z = nullptr;            // np  (L^-1 y)
     double* alpha = nullptr;        // np  (K^-1 y)

@@ -1,20 +1,23 @@
-// potf2.hip -- one workgroup factors a 128x128 diagonal block entirely in LDS and also
-// produces its explicit inverse.
+// potf2.hip -- the diagonal-block kernels of the blocked Cholesky (replaces
+// the diagonal steps of torch.linalg.cholesky, call sites gpim/gpreg/gpr.py:192,248).
 //
-// Role in the hot path: the diagonal step of the blocked right-looking
-// Cholesky that replaces torch.linalg.cholesky (call sites gpim/gpreg/gpr.py:192,248).  The
-// inverse turns the panel triangular solves and the leaves of the triangular inversion into
-// MFMA GEMMs.
+//   potf2_kernel   one workgroup (8 waves) factors a 128x128 diagonal block that is resident in
+//                  LDS and also emits the inverses of its eight 16x16 diagonal sub-blocks.
+//   inv128_kernel  one workgroup per block: explicit inverse of a factored 128x128 block by
+//                  recursive doubling (16 -> 32 -> 64 -> 128) on MFMA.  The inverse turns the panel
+//                  triangular solve and the leaves of the triangular inversion into GEMMs.
 //
-// Inside the workgroup the block is processed in 16-column panels:
-//   wave 0 / 16 lanes: 16x16 Cholesky + inverse held in registers (row per lane, cross-lane
-//                      broadcasts by v_readlane -- no LDS round trips on the serial chain)
-//   all waves:         panel solve  P <- P * inv(L16)^T         (v_mfma_f64_16x16x4_f64)
-//   all waves:         trailing     D <- D - P P^T  (lower)     (v_mfma_f64_16x16x4_f64)
-// then inv(L) by recursive doubling (16 -> 32 -> 64 -> 128), products on MFMA, done in place.
+// potf2 works in 16-column panels:
+//   wave 0, 16 lanes : 16x16 Cholesky in registers (row per lane; cross-lane broadcasts by
+//                      v_readlane, pivots by v_rsq_f64 + Newton) -- the only serial chain
+//   threads, 1/row   : panel solve by forward substitution against the 16x16 factor (LDS broadcast)
+//   8 waves          : trailing update D -= P P^T on the lower 16x16 tiles, v_mfma_f64_16x16x4_f64
+// A lone wave can issue an fp64 MFMA only every ~140 cycles, so the MFMA phases need >= 2 waves per
+// SIMD: hence 512-thread workgroups.
 #include "common.hpp"
 
 typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
 
 #ifdef POTF2_PROFILE
 #define PROF_ARG , long long* __restrict__ prof
@@ -25,6 +28,7 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 #endif
 
 #define LDD 130   // row stride of the LDS block: 130 % 32 == 2 keeps MK fragment reads conflict free
+#define NTH 512
 
 __device__ __forceinline__ double bcast_lane(double v, int srclane) {
     int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane);
@@ -32,35 +36,53 @@ __device__ __forceinline__ double bcast_lane(double v, int srclane) {
     return __hiloint2double(hi, lo);
 }
 
-// 16x16 lower Cholesky + inverse by lanes 0..15 of one wave.  D points at the (c0,c0) corner.
-// On exit D holds L16 (lower), I16 (stride 17) holds inv(L16) with explicit zeros above the diagonal.
-// Returns 0, or 1 + local column of the first non-positive pivot.
-__device__ __forceinline__ int chol16_inv(double* D, double* I16, int lane) {
+// 16x16 lower Cholesky by lanes 0..15 of one wave; D points at the (c0,c0) corner (stride LDD).
+// Writes L16 (lower) back and 1/L_jj to invd[0..15].  Returns 0 or 1 + first bad local column.
+__device__ __forceinline__ int chol16(double* D, double* invd_out, int lane) {
     const int r = lane & 15;
     double a[16];
 #pragma unroll
     for (int c = 0; c < 16; ++c) a[c] = D[r * LDD + c];
-    double invd[16];
     int bad = 0;
+    double myinv = 0.0;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         const double djj = bcast_lane(a[j], j);
         if (!(djj > 0.0) && bad == 0) bad = j + 1;
-        // 1/sqrt(d) by v_rsq_f64 + one Newton step each for l = sqrt(d) and 1/l: a third of the
-        // dependent-instruction chain of sqrt() followed by a division, same accuracy class
-        double inv = rsqrt(djj);
+        // 1/sqrt(d): v_rsq_f64 seed + Newton on both l = sqrt(d) and 1/l (a third of the dependent
+        // instruction chain of sqrt() followed by a divide)
+        double inv = __builtin_amdgcn_rsq(djj);
         double ljj = djj * inv;
         ljj = fma(0.5 * inv, fma(-ljj, ljj, djj), ljj);
         inv = fma(inv, fma(-ljj, inv, 1.0), inv);
-        invd[j] = inv;
+        ljj = fma(0.5 * inv, fma(-ljj, ljj, djj), ljj);
+        inv = fma(inv, fma(-ljj, inv, 1.0), inv);
+        if (r == j) myinv = inv;
         a[j] = (r == j) ? ljj : a[j] * inv;
 #pragma unroll
         for (int c = j + 1; c < 16; ++c) {
             const double lcj = bcast_lane(a[j], c);
-            a[c] -= a[j] * lcj;
+            a[c] = fma(-a[j], lcj, a[c]);
         }
     }
-    // inverse: lane c builds column c of X = inv(L): X[r][c] = (delta_rc - sum_{k<r} L[r][k] X[k][c]) / L[r][r]
+    if (lane < 16) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+            if (c <= r) D[r * LDD + c] = a[c];
+        invd_out[r] = myinv;
+    }
+    return bad;
+}
+
+// inverse of a 16x16 lower-triangular block held row-per-lane: lane c builds column c of X = L^-1
+//   X[r][c] = (delta_rc - sum_{k<r} L[r][k] X[k][c]) / L[r][r]
+__device__ __forceinline__ void trinv16(const double* L, int ldl, const double* invd, double* out, int ldo,
+                                        int lane) {
+    const int r = lane & 15;
+    double a[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) a[c] = (c <= r) ? L[r * ldl + c] : 0.0;
+    const double myinv = invd[r];
     double xc[16];
 #pragma unroll
     for (int rr = 0; rr < 16; ++rr) {
@@ -68,30 +90,14 @@ __device__ __forceinline__ int chol16_inv(double* D, double* I16, int lane) {
 #pragma unroll
         for (int k = 0; k < rr; ++k) {
             const double lrk = bcast_lane(a[k], rr);
-            s -= lrk * xc[k];
+            s = fma(-lrk, xc[k], s);
         }
-        xc[rr] = s * invd[rr];
+        xc[rr] = s * bcast_lane(myinv, rr);
     }
     if (lane < 16) {
 #pragma unroll
-        for (int c = 0; c < 16; ++c) D[r * LDD + c] = (c <= r) ? a[c] : 0.0;
-#pragma unroll
-        for (int rr = 0; rr < 16; ++rr) I16[rr * 17 + r] = (rr >= r) ? xc[rr] : 0.0;
+        for (int rr = 0; rr < 16; ++rr) out[rr * ldo + r] = (rr >= r) ? xc[rr] : 0.0;
     }
-    return bad;
-}
-
-// C(16x16 at D[r0.., c0..]) (op)= sum over kdepth of A(rows ar0.., k from ak0) * B
-// A is read "MK" from D; B either "MK" (NT: B[n][k] at D[(bn0+n)*ldb + bk0+k]) or "KM".
-__device__ __forceinline__ d4 tile_mma(d4 acc, const double* Ab, int lda, const double* Bb, int ldb,
-                                       bool b_km, int kdepth, int lane, double asign) {
-    for (int s = 0; s < kdepth; s += 4) {
-        const double a = asign * Ab[(lane & 15) * lda + s + (lane >> 4)];
-        const double b = b_km ? Bb[(s + (lane >> 4)) * ldb + (lane & 15)]
-                              : Bb[(lane & 15) * ldb + s + (lane >> 4)];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-    }
-    return acc;
 }
 
 __device__ __forceinline__ d4 tile_read(const double* C, int lane) {
@@ -105,25 +111,37 @@ __device__ __forceinline__ void tile_write(double* C, d4 v, int lane) {
     for (int rg = 0; rg < 4; ++rg) C[((lane >> 4) + 4 * rg) * LDD + (lane & 15)] = v[rg];
 }
 
-// A: matrix (row-major, ld); kblk: which diagonal block.  dinv_out: 128x128 (ld 128) inverse.
-// logdet_out[kblk] = sum_i log L_ii over the block.  info: first failing column + 1 (set once).
-__global__ __launch_bounds__(256, 1) void potf2_inv_kernel(double* __restrict__ A, int64_t ld, int kblk,
-                                                           double* __restrict__ dinv_all,
-                                                           double* __restrict__ logdet_out,
-                                                           int32_t* __restrict__ info PROF_ARG) {
+__device__ __forceinline__ void load_block(double* D, const double* __restrict__ Ablk, int64_t ld, int tid) {
+    // 128x128 doubles = 8192 16-byte chunks, 16 per thread, all loads in flight before the first store
+    d2 r[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int e = tid + NTH * i, row = e >> 6, c2 = (e & 63) * 2;
+        r[i] = *reinterpret_cast<const d2*>(Ablk + (int64_t)row * ld + c2);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int e = tid + NTH * i, row = e >> 6, c2 = (e & 63) * 2;
+        *reinterpret_cast<d2*>(D + row * LDD + c2) = r[i];
+    }
+}
+
+// A: matrix (row-major, ld); kblk: which diagonal block.
+// linv16_all[kblk][8][16][16]: inverses of the 16x16 diagonal sub-blocks (zeros above the diagonal).
+// logdet_out[kblk] = sum_i log L_ii.  info: 1 + first failing global column (set once).
+__global__ __launch_bounds__(NTH, 1) void potf2_kernel(double* __restrict__ A, int64_t ld, int kblk,
+                                                       double* __restrict__ linv16_all,
+                                                       double* __restrict__ logdet_out,
+                                                       int32_t* __restrict__ info PROF_ARG) {
     __shared__ __attribute__((aligned(16))) double D[NB * LDD];
-    __shared__ __attribute__((aligned(16))) double I16[8 * 16 * 17];
+    __shared__ double invd[NB];
+    __shared__ double red[128];
     __shared__ int s_bad;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double* Ablk = A + ((int64_t)kblk * NB) * ld + (int64_t)kblk * NB;
     if (tid == 0) s_bad = 0;
     STAMP(0);
-    for (int e = tid; e < NB * (NB / 2); e += 256) {
-        const int r = e >> 6, c2 = (e & 63) * 2;
-        const double2 v = *reinterpret_cast<const double2*>(Ablk + (int64_t)r * ld + c2);
-        D[r * LDD + c2] = v.x;
-        D[r * LDD + c2 + 1] = v.y;
-    }
+    load_block(D, Ablk, ld, tid);
     __syncthreads();
     STAMP(1);
 
@@ -131,78 +149,72 @@ __global__ __launch_bounds__(256, 1) void potf2_inv_kernel(double* __restrict__ 
         const int c0 = p * 16;
         STAMP(2 + 3 * p);
         if (wave == 0) {
-            int bad = chol16_inv(D + c0 * LDD + c0, I16 + p * 16 * 17, lane);
+            const int bad = chol16(D + c0 * LDD + c0, invd + c0, lane);
             if (lane == 0 && bad && s_bad == 0) s_bad = c0 + bad;
         }
         __syncthreads();
         STAMP(3 + 3 * p);
-        // panel solve: rows below the diagonal tile
-        for (int rt = p + 1 + wave; rt < 8; rt += 4) {
-            d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
-            acc = tile_mma(acc, D + rt * 16 * LDD + c0, LDD, I16 + p * 16 * 17, 17, false, 16, lane, 1.0);
-            tile_write(D + rt * 16 * LDD + c0, acc, lane);
+        // panel solve, one thread per row below the diagonal tile: x L16^T = a
+        {
+            const int row = c0 + 16 + tid;
+            if (row < NB) {
+                double x[16];
+                double* px = D + row * LDD + c0;
+#pragma unroll
+                for (int c = 0; c < 16; c += 2) {
+                    const d2 v = *reinterpret_cast<const d2*>(px + c);
+                    x[c] = v[0];
+                    x[c + 1] = v[1];
+                }
+                const double* Lp = D + c0 * LDD + c0;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    double s = x[c];
+#pragma unroll
+                    for (int k = 0; k < c; ++k) s = fma(-x[k], Lp[c * LDD + k], s);
+                    x[c] = s * invd[c0 + c];
+                }
+#pragma unroll
+                for (int c = 0; c < 16; c += 2) *reinterpret_cast<d2*>(px + c) = (d2){x[c], x[c + 1]};
+            }
         }
         __syncthreads();
         STAMP(4 + 3 * p);
-        // trailing update of the lower tiles (rt >= ct > p); each wave keeps up to four independent
-        // accumulators in flight (one dependent fp64 MFMA chain alone leaves the pipe mostly idle)
-        const int m = 7 - p;                 // tiles per side
+        // trailing update of the lower tiles (rt >= ct > p)
+        const int m = 7 - p;
         const int ntile = m * (m + 1) / 2;
-        for (int base = 0; base < ntile; base += 16) {
-            d4 acc[4];
-            int rt[4], ct[4];
-            bool on[4];
+        for (int q = wave; q < ntile; q += NTH / 64) {
+            int i = (int)((sqrtf(8.0f * q + 1.0f) - 1.0f) * 0.5f);
+            while (i * (i + 1) / 2 > q) --i;
+            while ((i + 1) * (i + 2) / 2 <= q) ++i;
+            const int j = q - i * (i + 1) / 2;
+            const int rt = p + 1 + i, ct = p + 1 + j;
+            double* C = D + rt * 16 * LDD + ct * 16;
+            d4 acc = tile_read(C, lane);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int q = base + wave + 4 * u;
-                on[u] = q < ntile;
-                int i = 0, j = 0;
-                if (on[u]) {
-                    i = (int)((sqrtf(8.0f * q + 1.0f) - 1.0f) * 0.5f);
-                    while (i * (i + 1) / 2 > q) --i;
-                    while ((i + 1) * (i + 2) / 2 <= q) ++i;
-                    j = q - i * (i + 1) / 2;
-                }
-                rt[u] = p + 1 + i;
-                ct[u] = p + 1 + j;
-                acc[u] = on[u] ? tile_read(D + rt[u] * 16 * LDD + ct[u] * 16, lane) : (d4){0.0, 0.0, 0.0, 0.0};
+            for (int s = 0; s < 16; s += 4) {
+                const double a = -D[(rt * 16 + (lane & 15)) * LDD + c0 + s + (lane >> 4)];
+                const double b = D[(ct * 16 + (lane & 15)) * LDD + c0 + s + (lane >> 4)];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
             }
-#pragma unroll
-            for (int sft = 0; sft < 16; sft += 4) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (!on[u]) continue;
-                    const double a = -D[(rt[u] * 16 + (lane & 15)) * LDD + c0 + sft + (lane >> 4)];
-                    const double b = D[(ct[u] * 16 + (lane & 15)) * LDD + c0 + sft + (lane >> 4)];
-                    acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[u], 0, 0, 0);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (on[u]) tile_write(D + rt[u] * 16 * LDD + ct[u] * 16, acc[u], lane);
+            tile_write(C, acc, lane);
         }
         __syncthreads();
     }
-
     STAMP(26);
-    // write L (zeros above the diagonal) back, and the log-determinant partial
-    for (int e = tid; e < NB * NB; e += 256) {
-        const int r = e >> 7, c = e & 127;
-        Ablk[(int64_t)r * ld + c] = (c <= r) ? D[r * LDD + c] : 0.0;
+    // L back to HBM (zeros above the diagonal)
+    for (int e = tid; e < NB * NB / 2; e += NTH) {
+        const int r = e >> 6, c = (e & 63) * 2;
+        d2 v;
+        v[0] = (c <= r) ? D[r * LDD + c] : 0.0;
+        v[1] = (c + 1 <= r) ? D[r * LDD + c + 1] : 0.0;
+        *reinterpret_cast<d2*>(Ablk + (int64_t)r * ld + c) = v;
     }
-    double lg = 0.0;
-    if (tid < 128) lg = log(D[tid * LDD + tid]);
-    __syncthreads();
-    // --- inverse by recursive doubling, in place in D ---
-    // level 0: diagonal 16x16 blocks <- inv(L16), zeros above
-    for (int e = tid; e < 8 * 256; e += 256) {
-        const int p = e >> 8, rr = (e >> 4) & 15, c = e & 15;
-        D[(p * 16 + rr) * LDD + p * 16 + c] = I16[p * 16 * 17 + rr * 17 + c];
-    }
-    __syncthreads();
-    // log-det reduction through LDS (I16 is free now)
-    double* red = I16;
-    if (tid < 128) red[tid] = lg;
+    // inverses of the eight 16x16 diagonal sub-blocks, one wave each
+    trinv16(D + wave * 16 * LDD + wave * 16, LDD, invd + wave * 16,
+            linv16_all + ((int64_t)kblk * 8 + wave) * 256, 16, lane);
+    // log-determinant partial (fixed tree)
+    if (tid < 128) red[tid] = log(D[tid * LDD + tid]);
     __syncthreads();
     for (int s = 64; s > 0; s >>= 1) {
         if (tid < s) red[tid] += red[tid + s];
@@ -212,89 +224,94 @@ __global__ __launch_bounds__(256, 1) void potf2_inv_kernel(double* __restrict__ 
         logdet_out[kblk] = red[0];
         if (s_bad != 0 && *info == 0) *info = kblk * NB + s_bad;
     }
-
     STAMP(27);
+}
+
+// dinv_all[blk] = inverse of the factored diagonal block blk = kblk0 + blockIdx.x (ld 128, zeros above
+// the diagonal), from L (in A) and the 16x16 diagonal inverses.
+__global__ __launch_bounds__(NTH, 1) void inv128_kernel(const double* __restrict__ A, int64_t ld, int kblk0,
+                                                        const double* __restrict__ linv16_all,
+                                                        double* __restrict__ dinv_all) {
+    __shared__ __attribute__((aligned(16))) double D[NB * LDD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kblk = kblk0 + blockIdx.x;
+    const double* Ablk = A + ((int64_t)kblk * NB) * ld + (int64_t)kblk * NB;
+    load_block(D, Ablk, ld, tid);
+    __syncthreads();
+    // level 0: diagonal 16x16 blocks <- their inverses
+    for (int e = tid; e < 8 * 256; e += NTH) {
+        const int p = e >> 8, rr = (e >> 4) & 15, c = e & 15;
+        D[(p * 16 + rr) * LDD + p * 16 + c] = linv16_all[((int64_t)kblk * 8 + p) * 256 + rr * 16 + c];
+    }
+    __syncthreads();
     for (int half = 16; half <= 64; half *= 2) {
         const int ht = half / 16;               // tiles per side of one sub-block
         const int tiles_per_pair = ht * ht;
-        const int ntile = (NB / (2 * half)) * tiles_per_pair;   // 4, 8, 16  (<= 4 per wave)
-        d4 keep[4];
-        // phase 1: T = L21 * X11  (X11 lower: k-tiles kt >= tj); results stay in registers until
-        // every wave has finished reading L21, then overwrite it.
-        int ti4[4], tj4[4], r04[4], c04[4];
-        bool on4[4];
+        const int ntile = (NB / (2 * half)) * tiles_per_pair;   // 4, 8, 16  (<= 2 per wave)
+        d4 keep[2];
+        int ti2[2], tj2[2], r02[2], c02[2];
+        bool on2[2];
 #pragma unroll
-        for (int cnt = 0; cnt < 4; ++cnt) {
-            const int q = wave + 4 * cnt;
-            on4[cnt] = q < ntile;
+        for (int cnt = 0; cnt < 2; ++cnt) {
+            const int q = wave + 8 * cnt;
+            on2[cnt] = q < ntile;
             const int pr = q / tiles_per_pair, w = q % tiles_per_pair;
-            ti4[cnt] = w / ht;
-            tj4[cnt] = w % ht;
-            r04[cnt] = (2 * pr + 1) * half;
-            c04[cnt] = 2 * pr * half;
+            ti2[cnt] = w / ht;
+            tj2[cnt] = w % ht;
+            r02[cnt] = (2 * pr + 1) * half;
+            c02[cnt] = 2 * pr * half;
             keep[cnt] = (d4){0.0, 0.0, 0.0, 0.0};
         }
+        // phase 1: T = L21 * X11 (X11 lower: k-tiles kt >= tj); results stay in registers until every
+        // wave has finished reading L21, then overwrite it
         for (int kt = 0; kt < ht; ++kt)
 #pragma unroll
             for (int sft = 0; sft < 16; sft += 4)
 #pragma unroll
-                for (int cnt = 0; cnt < 4; ++cnt) {
-                    if (!on4[cnt] || kt < tj4[cnt]) continue;
-                    const double a = D[(r04[cnt] + ti4[cnt] * 16 + (lane & 15)) * LDD + c04[cnt] + kt * 16 + sft + (lane >> 4)];
-                    const double b = D[(c04[cnt] + kt * 16 + sft + (lane >> 4)) * LDD + c04[cnt] + tj4[cnt] * 16 + (lane & 15)];
+                for (int cnt = 0; cnt < 2; ++cnt) {
+                    if (!on2[cnt] || kt < tj2[cnt]) continue;
+                    const double a = D[(r02[cnt] + ti2[cnt] * 16 + (lane & 15)) * LDD + c02[cnt] + kt * 16 + sft + (lane >> 4)];
+                    const double b = D[(c02[cnt] + kt * 16 + sft + (lane >> 4)) * LDD + c02[cnt] + tj2[cnt] * 16 + (lane & 15)];
                     keep[cnt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, keep[cnt], 0, 0, 0);
                 }
         __syncthreads();
 #pragma unroll
-        for (int cnt = 0; cnt < 4; ++cnt) {
-            const int q = wave + 4 * cnt;
-            if (q < ntile) {
-                const int pr = q / tiles_per_pair, w = q % tiles_per_pair;
-                const int ti = w / ht, tj = w % ht;
-                const int r0 = (2 * pr + 1) * half, c0 = 2 * pr * half;
-                tile_write(D + (r0 + ti * 16) * LDD + c0 + tj * 16, keep[cnt], lane);
-            }
-        }
+        for (int cnt = 0; cnt < 2; ++cnt)
+            if (on2[cnt]) tile_write(D + (r02[cnt] + ti2[cnt] * 16) * LDD + c02[cnt] + tj2[cnt] * 16, keep[cnt], lane);
         __syncthreads();
-        // phase 2: X21 = -X22 * T  (X22 lower: k-tiles kt <= ti)
+        // phase 2: X21 = -X22 * T (X22 lower: k-tiles kt <= ti)
 #pragma unroll
-        for (int cnt = 0; cnt < 4; ++cnt) keep[cnt] = (d4){0.0, 0.0, 0.0, 0.0};
+        for (int cnt = 0; cnt < 2; ++cnt) keep[cnt] = (d4){0.0, 0.0, 0.0, 0.0};
         for (int kt = 0; kt < ht; ++kt)
 #pragma unroll
             for (int sft = 0; sft < 16; sft += 4)
 #pragma unroll
-                for (int cnt = 0; cnt < 4; ++cnt) {
-                    if (!on4[cnt] || kt > ti4[cnt]) continue;
-                    const double a = -D[(r04[cnt] + ti4[cnt] * 16 + (lane & 15)) * LDD + r04[cnt] + kt * 16 + sft + (lane >> 4)];
-                    const double b = D[(r04[cnt] + kt * 16 + sft + (lane >> 4)) * LDD + c04[cnt] + tj4[cnt] * 16 + (lane & 15)];
+                for (int cnt = 0; cnt < 2; ++cnt) {
+                    if (!on2[cnt] || kt > ti2[cnt]) continue;
+                    const double a = -D[(r02[cnt] + ti2[cnt] * 16 + (lane & 15)) * LDD + r02[cnt] + kt * 16 + sft + (lane >> 4)];
+                    const double b = D[(r02[cnt] + kt * 16 + sft + (lane >> 4)) * LDD + c02[cnt] + tj2[cnt] * 16 + (lane & 15)];
                     keep[cnt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, keep[cnt], 0, 0, 0);
                 }
         __syncthreads();
 #pragma unroll
-        for (int cnt = 0; cnt < 4; ++cnt) {
-            const int q = wave + 4 * cnt;
-            if (q < ntile) {
-                const int pr = q / tiles_per_pair, w = q % tiles_per_pair;
-                const int ti = w / ht, tj = w % ht;
-                const int r0 = (2 * pr + 1) * half, c0 = 2 * pr * half;
-                tile_write(D + (r0 + ti * 16) * LDD + c0 + tj * 16, keep[cnt], lane);
-            }
-        }
+        for (int cnt = 0; cnt < 2; ++cnt)
+            if (on2[cnt]) tile_write(D + (r02[cnt] + ti2[cnt] * 16) * LDD + c02[cnt] + tj2[cnt] * 16, keep[cnt], lane);
         __syncthreads();
     }
-    STAMP(28);
     double* dinv = dinv_all + (int64_t)kblk * NB * NB;
-    for (int e = tid; e < NB * NB; e += 256) {
-        const int r = e >> 7, c = e & 127;
-        dinv[e] = (c <= r) ? D[r * LDD + c] : 0.0;
+    for (int e = tid; e < NB * NB / 2; e += NTH) {
+        const int r = e >> 6, c = (e & 63) * 2;
+        d2 v;
+        v[0] = (c <= r) ? D[r * LDD + c] : 0.0;
+        v[1] = (c + 1 <= r) ? D[r * LDD + c + 1] : 0.0;
+        *reinterpret_cast<d2*>(dinv + r * NB + c) = v;
     }
-    STAMP(29);
 }
 
 #ifndef POTF2_PROFILE
 int launch_potf2(gpimhip_ctx* h, double* A, int64_t ld, int kblk, int32_t* info) {
-    hipLaunchKernelGGL(potf2_inv_kernel, dim3(1), dim3(256), 0, h->stream, A, ld, kblk, h->dinv,
-                       h->logdet_part, info);
+    hipLaunchKernelGGL(potf2_kernel, dim3(1), dim3(NTH), 0, h->stream, A, ld, kblk, h->linv16, h->logdet_part, info);
+    hipLaunchKernelGGL(inv128_kernel, dim3(1), dim3(NTH), 0, h->stream, A, ld, kblk, h->linv16, h->dinv);
     HIP_TRY(hipGetLastError());
     return GPIMHIP_OK;
 }

@@ -9,14 +9,14 @@ int main() {
     std::vector<double> A(n * n);
     for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) A[i * n + j] = (i == j ? 2.0 : 0.0) + 1.0 / (1 + abs(i - j));
     double *dA, *dinv, *ld; int* info; long long* prof;
-    hipMalloc(&dA, n * n * 8); hipMalloc(&dinv, n * n * 8); hipMalloc(&ld, 8); hipMalloc(&info, 4); hipMalloc(&prof, 32 * 8);
+    hipMalloc(&dA, n * n * 8); hipMalloc(&dinv, n * n * 8); double* l16; hipMalloc(&l16, 8 * 256 * 8); hipMalloc(&ld, 8); hipMalloc(&info, 4); hipMalloc(&prof, 32 * 8);
     hipMemset(info, 0, 4);
     long long hp[32];
     for (int rep = 0; rep < 3; ++rep) {
         hipMemcpy(dA, A.data(), n * n * 8, hipMemcpyHostToDevice);
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         hipEventRecord(e0);
-        hipLaunchKernelGGL(potf2_inv_kernel, dim3(1), dim3(256), 0, 0, dA, (int64_t)n, 0, dinv, ld, info, prof);
+        hipLaunchKernelGGL(potf2_kernel, dim3(1), dim3(512), 0, 0, dA, (int64_t)n, 0, l16, ld, info, prof);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         hipMemcpy(hp, prof, 32 * 8, hipMemcpyDeviceToHost);
@@ -27,8 +27,15 @@ int main() {
             solve += hp[4 + 3 * p] - hp[3 + 3 * p];
             trail += (p < 7 ? hp[5 + 3 * p] : hp[26]) - hp[4 + 3 * p];
         }
-        printf(" | chol16 %lld solve %lld trail %lld | writeL+logdet %lld | inverse %lld | write dinv %lld | all %lld\n",
-               chol, solve, trail, hp[27] - hp[26], hp[28] - hp[27], hp[29] - hp[28], hp[29] - hp[0]);
+        printf(" | chol16 %lld solve %lld trail %lld | writeL+inv16+logdet %lld | all %lld\n",
+               chol, solve, trail, hp[27] - hp[26], hp[27] - hp[0]);
+        {
+            hipEventRecord(e0);
+            hipLaunchKernelGGL(inv128_kernel, dim3(1), dim3(512), 0, 0, dA, (int64_t)n, 0, l16, dinv);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms2; hipEventElapsedTime(&ms2, e0, e1);
+            printf("   inv128: %.1f us\n", ms2 * 1e3);
+        }
         printf("   chol16 per panel:"); for (int p = 0; p < 8; ++p) printf(" %lld", hp[3 + 3 * p] - hp[2 + 3 * p]);
         printf("\n   trail per panel:"); for (int p = 0; p < 8; ++p) printf(" %lld", (p < 7 ? hp[5 + 3 * p] : hp[26]) - hp[4 + 3 * p]);
         printf("\n");
@@ -39,5 +46,10 @@ int main() {
     double err = 0;
     for (int i = 0; i < n; ++i) for (int j = 0; j <= i; ++j) { double s = 0; for (int k = 0; k <= j; ++k) s += L[i * n + k] * L[j * n + k]; err = fmax(err, fabs(s - A[i * n + j])); }
     printf("max |LL^T - A| = %.3e\n", err);
+    std::vector<double> Xi(n * n);
+    hipMemcpy(Xi.data(), dinv, n * n * 8, hipMemcpyDeviceToHost);
+    double e2 = 0;
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) { double s2 = 0; for (int k = 0; k < n; ++k) s2 += L[i * n + k] * Xi[k * n + j]; e2 = fmax(e2, fabs(s2 - (i == j))); }
+    printf("max |L Linv - I| = %.3e\n", e2);
     return 0;
 }
