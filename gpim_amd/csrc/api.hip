@@ -30,6 +30,9 @@ int launch_acq(gpimhip_ctx* h, int kind, const double* mean, const double* sd, i
 int launch_nanmax(gpimhip_ctx* h, const double* x, int64_t n, double* out);
 int launch_topk(gpimhip_ctx* h, const double* x, int64_t M, int k, int keep_nan, double* vals, int64_t* idx,
                 int64_t* count);
+int launch_fit_small(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X, const double* y, int N, double* u,
+                     const double* lr_over_bc1, const double* bc2_sqrt, int T, double* hist, double* loss,
+                     double* grad);
 
 static thread_local std::string g_err;
 void gpim_set_error(const std::string& s) { g_err = s; }
@@ -379,6 +382,9 @@ struct StageTimer {
     ~StageTimer() { if (e1) hipEventRecord(e1, h->stream); }
 };
 
+// N <= 128: the fused single-workgroup trainer (smalln.hip) replaces the blocked path
+static bool use_small_path(int64_t N) { return N <= NB && !getenv("GPIMHIP_NO_SMALLN"); }
+
 static int check_model(const gpimhip_model_t* m) {
     if (!m || m->dim < 1 || m->dim > GPIMHIP_MAX_DIM || (m->n_ls != 1 && m->n_ls != m->dim) ||
         m->kernel < 0 || m->kernel > GPIMHIP_KERNEL_RQ) {
@@ -478,6 +484,7 @@ int gpimhip_destroy(gpimhip_handle h) {
     dev_free(h, &h->pred_tiles, h->pred_ntiles);
     dev_free(h, &h->mean_tmp, h->ks_cols);
     dev_free(h, &h->keys, h->keys_cap);
+    dev_free(h, &h->bc, h->bc_cap);
     dev_free(h, &h->theta, 1);
     dev_free(h, &h->adam_m, MAXP);
     dev_free(h, &h->adam_v, MAXP);
@@ -557,8 +564,13 @@ int gpimhip_nll_grad(gpimhip_handle h, const gpimhip_model_t* m, const double* X
     if (!h || !X || !y || !u || N < 1) return GPIMHIP_E_BADARG;
     GP_TRY(check_model(m));
     HIP_TRY(hipSetDevice(h->device));
-    GP_TRY(ws_ensure(h, N));
     HIP_TRY(hipMemsetAsync(h->info, 0, sizeof(int32_t), h->stream));
+    if (use_small_path(N)) {
+        GP_TRY(launch_fit_small(h, m, X, y, (int)N, const_cast<double*>(u), nullptr, nullptr, 0, nullptr, loss_out,
+                                grad_out));
+        return finish_and_check(h);
+    }
+    GP_TRY(ws_ensure(h, N));
     GP_TRY(launch_pad_copy(h, y, N, h->ypad, h->np));
     AdamStep st;
     memset(&st, 0, sizeof(st));
@@ -571,9 +583,30 @@ int gpimhip_fit_exact(gpimhip_handle h, const gpimhip_model_t* m, const double* 
     if (!h || !X || !y || !u_inout || N < 1 || T < 0) return GPIMHIP_E_BADARG;
     GP_TRY(check_model(m));
     HIP_TRY(hipSetDevice(h->device));
-    GP_TRY(ws_ensure(h, N));
     const int P = 2 + m->n_ls + (m->kernel == GPIMHIP_KERNEL_RQ ? 1 : 0);
     HIP_TRY(hipMemsetAsync(h->info, 0, sizeof(int32_t), h->stream));
+    if (use_small_path(N)) {
+        if (T == 0) return GPIMHIP_OK;
+        // fused single-launch trainer: Adam bias corrections are tabulated on the host so that they
+        // are the same libm pow() values the general path passes per iteration
+        if (h->bc_cap < 2 * (int64_t)T) {
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            dev_free(h, &h->bc, h->bc_cap);
+            h->bc_cap = 0;
+            GP_TRY(dev_alloc(h, &h->bc, 2 * (int64_t)T));
+            h->bc_cap = 2 * (int64_t)T;
+        }
+        h->bc_host.resize(2 * (size_t)T);
+        for (int t = 1; t <= T; ++t) {
+            h->bc_host[t - 1] = lr / (1.0 - pow(0.9, (double)t));
+            h->bc_host[T + t - 1] = sqrt(1.0 - pow(0.999, (double)t));
+        }
+        HIP_TRY(hipMemcpyAsync(h->bc, h->bc_host.data(), 2 * (size_t)T * sizeof(double), hipMemcpyHostToDevice,
+                               h->stream));
+        GP_TRY(launch_fit_small(h, m, X, y, (int)N, u_inout, h->bc, h->bc + T, T, hist_out, loss_out, nullptr));
+        return finish_and_check(h);
+    }
+    GP_TRY(ws_ensure(h, N));
     HIP_TRY(hipMemsetAsync(h->adam_m, 0, MAXP * sizeof(double), h->stream));
     HIP_TRY(hipMemsetAsync(h->adam_v, 0, MAXP * sizeof(double), h->stream));
     GP_TRY(launch_pad_copy(h, y, N, h->ypad, h->np));

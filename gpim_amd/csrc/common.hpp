@@ -109,6 +109,10 @@ struct gpimhip_ctx {
     // optional stage timing (bench.py): HIP event pairs on the handle's stream
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[4];
+    // Adam bias-correction table for the fused small-N trainer
+    double* bc = nullptr;
+    int64_t bc_cap = 0;
+    std::vector<double> bc_host;
     // top-k scratch
     unsigned long long* keys = nullptr;
     int64_t keys_cap = 0;

@@ -9,6 +9,7 @@
 // Row labels refer to SURVEY.md section 8(a).  All reductions use fixed-shape trees so results are
 // bit-reproducible run to run.
 #include "kfun.hpp"
+#include "theta.hpp"
 
 typedef double d2 __attribute__((ext_vector_type(2)));
 
@@ -16,40 +17,6 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 // u -> theta   (torch.distributions transform_to(interval) = Affine o Sigmoid with clipping;
 //               transform_to(positive) = exp.  SURVEY App. A.2)
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void interval_map(double u, double lo, double hi, double& val, double& dval) {
-    const double tiny = 2.2250738585072014e-308, eps = 2.220446049250313e-16;
-    double s = 1.0 / (1.0 + exp(-u));
-    double ds = s * (1.0 - s);
-    if (s < tiny) { s = tiny; ds = 0.0; }
-    if (s > 1.0 - eps) { s = 1.0 - eps; ds = 0.0; }
-    val = lo + (hi - lo) * s;
-    dval = (hi - lo) * ds;
-}
-
-__device__ void theta_from_u(const gpimhip_model_t& m, const double* u, ThetaDev& t) {
-    interval_map(u[0], m.amp_lo, m.amp_hi, t.var, t.dvar_du);
-    for (int k = 0; k < GPIMHIP_MAX_DIM; ++k) {
-        const int src = (m.n_ls == 1) ? 0 : k;
-        if (k < m.dim) {
-            interval_map(u[1 + src], m.ls_lo[src], m.ls_hi[src], t.ls[k], t.dls_du[k]);
-        } else {
-            t.ls[k] = 1.0;
-            t.dls_du[k] = 0.0;
-        }
-        t.inv_ls[k] = 1.0 / t.ls[k];
-    }
-    t.noise = exp(u[1 + m.n_ls]);
-    t.dnoise_du = t.noise;
-    if (m.kernel == GPIMHIP_KERNEL_RQ) {
-        t.alpha = exp(u[2 + m.n_ls]);
-        t.dalpha_du = t.alpha;
-    } else {
-        t.alpha = 1.0;
-        t.dalpha_du = 0.0;
-    }
-    t.diag_add = m.jitter + t.noise;
-}
-
 __global__ void theta_kernel(gpimhip_model_t m, const double* __restrict__ u, ThetaDev* __restrict__ out) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         ThetaDev t;
@@ -449,44 +416,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(gpimhip_model_t m, int64_
     lg = block_sum_256(lg, red);
     if (tid != 0) return;
 
-    const ThetaDev t = *th;
-    const int P = 2 + m.n_ls + (m.kernel == GPIMHIP_KERNEL_RQ ? 1 : 0);
-    double prior = log(m.amp_hi - m.amp_lo);
-    for (int k = 0; k < m.n_ls; ++k) prior += log(m.ls_hi[k] - m.ls_lo[k]);
-    const double loss = 0.5 * q2 + lg + 0.5 * (double)N * 1.8378770664093453 + prior;
-    double g[MAXP];
-    g[0] = 0.5 * S[0] * t.dvar_du;
-    if (m.n_ls == 1) {
-        double s = 0.0;
-        for (int k = 0; k < m.dim; ++k) s += S[1 + k];
-        g[1] = 0.5 * s * t.var / t.ls[0] * t.dls_du[0];
-    } else {
-        for (int k = 0; k < m.dim; ++k) g[1 + k] = 0.5 * S[1 + k] * t.var / t.ls[k] * t.dls_du[k];
-    }
-    g[1 + m.n_ls] = 0.5 * S[5] * t.dnoise_du;
-    if (m.kernel == GPIMHIP_KERNEL_RQ) g[2 + m.n_ls] = 0.5 * S[6] * t.var * t.dalpha_du;
-    if (loss_out) *loss_out = loss;
-    if (grad_out)
-        for (int k = 0; k < P; ++k) grad_out[k] = g[k];
-    if (do_adam) {
-        for (int k = 0; k < P; ++k) {
-            double mm = adam_m[k], vv = adam_v[k];
-            mm = mm + (g[k] - mm) * (1.0 - st.beta1);            // exp_avg.lerp_(grad, 1 - beta1)
-            vv = vv * st.beta2 + (1.0 - st.beta2) * g[k] * g[k]; // exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)
-            const double denom = sqrt(vv) / st.bc2_sqrt + st.eps;
-            u[k] = u[k] + (-st.lr_over_bc1) * (mm / denom);      // param.addcdiv_(exp_avg, denom, value=-step_size)
-            adam_m[k] = mm;
-            adam_v[k] = vv;
-        }
-        if (hist_row) {
-            ThetaDev tn;
-            theta_from_u(m, u, tn);
-            hist_row[0] = tn.var;
-            for (int k = 0; k < m.n_ls; ++k) hist_row[1 + k] = tn.ls[k];
-            hist_row[1 + m.n_ls] = tn.noise;
-            if (m.kernel == GPIMHIP_KERNEL_RQ) hist_row[2 + m.n_ls] = tn.alpha;
-        }
-    }
+    finalize_step(m, N, S, q2, lg, *th, u, adam_m, adam_v, do_adam, st, loss_out, grad_out, hist_row);
 }
 
 int launch_finalize(gpimhip_ctx* h, const gpimhip_model_t* m, int64_t N, int64_t np, double* u, int do_adam,
