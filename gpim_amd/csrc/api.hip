@@ -22,7 +22,8 @@ int launch_gemv_t(gpimhip_ctx* h, const double* A, int64_t ld, int64_t nrows, in
 int launch_grad_reduce(gpimhip_ctx* h, const gpimhip_model_t* m, const double* Kinv, int64_t ld,
                        const double* X, int64_t N, int nb, const double* alpha);
 int launch_finalize(gpimhip_ctx* h, const gpimhip_model_t* m, int64_t N, int64_t np, double* u, int do_adam,
-                    AdamStep st, double* loss_out, double* grad_out, double* hist_row);
+                    AdamStep st, double* loss_out, double* grad_out, double* hist_row, int32_t* iter,
+                    const double* bc, int T, double* hist_base, double* loss_base);
 int launch_predict_var(gpimhip_ctx* h, int64_t ldp, int nb, int64_t m0, int64_t mcount, double* var_out);
 int launch_copy_slice(gpimhip_ctx* h, const double* src, double* dst, int64_t n);
 int launch_acq(gpimhip_ctx* h, int kind, const double* mean, const double* sd, int64_t M, double p0, double p1,
@@ -38,6 +39,7 @@ static thread_local std::string g_err;
 void gpim_set_error(const std::string& s) { g_err = s; }
 
 #define RESERVED_CUS 16
+#define LOOKAHEAD_MIN_PANELS 24
 #define OUTER_W 4    // outer Cholesky panel = 4 x 128 columns: trailing updates run with k-depth 512
 
 // ------------------------------------------------------------------------------------------
@@ -121,7 +123,10 @@ int ws_ensure_predict(gpimhip_ctx* h, int64_t np, int64_t mc) {
                 for (int cj = jg * 8; cj < std::min(nc, jg * 8 + 8); ++cj) tl.push_back({ci, cj, 0, ci + 1});
     h->pred_ntiles = (int64_t)tl.size();
     GP_TRY(dev_alloc(h, &h->pred_tiles, h->pred_ntiles));
-    HIP_TRY(hipMemcpy(h->pred_tiles, tl.data(), tl.size() * sizeof(TileDesc), hipMemcpyHostToDevice));
+    // (async + stream sync rather than hipMemcpy: the latter serialises against the legacy stream and is
+    // illegal while another thread captures a graph)
+    HIP_TRY(hipMemcpyAsync(h->pred_tiles, tl.data(), tl.size() * sizeof(TileDesc), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
     h->ks_rows = np;
     h->ks_cols = mc;
     return GPIMHIP_OK;
@@ -237,7 +242,8 @@ int plan_ensure(gpimhip_ctx* h, int nb) {
     void* q = nullptr;
     HIP_TRY(hipMalloc(&q, std::max<size_t>(tl.size(), 1) * sizeof(TileDesc)));
     P.d_tiles = (TileDesc*)q;
-    HIP_TRY(hipMemcpy(P.d_tiles, tl.data(), tl.size() * sizeof(TileDesc), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpyAsync(P.d_tiles, tl.data(), tl.size() * sizeof(TileDesc), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
     P.nb = nb;
     return GPIMHIP_OK;
 }
@@ -291,7 +297,7 @@ int launch_potrf(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_t* inf
     hipStream_t main_s = h->stream;
     // below ~12k unknowns the trailing updates are too short to hide a panel chain behind them and
     // the extra cross-stream traffic costs more than it saves
-    const bool ahead = (h->panel_stream != nullptr) && npanel >= 24;
+    const bool ahead = (h->panel_stream != nullptr) && npanel >= LOOKAHEAD_MIN_PANELS;
     if ((int)h->ev_pool.size() < 2 * npanel + 1) {
         while ((int)h->ev_pool.size() < 2 * npanel + 1) {
             hipEvent_t e;
@@ -408,14 +414,40 @@ static int factor_at_u(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X
     return GPIMHIP_OK;
 }
 
+struct IterTable { int32_t* iter; const double* bc; int T; double* hist_base; double* loss_base; };
+
 static int loss_grad_at_u(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X, const double* y, int64_t N,
                           double* u, int do_adam, AdamStep st, double* loss_out, double* grad_out,
-                          double* hist_row) {
+                          double* hist_row, const IterTable* tab = nullptr) {
     const int64_t np = h->np;
     GP_TRY(factor_at_u(h, m, X, y, N, u));
     { StageTimer t(h, 2); GP_TRY(launch_lauum(h, h->A, h->B, np, np)); }
     GP_TRY(launch_grad_reduce(h, m, h->B, np, X, N, (int)(np / NB), h->alpha));
-    GP_TRY(launch_finalize(h, m, N, np, u, do_adam, st, loss_out, grad_out, hist_row));
+    if (tab)
+        GP_TRY(launch_finalize(h, m, N, np, u, do_adam, st, nullptr, nullptr, nullptr, tab->iter, tab->bc, tab->T,
+                               tab->hist_base, tab->loss_base));
+    else
+        GP_TRY(launch_finalize(h, m, N, np, u, do_adam, st, loss_out, grad_out, hist_row, nullptr, nullptr, 0,
+                               nullptr, nullptr));
+    return GPIMHIP_OK;
+}
+
+// Fill the device table of Adam bias corrections (same libm pow() values for every path).
+static int upload_bc_table(gpimhip_ctx* h, double lr, int T) {
+    if (h->bc_cap < 2 * (int64_t)T) {
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        dev_free(h, &h->bc, h->bc_cap);
+        h->bc_cap = 0;
+        GP_TRY(dev_alloc(h, &h->bc, 2 * (int64_t)T));
+        h->bc_cap = 2 * (int64_t)T;
+    }
+    h->bc_host.resize(2 * (size_t)T);
+    for (int t = 1; t <= T; ++t) {
+        h->bc_host[t - 1] = lr / (1.0 - pow(0.9, (double)t));
+        h->bc_host[T + t - 1] = sqrt(1.0 - pow(0.999, (double)t));
+    }
+    HIP_TRY(hipMemcpyAsync(h->bc, h->bc_host.data(), 2 * (size_t)T * sizeof(double), hipMemcpyHostToDevice,
+                           h->stream));
     return GPIMHIP_OK;
 }
 
@@ -453,6 +485,8 @@ int gpimhip_create(gpimhip_handle* out, int device, void* hip_stream) {
         // The bulk trailing updates run on a stream whose CU mask leaves RESERVED_CUS compute units
         // free: potf2 needs ~150 KB of LDS, i.e. a whole CU, and would otherwise wait until the bulk
         // kernel (2 x 74 KB per CU, thousands of workgroups queued) has drained.
+        if (hipStreamCreateWithFlags(&h->capture_stream, hipStreamNonBlocking) != hipSuccess)
+            h->capture_stream = nullptr;
         hipDeviceProp_t prop;
         if (h->panel_stream && hipGetDeviceProperties(&prop, device) == hipSuccess && !getenv("GPIMHIP_NO_CUMASK")) {
             const int ncu = prop.multiProcessorCount;
@@ -494,6 +528,7 @@ int gpimhip_destroy(gpimhip_handle h) {
     for (auto e : h->ev_pool) hipEventDestroy(e);
     if (h->panel_stream) hipStreamDestroy(h->panel_stream);
     if (h->bulk_stream) hipStreamDestroy(h->bulk_stream);
+    if (h->capture_stream) hipStreamDestroy(h->capture_stream);
     delete h;
     return GPIMHIP_OK;
 }
@@ -587,22 +622,8 @@ int gpimhip_fit_exact(gpimhip_handle h, const gpimhip_model_t* m, const double* 
     HIP_TRY(hipMemsetAsync(h->info, 0, sizeof(int32_t), h->stream));
     if (use_small_path(N)) {
         if (T == 0) return GPIMHIP_OK;
-        // fused single-launch trainer: Adam bias corrections are tabulated on the host so that they
-        // are the same libm pow() values the general path passes per iteration
-        if (h->bc_cap < 2 * (int64_t)T) {
-            HIP_TRY(hipStreamSynchronize(h->stream));
-            dev_free(h, &h->bc, h->bc_cap);
-            h->bc_cap = 0;
-            GP_TRY(dev_alloc(h, &h->bc, 2 * (int64_t)T));
-            h->bc_cap = 2 * (int64_t)T;
-        }
-        h->bc_host.resize(2 * (size_t)T);
-        for (int t = 1; t <= T; ++t) {
-            h->bc_host[t - 1] = lr / (1.0 - pow(0.9, (double)t));
-            h->bc_host[T + t - 1] = sqrt(1.0 - pow(0.999, (double)t));
-        }
-        HIP_TRY(hipMemcpyAsync(h->bc, h->bc_host.data(), 2 * (size_t)T * sizeof(double), hipMemcpyHostToDevice,
-                               h->stream));
+        // fused single-launch trainer
+        GP_TRY(upload_bc_table(h, lr, T));
         GP_TRY(launch_fit_small(h, m, X, y, (int)N, u_inout, h->bc, h->bc + T, T, hist_out, loss_out, nullptr));
         return finish_and_check(h);
     }
@@ -610,15 +631,44 @@ int gpimhip_fit_exact(gpimhip_handle h, const gpimhip_model_t* m, const double* 
     HIP_TRY(hipMemsetAsync(h->adam_m, 0, MAXP * sizeof(double), h->stream));
     HIP_TRY(hipMemsetAsync(h->adam_v, 0, MAXP * sizeof(double), h->stream));
     GP_TRY(launch_pad_copy(h, y, N, h->ypad, h->np));
-    const double b1 = 0.9, b2 = 0.999;
-    for (int t = 1; t <= T; ++t) {
-        AdamStep st;
-        st.beta1 = b1; st.beta2 = b2; st.eps = 1e-8;
-        st.lr_over_bc1 = lr / (1.0 - pow(b1, (double)t));
-        st.bc2_sqrt = sqrt(1.0 - pow(b2, (double)t));
-        GP_TRY(loss_grad_at_u(h, m, X, y, N, u_inout, 1, st, loss_out ? loss_out + (t - 1) : nullptr, nullptr,
-                              hist_out ? hist_out + (int64_t)(t - 1) * P : nullptr));
+    if (T == 0) return GPIMHIP_OK;
+    GP_TRY(upload_bc_table(h, lr, T));
+    HIP_TRY(hipMemsetAsync(h->info + 1, 0, sizeof(int32_t), h->stream));     // iteration counter
+    IterTable tab{h->info + 1, h->bc, T, hist_out, loss_out};
+    AdamStep st;
+    st.beta1 = 0.9; st.beta2 = 0.999; st.eps = 1e-8; st.lr_over_bc1 = 0.0; st.bc2_sqrt = 1.0;
+    // Every iteration enqueues the same launches (the iteration index lives on the device), so one
+    // iteration is captured into a hipGraph and replayed: ~10 us of host work per iteration instead
+    // of one launch call per kernel.  Not used with the multi-stream look-ahead schedule (large N,
+    // where launch cost is irrelevant), while stage timing is on, or for very short fits.
+    const int npanel = (int)((h->np / NB + OUTER_W - 1) / OUTER_W);
+    bool use_graph = T >= 8 && !h->timing && npanel < LOOKAHEAD_MIN_PANELS && h->capture_stream &&
+                     !getenv("GPIMHIP_NO_GRAPH");
+    if (use_graph) {
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        hipStream_t main_s = h->stream;
+        h->stream = h->capture_stream;
+        hipError_t e = hipStreamBeginCapture(h->capture_stream, hipStreamCaptureModeRelaxed);
+        int rc = GPIMHIP_OK;
+        if (e == hipSuccess) {
+            rc = loss_grad_at_u(h, m, X, y, N, u_inout, 1, st, nullptr, nullptr, nullptr, &tab);
+            e = hipStreamEndCapture(h->capture_stream, &graph);
+        }
+        h->stream = main_s;
+        if (rc != GPIMHIP_OK) { if (graph) hipGraphDestroy(graph); return rc; }
+        if (e == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+            for (int t = 0; t < T; ++t) HIP_TRY(hipGraphLaunch(exec, main_s));
+            rc = finish_and_check(h);
+            hipGraphExecDestroy(exec);
+            hipGraphDestroy(graph);
+            return rc;
+        }
+        if (graph) hipGraphDestroy(graph);
+        (void)hipGetLastError();                        // capture unavailable: plain launches below
     }
+    for (int t = 0; t < T; ++t)
+        GP_TRY(loss_grad_at_u(h, m, X, y, N, u_inout, 1, st, nullptr, nullptr, nullptr, &tab));
     return finish_and_check(h);
 }
 

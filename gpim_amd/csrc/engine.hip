@@ -390,6 +390,17 @@ __device__ double block_sum_256(double v, double* red) {
     return r;
 }
 
+// Iteration-indexed form: when `iter` is given the Adam bias corrections, the history row and the
+// loss slot are looked up by the device-resident iteration counter, which this kernel advances.  All
+// T iterations then enqueue byte-identical launches, i.e. one captured hipGraph can be replayed.
+struct FinalizeIter {
+    int32_t* iter;              // device counter (null: use the by-value arguments below)
+    const double* bc;           // [2*T]: lr/(1-beta1^t) then sqrt(1-beta2^t)
+    int32_t T;
+    double* hist_base;          // T x P or null
+    double* loss_base;          // T or null
+};
+
 __global__ __launch_bounds__(256) void finalize_kernel(gpimhip_model_t m, int64_t N, int64_t np, int nb,
                                                        int ntile, const double* __restrict__ grad_part,
                                                        const double* __restrict__ z,
@@ -398,7 +409,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(gpimhip_model_t m, int64_
                                                        double* __restrict__ adam_m, double* __restrict__ adam_v,
                                                        int do_adam, AdamStep st, double* __restrict__ loss_out,
                                                        double* __restrict__ grad_out,
-                                                       double* __restrict__ hist_row) {
+                                                       double* __restrict__ hist_row, FinalizeIter fi) {
     __shared__ double red[256];
     __shared__ double S[8];
     const int tid = threadIdx.x;
@@ -416,15 +427,26 @@ __global__ __launch_bounds__(256) void finalize_kernel(gpimhip_model_t m, int64_
     lg = block_sum_256(lg, red);
     if (tid != 0) return;
 
+    if (fi.iter) {
+        const int it = *fi.iter;
+        const int P = 2 + m.n_ls + (m.kernel == GPIMHIP_KERNEL_RQ ? 1 : 0);
+        st.lr_over_bc1 = fi.bc[it];
+        st.bc2_sqrt = fi.bc[fi.T + it];
+        loss_out = fi.loss_base ? fi.loss_base + it : nullptr;
+        hist_row = fi.hist_base ? fi.hist_base + (int64_t)it * P : nullptr;
+        *fi.iter = it + 1;
+    }
     finalize_step(m, N, S, q2, lg, *th, u, adam_m, adam_v, do_adam, st, loss_out, grad_out, hist_row);
 }
 
 int launch_finalize(gpimhip_ctx* h, const gpimhip_model_t* m, int64_t N, int64_t np, double* u, int do_adam,
-                    AdamStep st, double* loss_out, double* grad_out, double* hist_row) {
+                    AdamStep st, double* loss_out, double* grad_out, double* hist_row, int32_t* iter,
+                    const double* bc, int T, double* hist_base, double* loss_base) {
     const int nb = (int)(np / NB);
+    FinalizeIter fi{iter, bc, T, hist_base, loss_base};
     hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, h->stream, *m, N, np, nb, nb * (nb + 1) / 2,
                        h->grad_part, h->z, h->logdet_part, h->theta, u, h->adam_m, h->adam_v, do_adam, st,
-                       loss_out, grad_out, hist_row);
+                       loss_out, grad_out, hist_row, fi);
     HIP_TRY(hipGetLastError());
     return GPIMHIP_OK;
 }

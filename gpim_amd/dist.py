@@ -74,15 +74,25 @@ def gather_to_root(local, n_units, unit_shape, device=None, dtype=torch.float64)
     return full
 
 
-def run_units(units, unit_fn, out_shape, device=None):
+def run_units(units, unit_fn, out_shape, device=None, concurrency=1):
     """Deal `units` over the ranks, run ``unit_fn(unit) -> (mean, sd)`` on the owned ones and
-    gather; returns (mean_all, sd_all) of shape (len(units), *out_shape) on rank 0, else None."""
+    gather; returns (mean_all, sd_all) of shape (len(units), *out_shape) on rank 0, else None.
+    concurrency > 1 runs that many owned units at a time on host threads (the C ABI releases the
+    GIL; each worker should use its own HIP stream) so that small problems overlap on one GPU."""
     rank, ws = world()
-    mine = {}
-    for idx in shard_units(len(units), rank, ws):
+    owned = shard_units(len(units), rank, ws)
+
+    def one(idx):
         mean, sd = unit_fn(units[idx])
         mean, sd = torch.as_tensor(mean), torch.as_tensor(sd)
-        mine[idx] = torch.stack([mean.reshape(out_shape), sd.reshape(out_shape)])
+        return idx, torch.stack([mean.reshape(out_shape), sd.reshape(out_shape)])
+
+    if concurrency > 1 and len(owned) > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=concurrency) as pool:
+            mine = dict(pool.map(one, owned))
+    else:
+        mine = dict(one(i) for i in owned)
     if device is None and mine:
         device = next(iter(mine.values())).device
     if device is None:
@@ -94,27 +104,42 @@ def run_units(units, unit_fn, out_shape, device=None):
     return full[:, 0], full[:, 1]
 
 
-def reconstruct_slices(cube, axis=-1, **recon_kwargs):
+def reconstruct_slices(cube, axis=-1, concurrency=8, return_hyperparams=False, **recon_kwargs):
     """Independent 2D GP reconstruction of every slice of a 3D cube along `axis` (config C3 of
-    SURVEY 8(d)), slices sharded over the ranks.  Returns (mean, sd) cubes on rank 0."""
+    SURVEY 8(d)): slices are sharded over the ranks, and on each GPU `concurrency` slices are in
+    flight at a time, each on its own HIP stream (a single ~1000-point fit is latency-bound and
+    leaves most of the chip idle).  Returns (mean, sd) cubes on rank 0 (None elsewhere)."""
+    import threading
     from . import gprutils
     from .gpr import reconstructor
     cube = np.moveaxis(np.asarray(cube), axis, 0)
     units = [cube[i] for i in range(cube.shape[0])]
     dev = torch.device("cuda", torch.cuda.current_device())
+    local = threading.local()
+    hyper = {}
 
     def fit(R):
-        X, Xf = gprutils.get_sparse_grid(R), gprutils.get_full_grid(R)
-        rec = reconstructor(X, R, Xf, **recon_kwargs)
-        rec.train()
-        rec.predict()
-        return rec._last_pred
+        if not hasattr(local, "stream"):
+            torch.cuda.set_device(dev)
+            local.stream = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(local.stream):
+            X, Xf = gprutils.get_sparse_grid(R), gprutils.get_full_grid(R)
+            rec = reconstructor(X, R, Xf, **recon_kwargs)
+            rec.train()
+            rec.predict()
+            mean, sd = rec._last_pred
+            local.stream.synchronize()
+            hyper[id(R)] = rec.hyperparams
+        return mean, sd
 
-    res = run_units(units, fit, cube.shape[1:], device=dev)
+    res = run_units(units, fit, cube.shape[1:], device=dev, concurrency=concurrency)
     if res is None:
         return None
     mean, sd = res
-    return (np.moveaxis(mean.cpu().numpy(), 0, axis), np.moveaxis(sd.cpu().numpy(), 0, axis))
+    out = (np.moveaxis(mean.cpu().numpy(), 0, axis), np.moveaxis(sd.cpu().numpy(), 0, axis))
+    if return_hyperparams:
+        return out + ([hyper.get(id(u)) for u in units],)
+    return out
 
 
 def candidate_block(M, rank=None, world_size=None):

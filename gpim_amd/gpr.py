@@ -129,7 +129,9 @@ class reconstructor:
         self._spec = get_kernel(kernel, input_dim, lengthscale, use_gpu,
                                 amplitude=kwargs.get('amplitude'), precision=self.precision,
                                 jitter=kwargs.get("jitter", 1.0e-5))
-        self._u = self._spec.draw_initial_u().to(self._dev)
+        # drawn from a private generator seeded like the global one: identical numbers, no race when
+        # several reconstructors are built from different threads
+        self._u = self._spec.draw_initial_u(torch.Generator().manual_seed(seed)).to(self._dev)
         self._mstruct = self._spec.struct()
         self.fulldims = Xtest.shape[1:] if Xtest is not None else X.shape[1:]
         self.Xtest = gprutils.prepare_test_data(Xtest, precision=self.precision) if Xtest is not None else None

@@ -51,12 +51,15 @@ class KernelSpec:
         self.jitter = float(jitter)
         self.n_params = 2 + self.n_ls + (1 if kernel_type == "RationalQuadratic" else 0)
 
-    def draw_initial_u(self):
-        """The two prior draws (torch CPU generator; caller seeds it) mapped to u."""
+    def draw_initial_u(self, generator=None):
+        """The two prior draws mapped to u.  generator: a torch CPU Generator (default: the global
+        one, which the caller has just seeded like gpr.py:101 does); a private generator seeded
+        with the same value yields the same numbers and is safe under threads."""
         alo, ahi = torch.tensor(self.amp_lo, dtype=_F64), torch.tensor(self.amp_hi, dtype=_F64)
-        v0 = alo + torch.rand((), dtype=_F64) * (ahi - alo)
+        v0 = alo + torch.rand((), dtype=_F64, generator=generator) * (ahi - alo)
         shape = () if self.isotropic else (self.n_ls,)
-        l0 = self.ls_lo.reshape(shape) + torch.rand(shape, dtype=_F64) * (self.ls_hi - self.ls_lo).reshape(shape)
+        l0 = self.ls_lo.reshape(shape) + torch.rand(shape, dtype=_F64, generator=generator) * (
+            self.ls_hi - self.ls_lo).reshape(shape)
         u = torch.zeros(self.n_params, dtype=_F64)          # noise = exp(0) = 1, alpha_rq = exp(0) = 1
         u[0] = _logit_clipped((v0 - alo) / (ahi - alo))
         u[1:1 + self.n_ls] = _logit_clipped((l0.reshape(-1) - self.ls_lo) / (self.ls_hi - self.ls_lo))
