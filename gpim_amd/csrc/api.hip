@@ -10,7 +10,8 @@
 int launch_theta_raw(gpimhip_ctx* h, const gpimhip_model_t* m, const double* raw);
 int launch_kmat(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X, int64_t N, const double* Z,
                 int64_t M, const ThetaDev* theta, double diag_add, int use_theta_diag, double* out,
-                int64_t ld, int64_t rows_pad, int64_t cols_pad, int sym, int lower_only);
+                int64_t ld, int64_t rows_pad, int64_t cols_pad, int sym, int lower_only, int64_t x_bs,
+                int64_t z_bs, int64_t out_bs);
 int launch_potf2(gpimhip_ctx* h, double* A, int64_t ld, int kblk, int32_t* info);
 int launch_pad_copy(gpimhip_ctx* h, const double* src, int64_t n, double* dst, int64_t np);
 int launch_diag_inv_copy(gpimhip_ctx* h, double* A, int64_t ld, int nb);
@@ -18,22 +19,22 @@ int launch_pad_matrix_in(gpimhip_ctx* h, const double* src, int64_t n, int64_t l
 int launch_pad_matrix_out_lower(gpimhip_ctx* h, const double* src, int64_t np, double* dst, int64_t n, int64_t ld);
 int launch_trmv_lower(gpimhip_ctx* h, const double* L, int64_t ld, int64_t np, const double* y, double* z);
 int launch_gemv_t(gpimhip_ctx* h, const double* A, int64_t ld, int64_t nrows, int64_t ncols, const double* x,
-                  double* out, int tri);
+                  double* out, int tri, int64_t a_bs, int64_t x_bs, int64_t o_bs);
 int launch_grad_reduce(gpimhip_ctx* h, const gpimhip_model_t* m, const double* Kinv, int64_t ld,
-                       const double* X, int64_t N, int nb, const double* alpha);
+                       const double* X, int64_t N, int nb, const double* alpha, int64_t x_bs);
 int launch_finalize(gpimhip_ctx* h, const gpimhip_model_t* m, int64_t N, int64_t np, double* u, int do_adam,
                     AdamStep st, double* loss_out, double* grad_out, double* hist_row, int32_t* iter,
                     const double* bc, int T, double* hist_base, double* loss_base);
-int launch_predict_var(gpimhip_ctx* h, int64_t ldp, int nb, int64_t m0, int64_t mcount, double* var_out);
-int launch_copy_slice(gpimhip_ctx* h, const double* src, double* dst, int64_t n);
+int launch_predict_var(gpimhip_ctx* h, int64_t ldp, int nb, int64_t m0, int64_t mcount, double* var_out, int64_t M);
+int launch_copy_slice(gpimhip_ctx* h, const double* src, double* dst, int64_t n, int64_t s_bs, int64_t d_bs);
 int launch_acq(gpimhip_ctx* h, int kind, const double* mean, const double* sd, int64_t M, double p0, double p1,
                const double* mask, double* out);
 int launch_nanmax(gpimhip_ctx* h, const double* x, int64_t n, double* out);
 int launch_topk(gpimhip_ctx* h, const double* x, int64_t M, int k, int keep_nan, double* vals, int64_t* idx,
                 int64_t* count);
-int launch_fit_small(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X, const double* y, int N, double* u,
-                     const double* lr_over_bc1, const double* bc2_sqrt, int T, double* hist, double* loss,
-                     double* grad);
+int launch_fit_small(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X, int64_t x_bs, const double* y,
+                     int N, double* u, const double* lr_over_bc1, const double* bc2_sqrt, int T, double* hist,
+                     double* loss, double* grad);
 
 static thread_local std::string g_err;
 void gpim_set_error(const std::string& s) { g_err = s; }
@@ -67,52 +68,68 @@ static void dev_free(gpimhip_ctx* h, T** p, int64_t count) {
 }
 
 static void ws_release_matrix(gpimhip_ctx* h) {
-    const int64_t np = h->np, nb = np / NB;
+    const int64_t np = h->np, nb = np / NB, B = h->ws_batch;
     if (!np) return;
-    dev_free(h, &h->A, np * np);
-    dev_free(h, &h->B, np * np);
-    dev_free(h, &h->Tm, np * np);
-    dev_free(h, &h->dinv, nb * NB * NB);
-    dev_free(h, &h->linv16, nb * 8 * 256);
-    dev_free(h, &h->ypad, np);
-    dev_free(h, &h->z, np);
-    dev_free(h, &h->alpha, np);
-    dev_free(h, &h->logdet_part, nb);
-    dev_free(h, &h->grad_part, nb * (nb + 1) / 2 * 8);
+    dev_free(h, &h->A, B * np * np);
+    dev_free(h, &h->B, B * np * np);
+    dev_free(h, &h->Tm, B * np * np);
+    dev_free(h, &h->dinv, B * nb * NB * NB);
+    dev_free(h, &h->linv16, B * nb * 8 * 256);
+    dev_free(h, &h->ypad, B * np);
+    dev_free(h, &h->z, B * np);
+    dev_free(h, &h->alpha, B * np);
+    dev_free(h, &h->logdet_part, B * nb);
+    dev_free(h, &h->grad_part, B * nb * (nb + 1) / 2 * 8);
+    dev_free(h, &h->theta, B);
+    dev_free(h, &h->adam_m, B * MAXP);
+    dev_free(h, &h->adam_v, B * MAXP);
+    dev_free(h, &h->iter, B);
     h->np = 0;
+    h->ws_batch = 0;
 }
 
-int ws_ensure(gpimhip_ctx* h, int64_t N) {
+// Workspace for B problems of N observations processed in lock-step (all per-problem buffers are
+// stacked: problem b lives at base + b * size).
+static int ws_ensure_b(gpimhip_ctx* h, int64_t N, int B) {
     const int64_t np = pad_to(std::max<int64_t>(N, 1), NB);
-    if (np == h->np) return GPIMHIP_OK;
+    if (np == h->np && B == h->ws_batch) return GPIMHIP_OK;
     HIP_TRY(hipStreamSynchronize(h->stream));
     ws_release_matrix(h);
     const int64_t nb = np / NB;
-    GP_TRY(dev_alloc(h, &h->A, np * np));
-    GP_TRY(dev_alloc(h, &h->B, np * np));
-    GP_TRY(dev_alloc(h, &h->Tm, np * np));
-    GP_TRY(dev_alloc(h, &h->dinv, nb * NB * NB));
-    GP_TRY(dev_alloc(h, &h->linv16, nb * 8 * 256));
-    GP_TRY(dev_alloc(h, &h->ypad, np));
-    GP_TRY(dev_alloc(h, &h->z, np));
-    GP_TRY(dev_alloc(h, &h->alpha, np));
-    GP_TRY(dev_alloc(h, &h->logdet_part, nb));
-    GP_TRY(dev_alloc(h, &h->grad_part, nb * (nb + 1) / 2 * 8));
+    GP_TRY(dev_alloc(h, &h->A, B * np * np));
+    GP_TRY(dev_alloc(h, &h->B, B * np * np));
+    GP_TRY(dev_alloc(h, &h->Tm, B * np * np));
+    GP_TRY(dev_alloc(h, &h->dinv, B * nb * NB * NB));
+    GP_TRY(dev_alloc(h, &h->linv16, B * nb * 8 * 256));
+    GP_TRY(dev_alloc(h, &h->ypad, B * np));
+    GP_TRY(dev_alloc(h, &h->z, B * np));
+    GP_TRY(dev_alloc(h, &h->alpha, B * np));
+    GP_TRY(dev_alloc(h, &h->logdet_part, B * nb));
+    GP_TRY(dev_alloc(h, &h->grad_part, B * nb * (nb + 1) / 2 * 8));
+    GP_TRY(dev_alloc(h, &h->theta, (int64_t)B));
+    GP_TRY(dev_alloc(h, &h->adam_m, (int64_t)B * MAXP));
+    GP_TRY(dev_alloc(h, &h->adam_v, (int64_t)B * MAXP));
+    GP_TRY(dev_alloc(h, &h->iter, (int64_t)B));
     h->np = np;
+    h->ws_batch = B;
     return plan_ensure(h, (int)nb);
 }
+int ws_ensure(gpimhip_ctx* h, int64_t N) { return ws_ensure_b(h, N, h->nbatch); }
 
 int ws_ensure_predict(gpimhip_ctx* h, int64_t np, int64_t mc) {
-    if (h->ks_rows == np && h->ks_cols == mc) return GPIMHIP_OK;
+    const int B = h->nbatch;
+    if (h->ks_rows == np && h->ks_cols == mc && h->ks_batch == B) return GPIMHIP_OK;
     HIP_TRY(hipStreamSynchronize(h->stream));
-    dev_free(h, &h->Ks, h->ks_rows * h->ks_cols);
-    dev_free(h, &h->colpart, (h->ks_rows / NB) * h->ks_cols);
+    dev_free(h, &h->Ks, h->ks_batch * h->ks_rows * h->ks_cols);
+    dev_free(h, &h->colpart, h->ks_batch * (h->ks_rows / NB) * h->ks_cols);
     dev_free(h, &h->pred_tiles, h->pred_ntiles);
-    dev_free(h, &h->mean_tmp, h->ks_cols);
+    dev_free(h, &h->mean_tmp, h->ks_batch * h->ks_cols);
     h->ks_rows = h->ks_cols = 0;
-    GP_TRY(dev_alloc(h, &h->Ks, np * mc));
-    GP_TRY(dev_alloc(h, &h->colpart, (np / NB) * mc));
-    GP_TRY(dev_alloc(h, &h->mean_tmp, mc));
+    h->ks_batch = 0;
+    GP_TRY(dev_alloc(h, &h->Ks, B * np * mc));
+    GP_TRY(dev_alloc(h, &h->colpart, B * (np / NB) * mc));
+    GP_TRY(dev_alloc(h, &h->mean_tmp, B * mc));
+    h->ks_batch = B;
     // tile list of the variance product W = L^-1 K*: 8x8 patches, longest k-ranges first
     const int nb = (int)(np / NB), nc = (int)(mc / NB);
     std::vector<TileDesc> tl;
@@ -257,6 +274,7 @@ static GemmArgs gemm_args(const double* A, int64_t lda, const double* B, int64_t
     memset(&g, 0, sizeof(g));
     g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
     g.alpha = alpha; g.beta = beta; g.tiles = tiles; g.ntiles = n;
+    g.sA = lda * lda; g.sB = ldb * ldb; g.sC = ldc * ldc;     // square np x np workspace matrices
     return g;
 }
 
@@ -279,6 +297,7 @@ static int panel_steps(gpimhip_ctx* h, double* A, int64_t ld, int32_t* info, int
         if (P.trsm[k].n) {
             GemmArgs g = gemm_args(A, ld, h->dinv, NB, A, ld, 1.0, 0.0, P.d_tiles + P.trsm[k].off, P.trsm[k].n);
             g.b_coff = -k;            // dinv is a (nb*128) x 128 matrix: block (k, 0)
+            g.sB = (h->np / NB) * NB * NB;
             GP_TRY(launch_gemm(h, false, false, EPI_STORE, g));
         }
         if (P.inner[k].n) {
@@ -401,28 +420,28 @@ static int check_model(const gpimhip_model_t* m) {
 }
 
 // Everything needed at the current u: theta, K, L, L^-1, z, alpha.  (Shared by fit and predict.)
-static int factor_at_u(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X, const double* y, int64_t N,
+// x_bs: per-problem stride of X in elements (0 when all problems of a batch share one X).
+static int factor_at_u(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X, int64_t x_bs, int64_t N,
                        const double* u) {
     const int64_t np = h->np;
     GP_TRY(launch_theta(h, m, u));
-    GP_TRY(launch_kmat(h, m, X, N, nullptr, N, h->theta, 0.0, 1, h->A, np, np, np, 1, 1));
+    GP_TRY(launch_kmat(h, m, X, N, nullptr, N, h->theta, 0.0, 1, h->A, np, np, np, 1, 1, x_bs, x_bs, np * np));
     { StageTimer t(h, 0); GP_TRY(launch_potrf(h, h->A, np, np, h->info)); }
     { StageTimer t(h, 1); GP_TRY(launch_trtri(h, h->A, h->Tm, np, np)); }
     GP_TRY(launch_trmv_lower(h, h->A, np, np, h->ypad, h->z));
-    GP_TRY(launch_gemv_t(h, h->A, np, np, np, h->z, h->alpha, 1));
-    (void)y;
+    GP_TRY(launch_gemv_t(h, h->A, np, np, np, h->z, h->alpha, 1, np * np, np, np));
     return GPIMHIP_OK;
 }
 
 struct IterTable { int32_t* iter; const double* bc; int T; double* hist_base; double* loss_base; };
 
-static int loss_grad_at_u(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X, const double* y, int64_t N,
+static int loss_grad_at_u(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X, int64_t x_bs, int64_t N,
                           double* u, int do_adam, AdamStep st, double* loss_out, double* grad_out,
                           double* hist_row, const IterTable* tab = nullptr) {
     const int64_t np = h->np;
-    GP_TRY(factor_at_u(h, m, X, y, N, u));
+    GP_TRY(factor_at_u(h, m, X, x_bs, N, u));
     { StageTimer t(h, 2); GP_TRY(launch_lauum(h, h->A, h->B, np, np)); }
-    GP_TRY(launch_grad_reduce(h, m, h->B, np, X, N, (int)(np / NB), h->alpha));
+    GP_TRY(launch_grad_reduce(h, m, h->B, np, X, N, (int)(np / NB), h->alpha, x_bs));
     if (tab)
         GP_TRY(launch_finalize(h, m, N, np, u, do_adam, st, nullptr, nullptr, nullptr, tab->iter, tab->bc, tab->T,
                                tab->hist_base, tab->loss_base));
@@ -497,8 +516,7 @@ int gpimhip_create(gpimhip_handle* out, int device, void* hip_stream) {
         }
     }
     int rc = GPIMHIP_OK;
-    if ((rc = dev_alloc(h, &h->theta, 1)) || (rc = dev_alloc(h, &h->adam_m, MAXP)) ||
-        (rc = dev_alloc(h, &h->adam_v, MAXP)) || (rc = dev_alloc(h, &h->scratch, 4 * MAXP)) ||
+    if ((rc = dev_alloc(h, &h->theta1, 1)) || (rc = dev_alloc(h, &h->scratch, 4 * MAXP)) ||
         (rc = dev_alloc(h, &h->info, 4))) {
         delete h;
         return rc;
@@ -513,15 +531,13 @@ int gpimhip_destroy(gpimhip_handle h) {
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
     ws_release_matrix(h);
-    dev_free(h, &h->Ks, h->ks_rows * h->ks_cols);
-    dev_free(h, &h->colpart, (h->ks_rows / NB) * h->ks_cols);
+    dev_free(h, &h->Ks, h->ks_batch * h->ks_rows * h->ks_cols);
+    dev_free(h, &h->colpart, h->ks_batch * (h->ks_rows / NB) * h->ks_cols);
     dev_free(h, &h->pred_tiles, h->pred_ntiles);
-    dev_free(h, &h->mean_tmp, h->ks_cols);
+    dev_free(h, &h->mean_tmp, h->ks_batch * h->ks_cols);
     dev_free(h, &h->keys, h->keys_cap);
     dev_free(h, &h->bc, h->bc_cap);
-    dev_free(h, &h->theta, 1);
-    dev_free(h, &h->adam_m, MAXP);
-    dev_free(h, &h->adam_v, MAXP);
+    dev_free(h, &h->theta1, 1);
     dev_free(h, &h->scratch, 4 * MAXP);
     dev_free(h, &h->info, 4);
     if (h->plan.d_tiles) hipFree(h->plan.d_tiles);
@@ -572,11 +588,13 @@ int gpimhip_kmat(gpimhip_handle h, const gpimhip_model_t* m, const double* X, in
     const bool sym = (Z == nullptr);
     const int64_t Mv = sym ? N : M;
     if (Mv < 1 || ld < Mv) return GPIMHIP_E_BADARG;
+    h->nbatch = 1;
     GP_TRY(launch_theta_raw(h, m, theta));
     // tiles are 128x128: build into a padded scratch and copy out the valid part
     const int64_t rp = pad_to(N, NB), cp = pad_to(Mv, NB);
     GP_TRY(ws_ensure_predict(h, rp, cp));
-    GP_TRY(launch_kmat(h, m, X, N, sym ? nullptr : Z, Mv, h->theta, diag_add, 0, h->Ks, cp, rp, cp, sym ? 1 : 0, 0));
+    GP_TRY(launch_kmat(h, m, X, N, sym ? nullptr : Z, Mv, h->theta1, diag_add, 0, h->Ks, cp, rp, cp, sym ? 1 : 0, 0, 0,
+                       0, 0));
     HIP_TRY(hipMemcpy2DAsync(out, (size_t)ld * sizeof(double), h->Ks, (size_t)cp * sizeof(double),
                              (size_t)Mv * sizeof(double), (size_t)N, hipMemcpyDeviceToDevice, h->stream));
     return GPIMHIP_OK;
@@ -585,6 +603,7 @@ int gpimhip_kmat(gpimhip_handle h, const gpimhip_model_t* m, const double* X, in
 int gpimhip_potrf(gpimhip_handle h, double* A, int64_t n, int64_t ld, int32_t* info) {
     if (!h || !A || n < 1 || ld < n || !info) return GPIMHIP_E_BADARG;
     HIP_TRY(hipSetDevice(h->device));
+    h->nbatch = 1;
     GP_TRY(ws_ensure(h, n));
     const int64_t np = h->np;
     HIP_TRY(hipMemsetAsync(info, 0, sizeof(int32_t), h->stream));
@@ -594,47 +613,24 @@ int gpimhip_potrf(gpimhip_handle h, double* A, int64_t n, int64_t ld, int32_t* i
     return GPIMHIP_OK;
 }
 
-int gpimhip_nll_grad(gpimhip_handle h, const gpimhip_model_t* m, const double* X, const double* y, int64_t N,
-                     const double* u, double* loss_out, double* grad_out) {
-    if (!h || !X || !y || !u || N < 1) return GPIMHIP_E_BADARG;
-    GP_TRY(check_model(m));
+static int fit_impl(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X, int64_t x_bs, const double* y,
+                    int64_t N, int B, double* u, double lr, int32_t T, double* hist_out, double* loss_out) {
     HIP_TRY(hipSetDevice(h->device));
+    h->nbatch = B;
     HIP_TRY(hipMemsetAsync(h->info, 0, sizeof(int32_t), h->stream));
-    if (use_small_path(N)) {
-        GP_TRY(launch_fit_small(h, m, X, y, (int)N, const_cast<double*>(u), nullptr, nullptr, 0, nullptr, loss_out,
-                                grad_out));
-        return finish_and_check(h);
-    }
-    GP_TRY(ws_ensure(h, N));
-    GP_TRY(launch_pad_copy(h, y, N, h->ypad, h->np));
-    AdamStep st;
-    memset(&st, 0, sizeof(st));
-    GP_TRY(loss_grad_at_u(h, m, X, y, N, const_cast<double*>(u), 0, st, loss_out, grad_out, nullptr));
-    return finish_and_check(h);
-}
-
-int gpimhip_fit_exact(gpimhip_handle h, const gpimhip_model_t* m, const double* X, const double* y, int64_t N,
-                      double* u_inout, double lr, int32_t T, double* hist_out, double* loss_out) {
-    if (!h || !X || !y || !u_inout || N < 1 || T < 0) return GPIMHIP_E_BADARG;
-    GP_TRY(check_model(m));
-    HIP_TRY(hipSetDevice(h->device));
-    const int P = 2 + m->n_ls + (m->kernel == GPIMHIP_KERNEL_RQ ? 1 : 0);
-    HIP_TRY(hipMemsetAsync(h->info, 0, sizeof(int32_t), h->stream));
-    if (use_small_path(N)) {
-        if (T == 0) return GPIMHIP_OK;
-        // fused single-launch trainer
-        GP_TRY(upload_bc_table(h, lr, T));
-        GP_TRY(launch_fit_small(h, m, X, y, (int)N, u_inout, h->bc, h->bc + T, T, hist_out, loss_out, nullptr));
-        return finish_and_check(h);
-    }
-    GP_TRY(ws_ensure(h, N));
-    HIP_TRY(hipMemsetAsync(h->adam_m, 0, MAXP * sizeof(double), h->stream));
-    HIP_TRY(hipMemsetAsync(h->adam_v, 0, MAXP * sizeof(double), h->stream));
-    GP_TRY(launch_pad_copy(h, y, N, h->ypad, h->np));
     if (T == 0) return GPIMHIP_OK;
     GP_TRY(upload_bc_table(h, lr, T));
-    HIP_TRY(hipMemsetAsync(h->info + 1, 0, sizeof(int32_t), h->stream));     // iteration counter
-    IterTable tab{h->info + 1, h->bc, T, hist_out, loss_out};
+    if (use_small_path(N)) {
+        // fused single-launch trainer, one workgroup per problem
+        GP_TRY(launch_fit_small(h, m, X, x_bs, y, (int)N, u, h->bc, h->bc + T, T, hist_out, loss_out, nullptr));
+        return finish_and_check(h);
+    }
+    GP_TRY(ws_ensure(h, N));
+    HIP_TRY(hipMemsetAsync(h->adam_m, 0, (size_t)B * MAXP * sizeof(double), h->stream));
+    HIP_TRY(hipMemsetAsync(h->adam_v, 0, (size_t)B * MAXP * sizeof(double), h->stream));
+    HIP_TRY(hipMemsetAsync(h->iter, 0, (size_t)B * sizeof(int32_t), h->stream));     // iteration counters
+    GP_TRY(launch_pad_copy(h, y, N, h->ypad, h->np));
+    IterTable tab{h->iter, h->bc, T, hist_out, loss_out};
     AdamStep st;
     st.beta1 = 0.9; st.beta2 = 0.999; st.eps = 1e-8; st.lr_over_bc1 = 0.0; st.bc2_sqrt = 1.0;
     // Every iteration enqueues the same launches (the iteration index lives on the device), so one
@@ -652,7 +648,7 @@ int gpimhip_fit_exact(gpimhip_handle h, const gpimhip_model_t* m, const double* 
         hipError_t e = hipStreamBeginCapture(h->capture_stream, hipStreamCaptureModeRelaxed);
         int rc = GPIMHIP_OK;
         if (e == hipSuccess) {
-            rc = loss_grad_at_u(h, m, X, y, N, u_inout, 1, st, nullptr, nullptr, nullptr, &tab);
+            rc = loss_grad_at_u(h, m, X, x_bs, N, u, 1, st, nullptr, nullptr, nullptr, &tab);
             e = hipStreamEndCapture(h->capture_stream, &graph);
         }
         h->stream = main_s;
@@ -668,42 +664,99 @@ int gpimhip_fit_exact(gpimhip_handle h, const gpimhip_model_t* m, const double* 
         (void)hipGetLastError();                        // capture unavailable: plain launches below
     }
     for (int t = 0; t < T; ++t)
-        GP_TRY(loss_grad_at_u(h, m, X, y, N, u_inout, 1, st, nullptr, nullptr, nullptr, &tab));
+        GP_TRY(loss_grad_at_u(h, m, X, x_bs, N, u, 1, st, nullptr, nullptr, nullptr, &tab));
     return finish_and_check(h);
+}
+
+static int predict_impl(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X, int64_t x_bs, const double* y,
+                        int64_t N, int B, const double* u, const double* Xs, int64_t M, double* mean_out,
+                        double* var_out) {
+    HIP_TRY(hipSetDevice(h->device));
+    h->nbatch = B;
+    GP_TRY(ws_ensure(h, N));
+    const int64_t np = h->np;
+    const int nb = (int)(np / NB);
+    HIP_TRY(hipMemsetAsync(h->info, 0, sizeof(int32_t), h->stream));
+    GP_TRY(launch_pad_copy(h, y, N, h->ypad, np));
+    GP_TRY(factor_at_u(h, m, X, x_bs, N, u));
+    // chunk the test points so that the K* slabs of all problems together stay <= ~1 GiB
+    int64_t mc = pad_to(M, NB);
+    const int64_t cap = std::max<int64_t>(NB, ((int64_t)1 << 27) / np / B / NB * NB);
+    mc = std::min(mc, cap);
+    GP_TRY(ws_ensure_predict(h, np, mc));
+    for (int64_t m0 = 0; m0 < M; m0 += mc) {
+        const int64_t cnt = std::min(mc, M - m0);
+        const int64_t cpad = pad_to(cnt, NB);
+        // the test grid Xs is shared by all problems of the batch (z stride 0)
+        GP_TRY(launch_kmat(h, m, X, N, Xs + m0 * m->dim, cnt, h->theta, 0.0, 0, h->Ks, mc, np, cpad, 0, 0, x_bs, 0,
+                           np * mc));
+        GP_TRY(launch_gemv_t(h, h->Ks, mc, np, cpad, h->alpha, h->mean_tmp, 0, np * mc, np, mc));
+        GP_TRY(launch_copy_slice(h, h->mean_tmp, mean_out + m0, cnt, mc, M));
+        GemmArgs g = gemm_args(h->A, np, h->Ks, mc, nullptr, 0, 1.0, 0.0, h->pred_tiles, 0);
+        g.sB = np * mc;
+        g.chunk = 64;
+        g.colpart = h->colpart;
+        g.ld_colpart = mc;
+        g.sColpart = (int64_t)nb * mc;
+        // a ragged last chunk still sweeps all column tiles of the slab (stale columns are ignored)
+        g.ntiles = (int)h->pred_ntiles;
+        { StageTimer t(h, 3); GP_TRY(launch_gemm(h, false, true, EPI_COLSUMSQ, g)); }
+        GP_TRY(launch_predict_var(h, mc, nb, m0, cnt, var_out, M));
+    }
+    return finish_and_check(h);
+}
+
+int gpimhip_nll_grad(gpimhip_handle h, const gpimhip_model_t* m, const double* X, const double* y, int64_t N,
+                     const double* u, double* loss_out, double* grad_out) {
+    if (!h || !X || !y || !u || N < 1) return GPIMHIP_E_BADARG;
+    GP_TRY(check_model(m));
+    HIP_TRY(hipSetDevice(h->device));
+    h->nbatch = 1;
+    HIP_TRY(hipMemsetAsync(h->info, 0, sizeof(int32_t), h->stream));
+    if (use_small_path(N)) {
+        GP_TRY(launch_fit_small(h, m, X, 0, y, (int)N, const_cast<double*>(u), nullptr, nullptr, 0, nullptr,
+                                loss_out, grad_out));
+        return finish_and_check(h);
+    }
+    GP_TRY(ws_ensure(h, N));
+    GP_TRY(launch_pad_copy(h, y, N, h->ypad, h->np));
+    AdamStep st;
+    memset(&st, 0, sizeof(st));
+    GP_TRY(loss_grad_at_u(h, m, X, 0, N, const_cast<double*>(u), 0, st, loss_out, grad_out, nullptr));
+    return finish_and_check(h);
+}
+
+int gpimhip_fit_exact(gpimhip_handle h, const gpimhip_model_t* m, const double* X, const double* y, int64_t N,
+                      double* u_inout, double lr, int32_t T, double* hist_out, double* loss_out) {
+    if (!h || !X || !y || !u_inout || N < 1 || T < 0) return GPIMHIP_E_BADARG;
+    GP_TRY(check_model(m));
+    return fit_impl(h, m, X, 0, y, N, 1, u_inout, lr, T, hist_out, loss_out);
 }
 
 int gpimhip_predict_exact(gpimhip_handle h, const gpimhip_model_t* m, const double* X, const double* y, int64_t N,
                           const double* u, const double* Xs, int64_t M, double* mean_out, double* var_out) {
     if (!h || !X || !y || !u || !Xs || M < 1 || N < 1 || !mean_out || !var_out) return GPIMHIP_E_BADARG;
     GP_TRY(check_model(m));
-    HIP_TRY(hipSetDevice(h->device));
-    GP_TRY(ws_ensure(h, N));
-    const int64_t np = h->np;
-    const int nb = (int)(np / NB);
-    HIP_TRY(hipMemsetAsync(h->info, 0, sizeof(int32_t), h->stream));
-    GP_TRY(launch_pad_copy(h, y, N, h->ypad, np));
-    GP_TRY(factor_at_u(h, m, X, y, N, u));
-    // chunk the test points so that the K* slab stays <= ~1 GiB
-    int64_t mc = pad_to(M, NB);
-    const int64_t cap = std::max<int64_t>(NB, ((int64_t)1 << 27) / np / NB * NB);
-    mc = std::min(mc, cap);
-    GP_TRY(ws_ensure_predict(h, np, mc));
-    for (int64_t m0 = 0; m0 < M; m0 += mc) {
-        const int64_t cnt = std::min(mc, M - m0);
-        const int64_t cpad = pad_to(cnt, NB);
-        GP_TRY(launch_kmat(h, m, X, N, Xs + m0 * m->dim, cnt, h->theta, 0.0, 0, h->Ks, mc, np, cpad, 0, 0));
-        GP_TRY(launch_gemv_t(h, h->Ks, mc, np, cpad, h->alpha, h->mean_tmp, 0));
-        GP_TRY(launch_copy_slice(h, h->mean_tmp, mean_out + m0, cnt));
-        GemmArgs g = gemm_args(h->A, np, h->Ks, mc, nullptr, 0, 1.0, 0.0, h->pred_tiles, 0);
-        g.chunk = 64;
-        g.colpart = h->colpart;
-        g.ld_colpart = mc;
-        // a ragged last chunk still sweeps all column tiles of the slab (stale columns are ignored)
-        g.ntiles = (int)h->pred_ntiles;
-        { StageTimer t(h, 3); GP_TRY(launch_gemm(h, false, true, EPI_COLSUMSQ, g)); }
-        GP_TRY(launch_predict_var(h, mc, nb, m0, cnt, var_out));
-    }
-    return finish_and_check(h);
+    return predict_impl(h, m, X, 0, y, N, 1, u, Xs, M, mean_out, var_out);
+}
+
+int gpimhip_fit_exact_batched(gpimhip_handle h, const gpimhip_model_t* m, const double* X, int64_t x_stride,
+                              const double* y, int64_t N, int32_t B, double* u_inout, double lr, int32_t T,
+                              double* hist_out, double* loss_out) {
+    if (!h || !X || !y || !u_inout || N < 1 || T < 0 || B < 1 || B > 65535 ||
+        (x_stride != 0 && x_stride < N * (m ? m->dim : 1)))
+        return GPIMHIP_E_BADARG;
+    GP_TRY(check_model(m));
+    return fit_impl(h, m, X, x_stride, y, N, B, u_inout, lr, T, hist_out, loss_out);
+}
+
+int gpimhip_predict_exact_batched(gpimhip_handle h, const gpimhip_model_t* m, const double* X, int64_t x_stride,
+                                  const double* y, int64_t N, int32_t B, const double* u, const double* Xs,
+                                  int64_t M, double* mean_out, double* var_out) {
+    if (!h || !X || !y || !u || !Xs || M < 1 || N < 1 || !mean_out || !var_out || B < 1 || B > 65535)
+        return GPIMHIP_E_BADARG;
+    GP_TRY(check_model(m));
+    return predict_impl(h, m, X, x_stride, y, N, B, u, Xs, M, mean_out, var_out);
 }
 
 int gpimhip_acq(gpimhip_handle h, int32_t kind, const double* mean, const double* sd, int64_t M, double p0,

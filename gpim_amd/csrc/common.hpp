@@ -82,6 +82,8 @@ struct gpimhip_ctx {
     std::vector<hipEvent_t> ev_pool;      // cross-stream ordering events (no timing)
     // workspace (sized for np = padded N)
     int64_t np = 0;                 // padded matrix order the buffers are sized for
+    int nbatch = 1;                 // problems processed in lock-step by the current call (grid.y)
+    int ws_batch = 0;               // number of problems the workspace is sized for
     double* A = nullptr;            // np x np : K -> L -> L^-1
     double* B = nullptr;            // np x np : K^-1 (lower)
     double* Tm = nullptr;           // np x np : trtri temporary
@@ -93,13 +95,15 @@ struct gpimhip_ctx {
     double* logdet_part = nullptr;  // nb
     double* grad_part = nullptr;    // ntiles_lower x 8
     double* quad_part = nullptr;    // nb
-    ThetaDev* theta = nullptr;
+    ThetaDev* theta = nullptr;      // [ws_batch]
+    ThetaDev* theta1 = nullptr;     // single struct for the operator-level gpimhip_kmat
+    int32_t* iter = nullptr;        // [ws_batch] device-side iteration counters
     double* adam_m = nullptr;       // MAXP
     double* adam_v = nullptr;       // MAXP
     double* scratch = nullptr;      // small: loss, grad (MAXP+1)
     int32_t* info = nullptr;        // potrf status word
     // prediction workspace
-    int64_t ks_rows = 0, ks_cols = 0;
+    int64_t ks_rows = 0, ks_cols = 0, ks_batch = 0;
     double* Ks = nullptr;           // np x mc chunk of K(X, X*)
     double* colpart = nullptr;      // nb x mc partial column sums of squares
     double* mean_tmp = nullptr;     // mc
@@ -136,5 +140,6 @@ struct GemmArgs {
     const TileDesc* tiles; int ntiles;
     int chunk;                             // XCD dealing: 0 = contiguous slices, >0 = round-robin chunks
     double* colpart; int64_t ld_colpart;   // EPI_COLSUMSQ: colpart[ci*ld + cj*128 + col]
+    int64_t sA, sB, sC, sColpart;          // per-problem (blockIdx.y) strides in elements
 };
 int launch_gemm(gpimhip_ctx* h, bool a_km, bool b_km, int epi, const GemmArgs& g);

@@ -17,11 +17,14 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 // u -> theta   (torch.distributions transform_to(interval) = Affine o Sigmoid with clipping;
 //               transform_to(positive) = exp.  SURVEY App. A.2)
 // ------------------------------------------------------------------------------------------
-__global__ void theta_kernel(gpimhip_model_t m, const double* __restrict__ u, ThetaDev* __restrict__ out) {
+// Batch convention of this file: blockIdx.y = problem index b; every per-problem pointer advances by
+// b times the stride passed next to it (workspace buffers of the B problems are stacked).
+__global__ void theta_kernel(gpimhip_model_t m, const double* __restrict__ u, int ustride,
+                             ThetaDev* __restrict__ out) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         ThetaDev t;
-        theta_from_u(m, u, t);
-        *out = t;
+        theta_from_u(m, u + (int64_t)blockIdx.y * ustride, t);
+        out[blockIdx.y] = t;
     }
 }
 
@@ -44,12 +47,13 @@ __global__ void theta_raw_kernel(gpimhip_model_t m, const double* __restrict__ r
 }
 
 int launch_theta(gpimhip_ctx* h, const gpimhip_model_t* m, const double* u) {
-    hipLaunchKernelGGL(theta_kernel, dim3(1), dim3(64), 0, h->stream, *m, u, h->theta);
+    const int P = 2 + m->n_ls + (m->kernel == GPIMHIP_KERNEL_RQ ? 1 : 0);
+    hipLaunchKernelGGL(theta_kernel, dim3(1, h->nbatch), dim3(64), 0, h->stream, *m, u, P, h->theta);
     HIP_TRY(hipGetLastError());
     return GPIMHIP_OK;
 }
 int launch_theta_raw(gpimhip_ctx* h, const gpimhip_model_t* m, const double* raw) {
-    hipLaunchKernelGGL(theta_raw_kernel, dim3(1), dim3(64), 0, h->stream, *m, raw, h->theta);
+    hipLaunchKernelGGL(theta_raw_kernel, dim3(1), dim3(64), 0, h->stream, *m, raw, h->theta1);
     HIP_TRY(hipGetLastError());
     return GPIMHIP_OK;
 }
@@ -71,10 +75,15 @@ __global__ __launch_bounds__(256) void kmat_kernel(const double* __restrict__ X,
                                                    const double* __restrict__ Z, int64_t M, int d,
                                                    const ThetaDev* __restrict__ th, double diag_add,
                                                    int use_theta_diag, double* __restrict__ out, int64_t ld,
-                                                   int ntc, int sym, int lower_only) {
+                                                   int ntc, int sym, int lower_only, int64_t x_bs, int64_t z_bs,
+                                                   int64_t out_bs) {
     __shared__ double xa[128][5];
     __shared__ double xz[128][5];
     const int tid = threadIdx.x;
+    X += blockIdx.y * x_bs;
+    Z += blockIdx.y * z_bs;
+    th += blockIdx.y;
+    out += blockIdx.y * out_bs;
     int ci, cj;
     if (lower_only) lower_tile_from_linear(blockIdx.x, ci, cj);
     else { ci = blockIdx.x / ntc; cj = blockIdx.x % ntc; }
@@ -128,15 +137,17 @@ __global__ __launch_bounds__(256) void kmat_kernel(const double* __restrict__ X,
 
 int launch_kmat(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X, int64_t N, const double* Z,
                 int64_t M, const ThetaDev* theta, double diag_add, int use_theta_diag, double* out,
-                int64_t ld, int64_t rows_pad, int64_t cols_pad, int sym, int lower_only) {
+                int64_t ld, int64_t rows_pad, int64_t cols_pad, int sym, int lower_only, int64_t x_bs,
+                int64_t z_bs, int64_t out_bs) {
     const int ntr = (int)(rows_pad / 128), ntc = (int)(cols_pad / 128);
     const int64_t nblk = lower_only ? (int64_t)ntr * (ntr + 1) / 2 : (int64_t)ntr * ntc;
     if (nblk <= 0) return GPIMHIP_OK;
     const double* Zp = Z ? Z : X;
-    dim3 grid((unsigned)nblk), block(256);
+    dim3 grid((unsigned)nblk, h->nbatch), block(256);
+    if (!Z) z_bs = x_bs;
 #define KM_LAUNCH(KIND)                                                                              \
     hipLaunchKernelGGL((kmat_kernel<KIND>), grid, block, 0, h->stream, X, N, Zp, M, m->dim, theta,    \
-                       diag_add, use_theta_diag, out, ld, ntc, sym, lower_only)
+                       diag_add, use_theta_diag, out, ld, ntc, sym, lower_only, x_bs, z_bs, out_bs)
     switch (m->kernel) {
         case GPIMHIP_KERNEL_RBF: KM_LAUNCH(GPIMHIP_KERNEL_RBF); break;
         case GPIMHIP_KERNEL_MATERN52: KM_LAUNCH(GPIMHIP_KERNEL_MATERN52); break;
@@ -153,18 +164,24 @@ int launch_kmat(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X, int64
 // ------------------------------------------------------------------------------------------
 __global__ void pad_copy_kernel(const double* __restrict__ src, int64_t n, double* __restrict__ dst, int64_t np) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    src += blockIdx.y * n;
+    dst += blockIdx.y * np;
     if (i < np) dst[i] = (i < n) ? src[i] : 0.0;
 }
 int launch_pad_copy(gpimhip_ctx* h, const double* src, int64_t n, double* dst, int64_t np) {
-    hipLaunchKernelGGL(pad_copy_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, h->stream, src, n, dst, np);
+    hipLaunchKernelGGL(pad_copy_kernel, dim3((unsigned)((np + 255) / 256), h->nbatch), dim3(256), 0, h->stream, src,
+                       n, dst, np);
     HIP_TRY(hipGetLastError());
     return GPIMHIP_OK;
 }
 
 // A[k,k] <- dinv[k] for every diagonal block (leaves of the triangular inversion)
 __global__ __launch_bounds__(256) void diag_inv_copy_kernel(double* __restrict__ A, int64_t ld,
-                                                            const double* __restrict__ dinv) {
+                                                            const double* __restrict__ dinv, int64_t a_bs,
+                                                            int64_t d_bs) {
     const int k = blockIdx.x;
+    A += blockIdx.y * a_bs;
+    dinv += blockIdx.y * d_bs;
     double* dst = A + ((int64_t)k * NB) * ld + (int64_t)k * NB;
     const double* src = dinv + (int64_t)k * NB * NB;
     for (int e = threadIdx.x; e < NB * NB / 2; e += 256) {
@@ -173,7 +190,8 @@ __global__ __launch_bounds__(256) void diag_inv_copy_kernel(double* __restrict__
     }
 }
 int launch_diag_inv_copy(gpimhip_ctx* h, double* A, int64_t ld, int nb) {
-    hipLaunchKernelGGL(diag_inv_copy_kernel, dim3(nb), dim3(256), 0, h->stream, A, ld, h->dinv);
+    hipLaunchKernelGGL(diag_inv_copy_kernel, dim3(nb, h->nbatch), dim3(256), 0, h->stream, A, ld, h->dinv,
+                       (int64_t)nb * NB * ld, (int64_t)nb * NB * NB);
     HIP_TRY(hipGetLastError());
     return GPIMHIP_OK;
 }
@@ -227,6 +245,9 @@ __global__ __launch_bounds__(256) void trmv_lower_kernel(const double* __restric
                                                          const double* __restrict__ y, double* __restrict__ z) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t i = (int64_t)blockIdx.x * 4 + wave;
+    L += blockIdx.y * np * ld;
+    y += blockIdx.y * np;
+    z += blockIdx.y * np;
     if (i >= np) return;
     const int64_t jend = (i / NB + 1) * NB;
     const double* row = L + i * ld;
@@ -245,8 +266,11 @@ __global__ __launch_bounds__(256) void trmv_lower_kernel(const double* __restric
 // diagonal block of the column (A lower triangular), else at row 0.
 __global__ __launch_bounds__(256) void gemv_t_kernel(const double* __restrict__ A, int64_t ld, int64_t nrows,
                                                      const double* __restrict__ x, double* __restrict__ out,
-                                                     int tri) {
+                                                     int tri, int64_t a_bs, int64_t x_bs, int64_t o_bs) {
     __shared__ double red[4][64];
+    A += blockIdx.y * a_bs;
+    x += blockIdx.y * x_bs;
+    out += blockIdx.y * o_bs;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t j = (int64_t)blockIdx.x * 64 + lane;
     const int64_t i0 = tri ? ((int64_t)blockIdx.x * 64 / NB) * NB : 0;
@@ -258,13 +282,15 @@ __global__ __launch_bounds__(256) void gemv_t_kernel(const double* __restrict__ 
 }
 
 int launch_trmv_lower(gpimhip_ctx* h, const double* L, int64_t ld, int64_t np, const double* y, double* z) {
-    hipLaunchKernelGGL(trmv_lower_kernel, dim3((unsigned)((np + 3) / 4)), dim3(256), 0, h->stream, L, ld, np, y, z);
+    hipLaunchKernelGGL(trmv_lower_kernel, dim3((unsigned)((np + 3) / 4), h->nbatch), dim3(256), 0, h->stream, L, ld,
+                       np, y, z);
     HIP_TRY(hipGetLastError());
     return GPIMHIP_OK;
 }
 int launch_gemv_t(gpimhip_ctx* h, const double* A, int64_t ld, int64_t nrows, int64_t ncols, const double* x,
-                  double* out, int tri) {
-    hipLaunchKernelGGL(gemv_t_kernel, dim3((unsigned)(ncols / 64)), dim3(256), 0, h->stream, A, ld, nrows, x, out, tri);
+                  double* out, int tri, int64_t a_bs, int64_t x_bs, int64_t o_bs) {
+    hipLaunchKernelGGL(gemv_t_kernel, dim3((unsigned)(ncols / 64), h->nbatch), dim3(256), 0, h->stream, A, ld, nrows,
+                       x, out, tri, a_bs, x_bs, o_bs);
     HIP_TRY(hipGetLastError());
     return GPIMHIP_OK;
 }
@@ -282,12 +308,17 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const double* __restri
                                                           const double* __restrict__ X, int64_t N, int d,
                                                           const double* __restrict__ alpha,
                                                           const ThetaDev* __restrict__ th,
-                                                          double* __restrict__ part) {
+                                                          double* __restrict__ part, int64_t x_bs, int64_t np) {
     __shared__ double xa[128][5];
     __shared__ double xz[128][5];
     __shared__ double al_r[128], al_c[128];
     __shared__ double red[4][8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    Kinv += blockIdx.y * np * ld;
+    X += blockIdx.y * x_bs;
+    alpha += blockIdx.y * np;
+    th += blockIdx.y;
+    part += (int64_t)blockIdx.y * gridDim.x * 8;
     int ci, cj;
     lower_tile_from_linear(blockIdx.x, ci, cj);
     const ThetaDev t = *th;
@@ -356,12 +387,12 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const double* __restri
 }
 
 int launch_grad_reduce(gpimhip_ctx* h, const gpimhip_model_t* m, const double* Kinv, int64_t ld,
-                       const double* X, int64_t N, int nb, const double* alpha) {
+                       const double* X, int64_t N, int nb, const double* alpha, int64_t x_bs) {
     const int ntile = nb * (nb + 1) / 2;
-    dim3 grid(ntile), block(256);
+    dim3 grid(ntile, h->nbatch), block(256);
 #define GR_LAUNCH(KIND)                                                                                   \
     hipLaunchKernelGGL((grad_reduce_kernel<KIND>), grid, block, 0, h->stream, Kinv, ld, X, N, m->dim, alpha, \
-                       h->theta, h->grad_part)
+                       h->theta, h->grad_part, x_bs, (int64_t)nb * NB)
     switch (m->kernel) {
         case GPIMHIP_KERNEL_RBF: GR_LAUNCH(GPIMHIP_KERNEL_RBF); break;
         case GPIMHIP_KERNEL_MATERN52: GR_LAUNCH(GPIMHIP_KERNEL_MATERN52); break;
@@ -413,6 +444,22 @@ __global__ __launch_bounds__(256) void finalize_kernel(gpimhip_model_t m, int64_
     __shared__ double red[256];
     __shared__ double S[8];
     const int tid = threadIdx.x;
+    {
+        const int64_t b = blockIdx.y;
+        const int P = 2 + m.n_ls + (m.kernel == GPIMHIP_KERNEL_RQ ? 1 : 0);
+        grad_part += b * ntile * 8;
+        z += b * np;
+        logdet_part += b * nb;
+        th += b;
+        u += b * P;
+        adam_m += b * MAXP;
+        adam_v += b * MAXP;
+        if (fi.iter) {
+            fi.iter += b;
+            if (fi.hist_base) fi.hist_base += b * fi.T * P;
+            if (fi.loss_base) fi.loss_base += b * fi.T;
+        }
+    }
     for (int k = 0; k < 7; ++k) {
         double v = 0.0;
         for (int q = tid; q < ntile; q += 256) v += grad_part[(int64_t)q * 8 + k];
@@ -444,7 +491,7 @@ int launch_finalize(gpimhip_ctx* h, const gpimhip_model_t* m, int64_t N, int64_t
                     const double* bc, int T, double* hist_base, double* loss_base) {
     const int nb = (int)(np / NB);
     FinalizeIter fi{iter, bc, T, hist_base, loss_base};
-    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, h->stream, *m, N, np, nb, nb * (nb + 1) / 2,
+    hipLaunchKernelGGL(finalize_kernel, dim3(1, h->nbatch), dim3(256), 0, h->stream, *m, N, np, nb, nb * (nb + 1) / 2,
                        h->grad_part, h->z, h->logdet_part, h->theta, u, h->adam_m, h->adam_v, do_adam, st,
                        loss_out, grad_out, hist_row, fi);
     HIP_TRY(hipGetLastError());
@@ -455,26 +502,32 @@ int launch_finalize(gpimhip_ctx* h, const gpimhip_model_t* m, int64_t N, int64_t
 // prediction epilogue: var_j = clamp(s2 - sum_ci colpart[ci][j], 0) + noise
 // ------------------------------------------------------------------------------------------
 __global__ void predict_var_kernel(const double* __restrict__ colpart, int64_t ldp, int nb, int64_t m0,
-                                   int64_t mcount, const ThetaDev* __restrict__ th, double* __restrict__ var_out) {
+                                   int64_t mcount, const ThetaDev* __restrict__ th, double* __restrict__ var_out,
+                                   int64_t M) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    colpart += blockIdx.y * nb * ldp;
+    th += blockIdx.y;
+    var_out += blockIdx.y * M;
     if (j >= mcount) return;
     double q = 0.0;
     for (int ci = 0; ci < nb; ++ci) q += colpart[(int64_t)ci * ldp + j];
     const double v = clamp0_nan(th->var - q);
     var_out[m0 + j] = v + th->noise;
 }
-__global__ void copy_slice_kernel(const double* __restrict__ src, double* __restrict__ dst, int64_t n) {
+__global__ void copy_slice_kernel(const double* __restrict__ src, double* __restrict__ dst, int64_t n,
+                                  int64_t s_bs, int64_t d_bs) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < n) dst[j] = src[j];
+    if (j < n) dst[blockIdx.y * d_bs + j] = src[blockIdx.y * s_bs + j];
 }
-int launch_predict_var(gpimhip_ctx* h, int64_t ldp, int nb, int64_t m0, int64_t mcount, double* var_out) {
-    hipLaunchKernelGGL(predict_var_kernel, dim3((unsigned)((mcount + 255) / 256)), dim3(256), 0, h->stream,
-                       h->colpart, ldp, nb, m0, mcount, h->theta, var_out);
+int launch_predict_var(gpimhip_ctx* h, int64_t ldp, int nb, int64_t m0, int64_t mcount, double* var_out, int64_t M) {
+    hipLaunchKernelGGL(predict_var_kernel, dim3((unsigned)((mcount + 255) / 256), h->nbatch), dim3(256), 0, h->stream,
+                       h->colpart, ldp, nb, m0, mcount, h->theta, var_out, M);
     HIP_TRY(hipGetLastError());
     return GPIMHIP_OK;
 }
-int launch_copy_slice(gpimhip_ctx* h, const double* src, double* dst, int64_t n) {
-    hipLaunchKernelGGL(copy_slice_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, src, dst, n);
+int launch_copy_slice(gpimhip_ctx* h, const double* src, double* dst, int64_t n, int64_t s_bs, int64_t d_bs) {
+    hipLaunchKernelGGL(copy_slice_kernel, dim3((unsigned)((n + 255) / 256), h->nbatch), dim3(256), 0, h->stream, src,
+                       dst, n, s_bs, d_bs);
     HIP_TRY(hipGetLastError());
     return GPIMHIP_OK;
 }

@@ -98,6 +98,11 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_tiles_kernel(GemmArgs g) {
     }
     const TileDesc t = g.tiles[p];
     const int nsteps = (t.kb1 - t.kb0) * (NB / GEMM_BK);
+    // batch: blockIdx.y selects the problem; operands advance by their per-problem strides
+    g.A += blockIdx.y * g.sA;
+    g.B += blockIdx.y * g.sB;
+    if (g.C) g.C += blockIdx.y * g.sC;
+    if (g.colpart) g.colpart += blockIdx.y * g.sColpart;
 
     // operand origins (element units)
     const int64_t a_m0 = (int64_t)(t.ci + (A_KM ? g.a_coff : g.a_roff)) * NB;
@@ -192,10 +197,10 @@ template <bool A_KM, bool B_KM, int EPI>
 static int launch_one(gpimhip_ctx* h, const GemmArgs& g) {
     if (g.ntiles <= 0) return GPIMHIP_OK;
     // at most one tile per CU: use the 8-wave workgroup so every SIMD still holds two MFMA waves
-    if (g.ntiles <= 256)
-        hipLaunchKernelGGL((gemm_tiles_kernel<A_KM, B_KM, EPI, 8>), dim3(g.ntiles), dim3(512), 0, h->stream, g);
+    if ((int64_t)g.ntiles * h->nbatch <= 256)
+        hipLaunchKernelGGL((gemm_tiles_kernel<A_KM, B_KM, EPI, 8>), dim3(g.ntiles, h->nbatch), dim3(512), 0, h->stream, g);
     else
-        hipLaunchKernelGGL((gemm_tiles_kernel<A_KM, B_KM, EPI, 4>), dim3(g.ntiles), dim3(256), 0, h->stream, g);
+        hipLaunchKernelGGL((gemm_tiles_kernel<A_KM, B_KM, EPI, 4>), dim3(g.ntiles, h->nbatch), dim3(256), 0, h->stream, g);
     HIP_TRY(hipGetLastError());
     return GPIMHIP_OK;
 }

@@ -31,9 +31,12 @@
 __global__ __launch_bounds__(NTH, 1) void potf2_kernel(double* __restrict__ A, int64_t ld, int kblk,
                                                        double* __restrict__ linv16_all,
                                                        double* __restrict__ logdet_out,
-                                                       int32_t* __restrict__ info PROF_ARG) {
+                                                       int32_t* __restrict__ info, int nb PROF_ARG) {
     __shared__ __attribute__((aligned(16))) double D[NB * LDD];
     __shared__ double invd[NB];
+    A += (int64_t)blockIdx.y * nb * NB * ld;
+    linv16_all += (int64_t)blockIdx.y * nb * 2048;
+    logdet_out += (int64_t)blockIdx.y * nb;
     __shared__ double red[128];
     __shared__ int s_bad;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -75,10 +78,13 @@ __global__ __launch_bounds__(NTH, 1) void potf2_kernel(double* __restrict__ A, i
 // the diagonal), from L (in A) and the 16x16 diagonal inverses.
 __global__ __launch_bounds__(NTH, 1) void inv128_kernel(const double* __restrict__ A, int64_t ld, int kblk0,
                                                         const double* __restrict__ linv16_all,
-                                                        double* __restrict__ dinv_all) {
+                                                        double* __restrict__ dinv_all, int nb) {
     __shared__ __attribute__((aligned(16))) double D[NB * LDD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kblk = kblk0 + blockIdx.x;
+    A += (int64_t)blockIdx.y * nb * NB * ld;
+    linv16_all += (int64_t)blockIdx.y * nb * 2048;
+    dinv_all += (int64_t)blockIdx.y * nb * NB * NB;
     const double* Ablk = A + ((int64_t)kblk * NB) * ld + (int64_t)kblk * NB;
     load_block(D, Ablk, ld, tid);
     __syncthreads();
@@ -101,8 +107,10 @@ __global__ __launch_bounds__(NTH, 1) void inv128_kernel(const double* __restrict
 
 #ifndef POTF2_PROFILE
 int launch_potf2(gpimhip_ctx* h, double* A, int64_t ld, int kblk, int32_t* info) {
-    hipLaunchKernelGGL(potf2_kernel, dim3(1), dim3(NTH), 0, h->stream, A, ld, kblk, h->linv16, h->logdet_part, info);
-    hipLaunchKernelGGL(inv128_kernel, dim3(1), dim3(NTH), 0, h->stream, A, ld, kblk, h->linv16, h->dinv);
+    const int nb = (int)(h->np / NB);
+    hipLaunchKernelGGL(potf2_kernel, dim3(1, h->nbatch), dim3(NTH), 0, h->stream, A, ld, kblk, h->linv16,
+                       h->logdet_part, info, nb);
+    hipLaunchKernelGGL(inv128_kernel, dim3(1, h->nbatch), dim3(NTH), 0, h->stream, A, ld, kblk, h->linv16, h->dinv, nb);
     HIP_TRY(hipGetLastError());
     return GPIMHIP_OK;
 }

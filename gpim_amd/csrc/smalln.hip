@@ -16,6 +16,7 @@
 struct SmallFitArgs {
     gpimhip_model_t m;
     const double* X;       // N x d
+    int64_t x_bs;          // per-problem stride of X (0: shared)
     const double* y;       // N
     int N, T;
     double* u;             // P, in/out
@@ -41,6 +42,14 @@ __global__ __launch_bounds__(NTH, 1) void fit_small_kernel(SmallFitArgs a) {
     const int N = a.N, d = a.m.dim;
     const int npan = (N + 15) / 16, ns = npan * 16;
     const int P = 2 + a.m.n_ls + (KIND == GPIMHIP_KERNEL_RQ ? 1 : 0);
+    {   // one workgroup per problem of the batch
+        const int64_t b = blockIdx.x;
+        a.X += b * a.x_bs;
+        a.y += b * N;
+        a.u += b * P;
+        if (a.hist) a.hist += b * a.T * P;
+        if (a.loss) a.loss += b * (a.T > 0 ? a.T : 1);
+    }
 
     if (tid < MAXP) {
         su[tid] = (tid < P) ? a.u[tid] : 0.0;
@@ -198,20 +207,20 @@ __global__ __launch_bounds__(NTH, 1) void fit_small_kernel(SmallFitArgs a) {
     if (tid == 0 && s_bad != 0 && *a.info == 0) *a.info = s_bad;
 }
 
-int launch_fit_small(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X, const double* y, int N, double* u,
-                     const double* lr_over_bc1, const double* bc2_sqrt, int T, double* hist, double* loss,
-                     double* grad) {
+int launch_fit_small(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X, int64_t x_bs, const double* y,
+                     int N, double* u, const double* lr_over_bc1, const double* bc2_sqrt, int T, double* hist,
+                     double* loss, double* grad) {
     SmallFitArgs a;
-    a.m = *m; a.X = X; a.y = y; a.N = N; a.T = T; a.u = u;
+    a.m = *m; a.X = X; a.x_bs = x_bs; a.y = y; a.N = N; a.T = T; a.u = u;
     a.lr_over_bc1 = lr_over_bc1; a.bc2_sqrt = bc2_sqrt;
     a.hist = hist; a.loss = loss; a.grad = grad; a.info = h->info;
     switch (m->kernel) {
         case GPIMHIP_KERNEL_RBF:
-            hipLaunchKernelGGL((fit_small_kernel<GPIMHIP_KERNEL_RBF>), dim3(1), dim3(NTH), 0, h->stream, a); break;
+            hipLaunchKernelGGL((fit_small_kernel<GPIMHIP_KERNEL_RBF>), dim3(h->nbatch), dim3(NTH), 0, h->stream, a); break;
         case GPIMHIP_KERNEL_MATERN52:
-            hipLaunchKernelGGL((fit_small_kernel<GPIMHIP_KERNEL_MATERN52>), dim3(1), dim3(NTH), 0, h->stream, a); break;
+            hipLaunchKernelGGL((fit_small_kernel<GPIMHIP_KERNEL_MATERN52>), dim3(h->nbatch), dim3(NTH), 0, h->stream, a); break;
         case GPIMHIP_KERNEL_RQ:
-            hipLaunchKernelGGL((fit_small_kernel<GPIMHIP_KERNEL_RQ>), dim3(1), dim3(NTH), 0, h->stream, a); break;
+            hipLaunchKernelGGL((fit_small_kernel<GPIMHIP_KERNEL_RQ>), dim3(h->nbatch), dim3(NTH), 0, h->stream, a); break;
         default: gpim_set_error("unknown kernel kind"); return GPIMHIP_E_BADARG;
     }
     HIP_TRY(hipGetLastError());

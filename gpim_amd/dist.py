@@ -50,7 +50,7 @@ def shard_units(n_units, rank=None, world_size=None):
 
 def gather_to_root(local, n_units, unit_shape, device=None, dtype=torch.float64):
     """local: {unit index: tensor of shape unit_shape}.  Returns on rank 0 a tensor
-    (n_units, *unit_shape) with every unit in place (None on other ranks).  One gather of a
+    (n_units, *unit_shape) with every unit in place (None on other ranks).  One collective of a
     fixed-size slab per rank; ranks owning fewer units pad with NaN."""
     rank, ws = world()
     per = (n_units + ws - 1) // ws
@@ -60,11 +60,12 @@ def gather_to_root(local, n_units, unit_shape, device=None, dtype=torch.float64)
     for slot, idx in enumerate(shard_units(n_units, rank, ws)):
         slab[slot] = local[idx].to(device=device, dtype=dtype)
     if ws == 1:
-        out = slab
         parts = [slab]
     else:
-        parts = [torch.empty_like(slab) for _ in range(ws)] if rank == 0 else None
-        dist.gather(slab, parts, dst=0)
+        # all_gather (the most basic RCCL collective) rather than gather: the slabs are small and every
+        # backend implements it; only rank 0 assembles the result
+        parts = [torch.empty_like(slab) for _ in range(ws)]
+        dist.all_gather(parts, slab)
         if rank != 0:
             return None
     full = torch.empty((n_units,) + tuple(unit_shape), dtype=dtype, device=device)
@@ -104,41 +105,41 @@ def run_units(units, unit_fn, out_shape, device=None, concurrency=1):
     return full[:, 0], full[:, 1]
 
 
-def reconstruct_slices(cube, axis=-1, concurrency=8, return_hyperparams=False, **recon_kwargs):
+def reconstruct_slices(cube, axis=-1, batch=16, return_hyperparams=False, **recon_kwargs):
     """Independent 2D GP reconstruction of every slice of a 3D cube along `axis` (config C3 of
-    SURVEY 8(d)): slices are sharded over the ranks, and on each GPU `concurrency` slices are in
-    flight at a time, each on its own HIP stream (a single ~1000-point fit is latency-bound and
-    leaves most of the chip idle).  Returns (mean, sd) cubes on rank 0 (None elsewhere)."""
-    import threading
+    SURVEY 8(d)).  Slices are sharded over the ranks; on each GPU the owned slices with the same
+    number of observations advance in lock-step, `batch` at a time, through the batched engine
+    (gpim_amd.batch) -- a single ~1000-point fit is latency-bound and leaves most of the chip idle.
+    Per-slice results are those of ``reconstructor(X_slice, R_slice, X_full, **recon_kwargs).run()``.
+    Returns (mean, sd) cubes on rank 0 (None elsewhere)."""
     from . import gprutils
-    from .gpr import reconstructor
+    from .batch import fit_predict_batch
     cube = np.moveaxis(np.asarray(cube), axis, 0)
-    units = [cube[i] for i in range(cube.shape[0])]
+    nunits = cube.shape[0]
+    rank, ws = world()
     dev = torch.device("cuda", torch.cuda.current_device())
-    local = threading.local()
-    hyper = {}
-
-    def fit(R):
-        if not hasattr(local, "stream"):
-            torch.cuda.set_device(dev)
-            local.stream = torch.cuda.Stream(device=dev)
-        with torch.cuda.stream(local.stream):
-            X, Xf = gprutils.get_sparse_grid(R), gprutils.get_full_grid(R)
-            rec = reconstructor(X, R, Xf, **recon_kwargs)
-            rec.train()
-            rec.predict()
-            mean, sd = rec._last_pred
-            local.stream.synchronize()
-            hyper[id(R)] = rec.hyperparams
-        return mean, sd
-
-    res = run_units(units, fit, cube.shape[1:], device=dev, concurrency=concurrency)
-    if res is None:
+    owned = shard_units(nunits, rank, ws)
+    Xf = gprutils.get_full_grid(cube[0])
+    by_n = {}
+    for i in owned:
+        by_n.setdefault(int(np.count_nonzero(~np.isnan(cube[i]))), []).append(i)
+    mine, hyper = {}, {}
+    recon_kwargs = dict(recon_kwargs)
+    recon_kwargs.pop("verbose", None)
+    for n_obs, idxs in sorted(by_n.items()):
+        for s in range(0, len(idxs), batch):
+            grp = idxs[s:s + batch]
+            Xs = [gprutils.get_sparse_grid(cube[i]) for i in grp]
+            mean, sd, hist = fit_predict_batch(Xs, [cube[i] for i in grp], Xf, **recon_kwargs)
+            for k, i in enumerate(grp):
+                mine[i] = torch.stack([mean[k], sd[k]])
+                hyper[i] = hist[k].cpu().numpy()
+    full = gather_to_root(mine, nunits, (2,) + tuple(cube.shape[1:]), device=dev)
+    if full is None:
         return None
-    mean, sd = res
-    out = (np.moveaxis(mean.cpu().numpy(), 0, axis), np.moveaxis(sd.cpu().numpy(), 0, axis))
+    out = (np.moveaxis(full[:, 0].cpu().numpy(), 0, axis), np.moveaxis(full[:, 1].cpu().numpy(), 0, axis))
     if return_hyperparams:
-        return out + ([hyper.get(id(u)) for u in units],)
+        return out + ([hyper.get(i) for i in range(nunits)],)
     return out
 
 

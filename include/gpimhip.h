@@ -128,6 +128,23 @@ int gpimhip_predict_exact(gpimhip_handle h, const gpimhip_model_t* m,
                           const double* u, const double* Xs, int64_t M,
                           double* mean_out, double* var_out);
 
+/* Batched forms: B independent problems with the SAME N (and the same model description), advanced in
+ * lock-step by every launch (grid.y = problem index) -- B spectral slices of a cube share each
+ * latency-bound step of the blocked factorisation instead of paying for it B times.
+ *   X         problem b reads X + b*x_stride (N x d); x_stride = 0 shares one X between all problems
+ *   y         B x N,  u_inout / u  B x P,  hist_out  B x T x P,  loss_out  B x T
+ *   Xs        M x d test points shared by all problems;  mean_out / var_out  B x M
+ * The reference has no such loop (it fits one GP per call, gpr.py:257-283); a caller that loops
+ * reconstructor(...).run() over slices gets identical per-slice results from one batched call. */
+int gpimhip_fit_exact_batched(gpimhip_handle h, const gpimhip_model_t* m,
+                              const double* X, int64_t x_stride, const double* y, int64_t N, int32_t B,
+                              double* u_inout, double lr, int32_t T,
+                              double* hist_out, double* loss_out);
+int gpimhip_predict_exact_batched(gpimhip_handle h, const gpimhip_model_t* m,
+                                  const double* X, int64_t x_stride, const double* y, int64_t N, int32_t B,
+                                  const double* u, const double* Xs, int64_t M,
+                                  double* mean_out, double* var_out);
+
 /* Acquisition sweep over the dense grid (gpim/gpbayes/acqfunc.py:11-92):
  *   CB : p0*mean + p1*sd                                  (alpha, beta)
  *   EI : imp*Phi(imp/sd) + sd*phi(imp/sd), imp = mean - p0 - p1     (best, xi)

@@ -16,7 +16,7 @@ int main() {
         hipMemcpy(dA, A.data(), n * n * 8, hipMemcpyHostToDevice);
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         hipEventRecord(e0);
-        hipLaunchKernelGGL(potf2_kernel, dim3(1), dim3(512), 0, 0, dA, (int64_t)n, 0, l16, ld, info, prof);
+        hipLaunchKernelGGL(potf2_kernel, dim3(1), dim3(512), 0, 0, dA, (int64_t)n, 0, l16, ld, info, 1, prof);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         hipMemcpy(hp, prof, 32 * 8, hipMemcpyDeviceToHost);
@@ -31,7 +31,7 @@ int main() {
                chol, solve, trail, hp[27] - hp[26], hp[27] - hp[0]);
         {
             hipEventRecord(e0);
-            hipLaunchKernelGGL(inv128_kernel, dim3(1), dim3(512), 0, 0, dA, (int64_t)n, 0, l16, dinv);
+            hipLaunchKernelGGL(inv128_kernel, dim3(1), dim3(512), 0, 0, dA, (int64_t)n, 0, l16, dinv, 1);
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms2; hipEventElapsedTime(&ms2, e0, e1);
             printf("   inv128: %.1f us\n", ms2 * 1e3);
