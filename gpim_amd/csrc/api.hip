@@ -482,6 +482,9 @@ static int finish_and_check(gpimhip_ctx* h) {
     return GPIMHIP_OK;
 }
 
+int vfe_finish_and_check(gpimhip_ctx* h) { return finish_and_check(h); }
+void vfe_release(gpimhip_ctx* h);
+
 // ------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------
@@ -530,6 +533,7 @@ int gpimhip_destroy(gpimhip_handle h) {
     if (!h) return GPIMHIP_OK;
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
+    vfe_release(h);
     ws_release_matrix(h);
     dev_free(h, &h->Ks, h->ks_batch * h->ks_rows * h->ks_cols);
     dev_free(h, &h->colpart, h->ks_batch * (h->ks_rows / NB) * h->ks_cols);

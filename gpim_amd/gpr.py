@@ -16,7 +16,7 @@ Deliberate differences from the reference, all on the outside of the numerics:
   * no process-global side effects: torch's default tensor type is left alone.
   * a non-positive-definite covariance is reported at the end of ``train``/``predict`` (the
     device loop runs without host synchronisation) instead of at the failing iteration.
-  * ``precision='single'`` and ``sparse=True`` are not implemented yet and raise.
+  * ``precision='single'`` is not implemented yet and raises.
 """
 import ctypes
 import time
@@ -83,6 +83,12 @@ class _ModelView:
     def jitter(self):
         return self._o._spec.jitter
 
+    @property
+    def Xu(self):
+        o = self._o
+        P = o._spec.n_params
+        return o._u[P:].reshape(o._n_ind, o._spec.dim) if o._n_ind else None
+
     def parameters(self):
         yield self._o._u
 
@@ -112,15 +118,13 @@ class reconstructor:
         self.precision = kwargs.get("precision", "double")
         if self.precision != "double":
             raise NotImplementedError("gpim_amd: only precision='double' is implemented")
-        if sparse:
-            raise NotImplementedError("gpim_amd: sparse (inducing-point) GP regression is not implemented yet")
         self._handle = _lib.Handle()          # raises if there is no GPU / no library
         self._dev = self._handle.device
         self.verbose = verbose
         torch.manual_seed(seed)
         input_dim = np.ndim(y)
         self.X, self.y = gprutils.prepare_training_data(X, y, precision=self.precision)
-        self.do_sparse = False
+        self.do_sparse = bool(sparse)
         if lengthscale is None and not kwargs.get("isotropic"):
             lmean = float(np.mean(y.shape) / 2)
             lengthscale = [[0. for _ in range(input_dim)], [lmean for _ in range(input_dim)]]
@@ -133,6 +137,20 @@ class reconstructor:
         # several reconstructors are built from different threads
         self._u = self._spec.draw_initial_u(torch.Generator().manual_seed(seed)).to(self._dev)
         self._mstruct = self._spec.struct()
+        self._n_ind = 0
+        if self.do_sparse:
+            # inducing inputs: every (N // indpoints)-th observation, trainable (gpr.py:145-153)
+            n = len(self.X)
+            if indpoints is None:
+                indpoints = n // 10
+                indpoints = indpoints + 1 if indpoints == 0 else indpoints
+            else:
+                indpoints = n if indpoints > n else indpoints
+            Xu = self.X[::n // indpoints]
+            if self.verbose == 2:
+                print("# of inducing points for sparse GP regression: {}".format(len(Xu)))
+            self._n_ind = len(Xu)
+            self._u = torch.cat([self._u, Xu.reshape(-1).to(self._dev, _F64)]).contiguous()
         self.fulldims = Xtest.shape[1:] if Xtest is not None else X.shape[1:]
         self.Xtest = gprutils.prepare_test_data(Xtest, precision=self.precision) if Xtest is not None else None
         self._Xd = self._to_device(self.X)
@@ -183,11 +201,21 @@ class reconstructor:
             print('Model training...')
         hist = torch.empty((max(T, 1), P), dtype=_F64, device=self._dev)
         loss = torch.empty((max(T, 1),), dtype=_F64, device=self._dev)
-        rc = self._handle.lib.gpimhip_fit_exact(
-            self._handle.h, ctypes.byref(self._mstruct), _lib.ptr(self._Xd), _lib.ptr(self._yd),
-            self._Xd.shape[0], _lib.ptr(self._u), float(self.learning_rate), T,
-            _lib.ptr(hist), _lib.ptr(loss))
+        if not self.do_sparse:
+            rc = self._handle.lib.gpimhip_fit_exact(
+                self._handle.h, ctypes.byref(self._mstruct), _lib.ptr(self._Xd), _lib.ptr(self._yd),
+                self._Xd.shape[0], _lib.ptr(self._u), float(self.learning_rate), T,
+                _lib.ptr(hist), _lib.ptr(loss))
+        else:
+            d = self._spec.dim
+            hist_xu = torch.empty((max(T, 1), self._n_ind, d), dtype=_F64, device=self._dev)
+            rc = self._handle.lib.gpimhip_fit_vfe(
+                self._handle.h, ctypes.byref(self._mstruct), _lib.ptr(self._Xd), _lib.ptr(self._yd),
+                self._Xd.shape[0], self._n_ind, _lib.ptr(self._u), float(self.learning_rate), T,
+                _lib.ptr(hist), _lib.ptr(hist_xu), _lib.ptr(loss))
         _lib.check(rc)
+        if self.do_sparse and T > 0:
+            self.indpoints_all.extend(list(hist_xu[:T].cpu().numpy()))
         hist_h = hist[:T].cpu().numpy()
         loss_h = loss[:T].cpu().numpy()
         n_ls = self._spec.n_ls
@@ -234,9 +262,15 @@ class reconstructor:
         M = self._Xtest_d.shape[0]
         mean = torch.empty((M,), dtype=_F64, device=self._dev)
         var = torch.empty((M,), dtype=_F64, device=self._dev)
-        rc = self._handle.lib.gpimhip_predict_exact(
-            self._handle.h, ctypes.byref(self._mstruct), _lib.ptr(self._Xd), _lib.ptr(self._yd),
-            self._Xd.shape[0], _lib.ptr(self._u), _lib.ptr(self._Xtest_d), M, _lib.ptr(mean), _lib.ptr(var))
+        if not self.do_sparse:
+            rc = self._handle.lib.gpimhip_predict_exact(
+                self._handle.h, ctypes.byref(self._mstruct), _lib.ptr(self._Xd), _lib.ptr(self._yd),
+                self._Xd.shape[0], _lib.ptr(self._u), _lib.ptr(self._Xtest_d), M, _lib.ptr(mean), _lib.ptr(var))
+        else:
+            rc = self._handle.lib.gpimhip_predict_vfe(
+                self._handle.h, ctypes.byref(self._mstruct), _lib.ptr(self._Xd), _lib.ptr(self._yd),
+                self._Xd.shape[0], self._n_ind, _lib.ptr(self._u), _lib.ptr(self._Xtest_d), M, _lib.ptr(mean),
+                _lib.ptr(var))
         _lib.check(rc)
         sd = var.sqrt()
         self._last_pred = (mean, sd)
@@ -260,12 +294,18 @@ class reconstructor:
     def loss_and_grad(self):
         """(loss, d loss/du) at the current hyper-parameters; used by the parity tests."""
         self._check_data()
-        P = self._spec.n_params
+        P = self._u.numel()
         out = torch.empty((1 + P,), dtype=_F64, device=self._dev)
-        rc = self._handle.lib.gpimhip_nll_grad(
-            self._handle.h, ctypes.byref(self._mstruct), _lib.ptr(self._Xd), _lib.ptr(self._yd),
-            self._Xd.shape[0], _lib.ptr(self._u), ctypes.c_void_p(out.data_ptr()),
-            ctypes.c_void_p(out.data_ptr() + 8))
+        if self.do_sparse:
+            rc = self._handle.lib.gpimhip_vfe_nll_grad(
+                self._handle.h, ctypes.byref(self._mstruct), _lib.ptr(self._Xd), _lib.ptr(self._yd),
+                self._Xd.shape[0], self._n_ind, _lib.ptr(self._u), ctypes.c_void_p(out.data_ptr()),
+                ctypes.c_void_p(out.data_ptr() + 8))
+        else:
+            rc = self._handle.lib.gpimhip_nll_grad(
+                self._handle.h, ctypes.byref(self._mstruct), _lib.ptr(self._Xd), _lib.ptr(self._yd),
+                self._Xd.shape[0], _lib.ptr(self._u), ctypes.c_void_p(out.data_ptr()),
+                ctypes.c_void_p(out.data_ptr() + 8))
         _lib.check(rc)
         o = out.cpu()
         return o[0].item(), o[1:].clone()

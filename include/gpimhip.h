@@ -145,6 +145,28 @@ int gpimhip_predict_exact_batched(gpimhip_handle h, const gpimhip_model_t* m,
                                   const double* u, const double* Xs, int64_t M,
                                   double* mean_out, double* var_out);
 
+/* ---- sparse (inducing-point) GP, variational free energy ---------------------------------
+ * Replaces pyro.contrib.gp.models.SparseGPRegression(approx="VFE") as constructed by
+ * reconstructor(sparse=True) (gpim/gpreg/gpr.py:145-155; formulas SURVEY App. A.7).
+ * The parameter vector is u = [ P kernel/noise entries as above | Mu x d inducing inputs Xu,
+ * row-major, unconstrained ]; both parts are trained by Adam (the reference trains Xu too and
+ * records it every iteration, gpr.py:198-199).
+ *   gpimhip_vfe_nll_grad   loss (1 double) and gradient (P + Mu*d doubles) at u
+ *   gpimhip_fit_vfe        T Adam iterations; hist_theta T x P, hist_xu T x Mu x d (either may be
+ *                          NULL), loss_out T or NULL; synchronises at the end
+ *   gpimhip_predict_vfe    posterior mean / variance (full_cov=False, noiseless=False) at Xs */
+int gpimhip_vfe_nll_grad(gpimhip_handle h, const gpimhip_model_t* m,
+                         const double* X, const double* y, int64_t N, int64_t Mu,
+                         const double* u, double* loss_out, double* grad_out);
+int gpimhip_fit_vfe(gpimhip_handle h, const gpimhip_model_t* m,
+                    const double* X, const double* y, int64_t N, int64_t Mu,
+                    double* u_inout, double lr, int32_t T,
+                    double* hist_theta, double* hist_xu, double* loss_out);
+int gpimhip_predict_vfe(gpimhip_handle h, const gpimhip_model_t* m,
+                        const double* X, const double* y, int64_t N, int64_t Mu,
+                        const double* u, const double* Xs, int64_t M,
+                        double* mean_out, double* var_out);
+
 /* Acquisition sweep over the dense grid (gpim/gpbayes/acqfunc.py:11-92):
  *   CB : p0*mean + p1*sd                                  (alpha, beta)
  *   EI : imp*Phi(imp/sd) + sd*phi(imp/sd), imp = mean - p0 - p1     (best, xi)

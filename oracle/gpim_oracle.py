@@ -30,6 +30,10 @@ this image, so the restatement is pinned against the reference's own known answe
   ``examples/notebooks/GP_based_exploration_exploitation.ipynb`` (tests/golden/
   notebook_trace.json, tests/test_oracle_golden.py::test_notebook_trace).
 
+Sparse (inducing-point) regression -- ``reconstructor(sparse=True)``, gpr.py:145-155 -- restates
+pyro.contrib.gp.models.SparseGPRegression with its default approx="VFE" (SURVEY App. A.7):
+``SparseGP`` below.  No reference known answer exists for it (parity UNPINNED).
+
 Parity status: PINNED for RBF exact GP + EI/POI/CB BO (fp64, CPU generator).
 Matern52 / RationalQuadratic / isotropic lengthscale / mask / batch_update / dscale are
 parity-UNPINNED by the reference's own tests (shape/NaN smoke only,
@@ -251,6 +255,69 @@ class ExactGP:
         return loc, var + self.kernel.noise
 
 
+class SparseGP:
+    """pyro.contrib.gp.models.SparseGPRegression (approx="VFE") restated: inducing inputs Xu are
+    trainable, loss = -log N_lowrank(y; 0, W W^T + noise I) + trace(Kff - Qff) / (2 noise)."""
+
+    def __init__(self, X, y, kernel, Xu, jitter):
+        self.X, self.y, self.kernel, self.jitter = X, y, kernel, jitter
+        self.Xu = Xu.clone().requires_grad_()
+
+    def parameters(self):
+        return self.kernel.parameters() + [self.Xu]
+
+    def _luu_w(self, Z):
+        M = self.Xu.size(0)
+        Kuu = self.kernel.K(self.Xu).contiguous()
+        Kuu.view(-1)[::M + 1] += self.jitter
+        Luu = torch.linalg.cholesky(Kuu)
+        return Luu, torch.linalg.solve_triangular(Luu, self.kernel.K(self.Xu, Z), upper=False)
+
+    def loss(self):
+        N, M = self.X.size(0), self.Xu.size(0)
+        _, W = self._luu_w(self.X)                       # (M, N)
+        noise = self.kernel.noise
+        trace_term = ((self.kernel.Kdiag(self.X) - W.pow(2).sum(0)).sum() / noise).clamp(min=0)
+        # LowRankMultivariateNormal(0, cov_factor=W^T, cov_diag=noise).log_prob(y)
+        Wt_Dinv = W / noise
+        cap = Wt_Dinv.matmul(W.t()).contiguous()
+        cap.view(-1)[::M + 1] += 1
+        Lc = torch.linalg.cholesky(cap)
+        log_det = 2 * Lc.diagonal().log().sum() + N * noise.log()
+        Wt_Dinv_y = Wt_Dinv.matmul(self.y.unsqueeze(-1))
+        t2 = torch.linalg.solve_triangular(Lc, Wt_Dinv_y, upper=False).pow(2).sum()
+        mahal = (self.y.pow(2) / noise).sum() - t2
+        log_prob = -0.5 * (N * math.log(2 * math.pi) + log_det + mahal)
+        return -log_prob + 0.5 * trace_term + self.kernel.neg_log_prior()
+
+    def loss_and_grad(self):
+        ps = self.parameters()
+        for p in ps:
+            p.grad = None
+        loss = self.loss()
+        loss.backward()
+        g = torch.cat([p.grad.reshape(-1) for p in ps])
+        return loss.detach(), g
+
+    @torch.no_grad()
+    def predict(self, Xnew):
+        """SparseGPRegression.forward, full_cov=False, noiseless=False."""
+        M = self.Xu.size(0)
+        noise = self.kernel.noise
+        Luu, W = self._luu_w(self.X)
+        W_Dinv = W / noise
+        K = W_Dinv.matmul(W.t()).contiguous()
+        K.view(-1)[::M + 1] += 1
+        L = torch.linalg.cholesky(K)
+        W_Dinv_y = W_Dinv.matmul(self.y.unsqueeze(-1))
+        Ws = torch.linalg.solve_triangular(Luu, self.kernel.K(self.Xu, Xnew), upper=False)
+        pack = torch.linalg.solve_triangular(L, torch.cat((W_Dinv_y, Ws), dim=1), upper=False)
+        Linv_W_Dinv_y, Linv_Ws = pack[:, :1], pack[:, 1:]
+        loc = Linv_W_Dinv_y.t().matmul(Linv_Ws).reshape(-1)
+        var = self.kernel.Kdiag(Xnew) + noise - Ws.pow(2).sum(0) + Linv_Ws.pow(2).sum(0)
+        return loc, var
+
+
 class _KernelFacade:
     """``model.kernel.lengthscale`` as read by boptim.py:319."""
     def __init__(self, kp):
@@ -274,8 +341,6 @@ class reconstructor:
                  verbose=1, seed=0, **kwargs):
         if kwargs.get("precision", "double") != "double":
             raise NotImplementedError("oracle restates the double-precision path only")
-        if sparse:
-            raise NotImplementedError("oracle restates the exact GP only")
         self.verbose = verbose
         torch.manual_seed(seed)
         input_dim = np.ndim(y)
@@ -290,7 +355,17 @@ class reconstructor:
         self.fulldims = Xtest.shape[1:] if Xtest is not None else X.shape[1:]
         self.Xtest = prepare_test_data(Xtest) if Xtest is not None else None
         self.jitter = kwargs.get("jitter", 1.0e-5)
-        self.model = ExactGP(self.X, self.y, self.kernel, self.jitter)
+        self.do_sparse = sparse
+        if not sparse:
+            self.model = ExactGP(self.X, self.y, self.kernel, self.jitter)
+        else:
+            n = len(self.X)
+            if indpoints is None:
+                indpoints = n // 10
+                indpoints = indpoints + 1 if indpoints == 0 else indpoints
+            else:
+                indpoints = n if indpoints > n else indpoints
+            self.model = SparseGP(self.X, self.y, self.kernel, self.X[::n // indpoints], self.jitter)
         self.model.kernel_facade = _KernelFacade(self.kernel)
         self.learning_rate = learning_rate
         self.iterations = iterations
@@ -307,7 +382,8 @@ class reconstructor:
         if kwargs.get("verbose") is not None:
             self.verbose = kwargs.get("verbose")
         # a NEW Adam (t=0, m=v=0) on every call; parameters persist (gpr.py:185)
-        opt = torch.optim.Adam(self.kernel.parameters(), lr=self.learning_rate)
+        params = self.model.parameters() if self.do_sparse else self.kernel.parameters()
+        opt = torch.optim.Adam(params, lr=self.learning_rate)
         for _ in range(self.iterations):
             opt.zero_grad()
             loss = self.model.loss()
@@ -317,6 +393,8 @@ class reconstructor:
             self.lscales.append(self.kernel.lengthscale.tolist())
             self.amp_all.append(self.kernel.variance.item())
             self.noise_all.append(self.kernel.noise.item())
+            if self.do_sparse:
+                self.indpoints_all.append(self.model.Xu.detach().numpy().copy())
 
     def predict(self, Xtest=None, **kwargs):
         if Xtest is None and self.Xtest is None:

@@ -1,0 +1,116 @@
+"""
+Sparse (inducing-point, VFE) GP on the MI355X -- SURVEY 8(a) row a16 -- against the oracle's
+restatement of pyro.contrib.gp.models.SparseGPRegression (torch CPU fp64 + autograd).  The reference
+holds no known answer for this model (parity unpinned; only shape/NaN smoke in its own tests), so
+the oracle is the only checker: operator level (loss, full gradient incl. the inducing inputs,
+posterior) and end to end through ``reconstructor(sparse=True)``.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+from numpy.testing import assert_allclose
+
+pytestmark = pytest.mark.gpu
+
+from oracle import gpim_oracle as O
+from problems import spiral_image
+
+
+@pytest.fixture(scope="module")
+def gpim(ensure_built):
+    import gpim_amd
+    return gpim_amd
+
+
+@pytest.mark.parametrize("kind,N,Mu,d", [("RBF", 200, 20, 2), ("Matern52", 700, 150, 2), ("RBF", 1000, 260, 3),
+                                         ("RationalQuadratic", 300, 40, 2)])
+def test_vfe_loss_grad_predict(gpim, kind, N, Mu, d):
+    from gpim_amd import _lib
+    from gpim_amd.kernels import KernelSpec
+    H = _lib.Handle()
+    rng = np.random.default_rng(N)
+    X = torch.from_numpy(np.unique(rng.integers(0, 40, size=(4 * N, d)), axis=0)[:N].astype(np.float64))
+    N = len(X)
+    y = torch.from_numpy(np.sin(X.numpy().sum(1) / 6.0) + 0.1 * rng.standard_normal(N))
+    ls = [[1.0] * d, [15.0] * d]
+    torch.manual_seed(1)
+    kp = O.KernelParams(kind, d, ls)
+    spec = KernelSpec(kind, d, ls, jitter=1e-5)
+    u_t = spec.draw_initial_u(torch.Generator().manual_seed(1))
+    with torch.no_grad():
+        kp.u_noise.fill_(-2.0)
+    u_t[1 + spec.n_ls] = -2.0
+    Xu0 = X[::N // Mu].clone()
+    Mu = len(Xu0)
+    gp = O.SparseGP(X, y, kp, Xu0, 1e-5)
+    loss_ref, g_ref = gp.loss_and_grad()
+    u = torch.cat([u_t, Xu0.reshape(-1)]).cuda()
+    m = spec.struct()
+    Xd, yd = X.cuda().contiguous(), y.cuda().contiguous()
+    P = spec.n_params
+    out = torch.empty(1 + P + Mu * d, dtype=torch.float64, device="cuda")
+    _lib.check(H.lib.gpimhip_vfe_nll_grad(H.h, ctypes.byref(m), _lib.ptr(Xd), _lib.ptr(yd), N, Mu, _lib.ptr(u),
+                                          ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(out.data_ptr() + 8)))
+    o = out.cpu()
+    assert_allclose(o[0].item(), loss_ref.item(), rtol=1e-12)
+    assert_allclose(o[1:1 + P].numpy(), g_ref[:P].numpy(), rtol=1e-9, atol=1e-9)
+    assert_allclose(o[1 + P:].numpy(), g_ref[P:].numpy(), rtol=0, atol=1e-9 * max(1.0, g_ref[P:].abs().max().item()))
+    Xs = torch.from_numpy(rng.uniform(0, 40, size=(500, d)))
+    Xsd = Xs.cuda().contiguous()
+    mean = torch.empty(500, dtype=torch.float64, device="cuda")
+    var = torch.empty_like(mean)
+    _lib.check(H.lib.gpimhip_predict_vfe(H.h, ctypes.byref(m), _lib.ptr(Xd), _lib.ptr(yd), N, Mu, _lib.ptr(u),
+                                         _lib.ptr(Xsd), 500, _lib.ptr(mean), _lib.ptr(var)))
+    mr, vr = gp.predict(Xs)
+    assert_allclose(mean.cpu().numpy(), mr.numpy(), atol=1e-10)
+    assert_allclose(var.cpu().numpy(), vr.numpy(), atol=1e-10)
+    H.close()
+
+
+@pytest.mark.parametrize("kernel", ["RBF", "Matern52"])
+def test_sparse_reconstructor_run(gpim, kernel):
+    """reconstructor(sparse=True).run(): hyper-parameter and inducing-point histories and the
+    reconstruction follow the oracle over 40 Adam iterations."""
+    R, _ = spiral_image(size=48, keep=0.3, seed=2)
+    X, Xf = gpim.utils.get_sparse_grid(R), gpim.utils.get_full_grid(R)
+    kw = dict(kernel=kernel, lengthscale=[[1., 1.], [8., 8.]], sparse=True, indpoints=60, learning_rate=0.05,
+              iterations=40, verbose=0)
+    rec = gpim.reconstructor(X, R, Xf, **kw)
+    mean, sd, hyper = rec.run()
+    orc = O.reconstructor(X, R, Xf, **kw)
+    mo, so, ho = orc.run()
+    assert mean.shape == R.shape and not np.isnan(mean).any() and not np.isnan(sd).any()
+    assert len(hyper["inducing_points"]) == 40 and hyper["inducing_points"][0].shape == ho["inducing_points"][0].shape
+    assert_allclose(hyper["variance"], ho["variance"], rtol=1e-7)
+    assert_allclose(hyper["lengthscale"], ho["lengthscale"], rtol=1e-7)
+    assert_allclose(hyper["noise"], ho["noise"], rtol=1e-7)
+    assert_allclose(hyper["inducing_points"][-1], ho["inducing_points"][-1], atol=1e-7)
+    assert_allclose(mean, mo, atol=1e-7)
+    assert_allclose(sd, so, atol=1e-7)
+    assert rec.model.Xu.shape == (rec._n_ind, 2)
+
+
+def test_sparse_default_indpoints_and_3d(gpim):
+    """indpoints=None -> N // 10 (gpr.py:146-148); 3D input; second train() call warm-starts."""
+    rng = np.random.default_rng(3)
+    R3 = np.sin(np.arange(10)[:, None, None] / 3.0) * np.cos(np.arange(9)[None, :, None] / 2.0) * \
+        np.ones((1, 1, 6)) + 0.01 * rng.standard_normal((10, 9, 6))
+    R3[rng.random((10, 9)) < 0.4] = np.nan
+    X, Xf = gpim.utils.get_sparse_grid(R3), gpim.utils.get_full_grid(R3)
+    kw = dict(kernel="RBF", sparse=True, learning_rate=0.05, iterations=15, verbose=0)
+    rec = gpim.reconstructor(X, R3, Xf, **kw)
+    orc = O.reconstructor(X, R3, Xf, **kw)
+    n = rec.X.shape[0]
+    assert rec._n_ind == len(rec.X[::n // (n // 10)]) == orc.model.Xu.shape[0]
+    rec.train()
+    rec.train(iterations=5)
+    orc.train()
+    orc.train(iterations=5)
+    assert len(rec.hyperparams["inducing_points"]) == 20
+    assert_allclose(rec.hyperparams["noise"], orc.hyperparams["noise"], rtol=1e-7)
+    m, s = rec.predict()
+    mo, so = orc.predict()
+    assert_allclose(m, mo, atol=1e-7)
+    assert_allclose(s, so, atol=1e-7)

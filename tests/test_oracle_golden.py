@@ -108,3 +108,48 @@ def test_init_draw_constants():
     assert kp.variance.item() == pytest.approx(9.70053301276535, rel=1e-14)
     assert kp.lengthscale.tolist() == pytest.approx([8.84774830499735, 5.742286789093136], rel=1e-14)
     assert kp.noise.item() == 1.0
+
+
+def test_oracle_sparse_gp_properties():
+    """No reference known answer exists for the sparse (VFE) model, so the oracle's restatement is
+    at least checked against identities of the model itself: (i) with every observation used as an
+    inducing input the bound is tight -- VFE loss == exact negative log marginal likelihood and the
+    posteriors coincide; (ii) fewer inducing inputs can only raise the loss (it is an upper bound
+    of the exact NLL); (iii) autograd gradient == central finite differences."""
+    import torch
+    torch.manual_seed(3)
+    rng = np.random.default_rng(0)
+    X = torch.from_numpy(np.unique(rng.integers(0, 12, size=(80, 2)), axis=0).astype(np.float64))[:40]
+    y = torch.from_numpy(np.sin(X.numpy().sum(1) / 3.0) + 0.05 * rng.standard_normal(len(X)))
+    kp = O.KernelParams("RBF", 2, [[1., 1.], [6., 6.]])
+    with torch.no_grad():
+        kp.u_noise.fill_(-3.0)
+    exact = O.ExactGP(X, y, kp, 0.0)
+    full = O.SparseGP(X, y, kp, X.clone(), 1e-10)
+    assert_allclose(full.loss().item(), exact.loss().item(), rtol=1e-6)
+    Xs = torch.from_numpy(rng.uniform(0, 12, size=(50, 2)))
+    me, ve = exact.predict(Xs)
+    ms, vs = full.predict(Xs)
+    assert_allclose(ms.numpy(), me.numpy(), atol=1e-5)
+    assert_allclose(vs.numpy(), ve.numpy(), atol=1e-5)
+    few = O.SparseGP(X, y, kp, X[::5].clone(), 1e-10)
+    assert few.loss().item() >= exact.loss().item() - 1e-9
+    # gradient check on the inducing inputs and the noise
+    loss0, g = few.loss_and_grad()
+    P = 4
+    eps = 1e-6
+    for idx in (0, 3, 7):
+        with torch.no_grad():
+            few.Xu.view(-1)[idx] += eps
+            lp = few.loss().item()
+            few.Xu.view(-1)[idx] -= 2 * eps
+            lm = few.loss().item()
+            few.Xu.view(-1)[idx] += eps
+        assert_allclose((lp - lm) / (2 * eps), g[P + idx].item(), rtol=1e-5, atol=1e-6)
+    with torch.no_grad():
+        kp.u_noise += eps
+        lp = few.loss().item()
+        kp.u_noise -= 2 * eps
+        lm = few.loss().item()
+        kp.u_noise += eps
+    assert_allclose((lp - lm) / (2 * eps), g[3].item(), rtol=1e-5)
