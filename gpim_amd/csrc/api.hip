@@ -70,9 +70,9 @@ static void dev_free(gpimhip_ctx* h, T** p, int64_t count) {
 static void ws_release_matrix(gpimhip_ctx* h) {
     const int64_t np = h->np, nb = np / NB, B = h->ws_batch;
     if (!np) return;
-    dev_free(h, &h->A, B * np * np);
-    dev_free(h, &h->B, B * np * np);
-    dev_free(h, &h->Tm, B * np * np);
+    dev_free(h, &h->A, B * np * h->ld);
+    dev_free(h, &h->B, B * np * h->ld);
+    dev_free(h, &h->Tm, B * np * h->ld);
     dev_free(h, &h->dinv, B * nb * NB * NB);
     dev_free(h, &h->linv16, B * nb * 8 * 256);
     dev_free(h, &h->ypad, B * np);
@@ -90,15 +90,20 @@ static void ws_release_matrix(gpimhip_ctx* h) {
 
 // Workspace for B problems of N observations processed in lock-step (all per-problem buffers are
 // stacked: problem b lives at base + b * size).
-static int ws_ensure_b(gpimhip_ctx* h, int64_t N, int B) {
+// padded != 0: rows of the np x np matrices are np + 16 doubles apart.  With ld = np = 2^k every row
+// of a 128-column panel maps to the same L2 sets (row stride 2^(k+3) bytes) and tiles that share a
+// panel evict each other's lines; one extra cache line per row spreads the rows over the sets.
+static int ws_ensure_b(gpimhip_ctx* h, int64_t N, int B, int padded) {
     const int64_t np = pad_to(std::max<int64_t>(N, 1), NB);
-    if (np == h->np && B == h->ws_batch) return GPIMHIP_OK;
+    const int64_t ld = np + ((padded && np >= 1024) ? 16 : 0);
+    if (np == h->np && B == h->ws_batch && ld == h->ld) return GPIMHIP_OK;
     HIP_TRY(hipStreamSynchronize(h->stream));
     ws_release_matrix(h);
     const int64_t nb = np / NB;
-    GP_TRY(dev_alloc(h, &h->A, B * np * np));
-    GP_TRY(dev_alloc(h, &h->B, B * np * np));
-    GP_TRY(dev_alloc(h, &h->Tm, B * np * np));
+    GP_TRY(dev_alloc(h, &h->A, B * np * ld));
+    GP_TRY(dev_alloc(h, &h->B, B * np * ld));
+    GP_TRY(dev_alloc(h, &h->Tm, B * np * ld));
+    h->ld = ld;
     GP_TRY(dev_alloc(h, &h->dinv, B * nb * NB * NB));
     GP_TRY(dev_alloc(h, &h->linv16, B * nb * 8 * 256));
     GP_TRY(dev_alloc(h, &h->ypad, B * np));
@@ -114,19 +119,20 @@ static int ws_ensure_b(gpimhip_ctx* h, int64_t N, int B) {
     h->ws_batch = B;
     return plan_ensure(h, (int)nb);
 }
-int ws_ensure(gpimhip_ctx* h, int64_t N) { return ws_ensure_b(h, N, h->nbatch); }
+int ws_ensure(gpimhip_ctx* h, int64_t N) { return ws_ensure_b(h, N, h->nbatch, 0); }
+static int ws_ensure_padded(gpimhip_ctx* h, int64_t N) { return ws_ensure_b(h, N, h->nbatch, 1); }
 
 int ws_ensure_predict(gpimhip_ctx* h, int64_t np, int64_t mc) {
     const int B = h->nbatch;
     if (h->ks_rows == np && h->ks_cols == mc && h->ks_batch == B) return GPIMHIP_OK;
     HIP_TRY(hipStreamSynchronize(h->stream));
-    dev_free(h, &h->Ks, h->ks_batch * h->ks_rows * h->ks_cols);
+    dev_free(h, &h->Ks, h->ks_batch * h->ks_rows * (h->ks_cols + 16));
     dev_free(h, &h->colpart, h->ks_batch * (h->ks_rows / NB) * h->ks_cols);
     dev_free(h, &h->pred_tiles, h->pred_ntiles);
     dev_free(h, &h->mean_tmp, h->ks_batch * h->ks_cols);
     h->ks_rows = h->ks_cols = 0;
     h->ks_batch = 0;
-    GP_TRY(dev_alloc(h, &h->Ks, B * np * mc));
+    GP_TRY(dev_alloc(h, &h->Ks, B * np * (mc + 16)));      // rows mc + 16 apart (no power-of-two row stride)
     GP_TRY(dev_alloc(h, &h->colpart, B * (np / NB) * mc));
     GP_TRY(dev_alloc(h, &h->mean_tmp, B * mc));
     h->ks_batch = B;
@@ -245,13 +251,16 @@ int plan_ensure(gpimhip_ctx* h, int nb) {
                              [&](int ci, int, int& k0, int& k1) { k0 = nd.mid; k1 = ci + 1; });
         P.tri_x.push_back(mark(s));
     }
-    // K^-1 = L^-T L^-1 (lower): k-range [ci, nb), longest first, 8x8 patches
+    // K^-1 = L^-T L^-1 (lower): k-range [ci, nb), longest first.  Patches are 2 rows x 32 columns:
+    // tiles of one row have the same k-length and stay in lock-step (their shared operand panel is
+    // read once per XCD), neighbouring rows differ by one block only.
     {
         size_t s = tl.size();
-        for (int ig = 0; ig <= (nb - 1) / 8; ++ig)
-            for (int jg = 0; jg <= ig; ++jg)
-                for (int i = ig * 8; i < std::min(nb, ig * 8 + 8); ++i)
-                    for (int j = jg * 8; j < std::min(nb, jg * 8 + 8); ++j)
+        const int PR = 2, PC = 32;
+        for (int ig = 0; ig <= (nb - 1) / PR; ++ig)
+            for (int jg = 0; jg * PC <= std::min(nb - 1, ig * PR + PR - 1); ++jg)
+                for (int i = ig * PR; i < std::min(nb, ig * PR + PR); ++i)
+                    for (int j = jg * PC; j < std::min(nb, jg * PC + PC); ++j)
                         if (j <= i) tl.push_back({i, j, i, nb});
         P.lauum = mark(s);
     }
@@ -269,12 +278,12 @@ int plan_ensure(gpimhip_ctx* h, int nb) {
 // blocked drivers
 // ------------------------------------------------------------------------------------------
 static GemmArgs gemm_args(const double* A, int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc,
-                          double alpha, double beta, const TileDesc* tiles, int n) {
+                          double alpha, double beta, const TileDesc* tiles, int n, int64_t rows) {
     GemmArgs g;
     memset(&g, 0, sizeof(g));
     g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
     g.alpha = alpha; g.beta = beta; g.tiles = tiles; g.ntiles = n;
-    g.sA = lda * lda; g.sB = ldb * ldb; g.sC = ldc * ldc;     // square np x np workspace matrices
+    g.sA = rows * lda; g.sB = rows * ldb; g.sC = rows * ldc;  // stacked np-row workspace matrices
     return g;
 }
 
@@ -295,13 +304,13 @@ static int panel_steps(gpimhip_ctx* h, double* A, int64_t ld, int32_t* info, int
     for (int k = p0; k < p1; ++k) {
         GP_TRY(launch_potf2(h, A, ld, k, info));
         if (P.trsm[k].n) {
-            GemmArgs g = gemm_args(A, ld, h->dinv, NB, A, ld, 1.0, 0.0, P.d_tiles + P.trsm[k].off, P.trsm[k].n);
+            GemmArgs g = gemm_args(A, ld, h->dinv, NB, A, ld, 1.0, 0.0, P.d_tiles + P.trsm[k].off, P.trsm[k].n, h->np);
             g.b_coff = -k;            // dinv is a (nb*128) x 128 matrix: block (k, 0)
             g.sB = (h->np / NB) * NB * NB;
             GP_TRY(launch_gemm(h, false, false, EPI_STORE, g));
         }
         if (P.inner[k].n) {
-            GemmArgs g = gemm_args(A, ld, A, ld, A, ld, -1.0, 1.0, P.d_tiles + P.inner[k].off, P.inner[k].n);
+            GemmArgs g = gemm_args(A, ld, A, ld, A, ld, -1.0, 1.0, P.d_tiles + P.inner[k].off, P.inner[k].n, h->np);
             GP_TRY(launch_gemm(h, false, false, EPI_STORE, g));
         }
     }
@@ -334,7 +343,7 @@ int launch_potrf(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_t* inf
         const int q0 = (p + 1) * OUTER_W, q1 = std::min(q0 + OUTER_W, nb);
         if (P.trail_next[klast].n) {
             GemmArgs g = gemm_args(A, ld, A, ld, A, ld, -1.0, 1.0, P.d_tiles + P.trail_next[klast].off,
-                                   P.trail_next[klast].n);
+                                   P.trail_next[klast].n, h->np);
             GP_TRY(launch_gemm(h, false, false, EPI_STORE, g));
         }
         if (ahead) {
@@ -347,7 +356,7 @@ int launch_potrf(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_t* inf
             HIP_TRY(hipEventRecord(evF(p), h->panel_stream));
         }
         if (P.trail[klast].n) {
-            GemmArgs g = gemm_args(A, ld, A, ld, A, ld, -1.0, 1.0, P.d_tiles + P.trail[klast].off, P.trail[klast].n);
+            GemmArgs g = gemm_args(A, ld, A, ld, A, ld, -1.0, 1.0, P.d_tiles + P.trail[klast].off, P.trail[klast].n, h->np);
             if (ahead && h->bulk_stream) {
                 HIP_TRY(hipStreamWaitEvent(h->bulk_stream, evE(p), 0));
                 h->stream = h->bulk_stream;
@@ -374,10 +383,11 @@ int launch_trtri(gpimhip_ctx* h, double* A, double* Tm, int64_t np, int64_t ld) 
     const LinalgPlan& P = h->plan;
     GP_TRY(launch_diag_inv_copy(h, A, ld, nb));
     for (size_t lv = 0; lv < P.tri_t.size(); ++lv) {
-        GemmArgs g1 = gemm_args(A, ld, A, ld, Tm, ld, 1.0, 0.0, P.d_tiles + P.tri_t[lv].off, P.tri_t[lv].n);
+        GemmArgs g1 = gemm_args(A, ld, A, ld, Tm, ld, 1.0, 0.0, P.d_tiles + P.tri_t[lv].off, P.tri_t[lv].n, h->np);
         g1.chunk = 64;
+        g1.krev = 1;              // ranges [cj, mid) share their end
         GP_TRY(launch_gemm(h, false, true, EPI_STORE, g1));
-        GemmArgs g2 = gemm_args(A, ld, Tm, ld, A, ld, -1.0, 0.0, P.d_tiles + P.tri_x[lv].off, P.tri_x[lv].n);
+        GemmArgs g2 = gemm_args(A, ld, Tm, ld, A, ld, -1.0, 0.0, P.d_tiles + P.tri_x[lv].off, P.tri_x[lv].n, h->np);
         g2.chunk = 64;
         GP_TRY(launch_gemm(h, false, true, EPI_STORE, g2));
     }
@@ -389,8 +399,9 @@ int launch_lauum(gpimhip_ctx* h, const double* A, double* B, int64_t np, int64_t
     const int nb = (int)(np / NB);
     GP_TRY(plan_ensure(h, nb));
     const LinalgPlan& P = h->plan;
-    GemmArgs g = gemm_args(A, ld, A, ld, B, ld, 1.0, 0.0, P.d_tiles + P.lauum.off, P.lauum.n);
+    GemmArgs g = gemm_args(A, ld, A, ld, B, ld, 1.0, 0.0, P.d_tiles + P.lauum.off, P.lauum.n, h->np);
     g.chunk = 64;
+    g.krev = 1;                   // ranges [ci, nb) share their end
     return launch_gemm(h, true, true, EPI_STORE, g);
 }
 
@@ -423,13 +434,13 @@ static int check_model(const gpimhip_model_t* m) {
 // x_bs: per-problem stride of X in elements (0 when all problems of a batch share one X).
 static int factor_at_u(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X, int64_t x_bs, int64_t N,
                        const double* u) {
-    const int64_t np = h->np;
+    const int64_t np = h->np, ld = h->ld;
     GP_TRY(launch_theta(h, m, u));
-    GP_TRY(launch_kmat(h, m, X, N, nullptr, N, h->theta, 0.0, 1, h->A, np, np, np, 1, 1, x_bs, x_bs, np * np));
-    { StageTimer t(h, 0); GP_TRY(launch_potrf(h, h->A, np, np, h->info)); }
-    { StageTimer t(h, 1); GP_TRY(launch_trtri(h, h->A, h->Tm, np, np)); }
-    GP_TRY(launch_trmv_lower(h, h->A, np, np, h->ypad, h->z));
-    GP_TRY(launch_gemv_t(h, h->A, np, np, np, h->z, h->alpha, 1, np * np, np, np));
+    GP_TRY(launch_kmat(h, m, X, N, nullptr, N, h->theta, 0.0, 1, h->A, ld, np, np, 1, 1, x_bs, x_bs, np * ld));
+    { StageTimer t(h, 0); GP_TRY(launch_potrf(h, h->A, np, ld, h->info)); }
+    { StageTimer t(h, 1); GP_TRY(launch_trtri(h, h->A, h->Tm, np, ld)); }
+    GP_TRY(launch_trmv_lower(h, h->A, ld, np, h->ypad, h->z));
+    GP_TRY(launch_gemv_t(h, h->A, ld, np, np, h->z, h->alpha, 1, np * ld, np, np));
     return GPIMHIP_OK;
 }
 
@@ -440,8 +451,8 @@ static int loss_grad_at_u(gpimhip_ctx* h, const gpimhip_model_t* m, const double
                           double* hist_row, const IterTable* tab = nullptr) {
     const int64_t np = h->np;
     GP_TRY(factor_at_u(h, m, X, x_bs, N, u));
-    { StageTimer t(h, 2); GP_TRY(launch_lauum(h, h->A, h->B, np, np)); }
-    GP_TRY(launch_grad_reduce(h, m, h->B, np, X, N, (int)(np / NB), h->alpha, x_bs));
+    { StageTimer t(h, 2); GP_TRY(launch_lauum(h, h->A, h->B, np, h->ld)); }
+    GP_TRY(launch_grad_reduce(h, m, h->B, h->ld, X, N, (int)(np / NB), h->alpha, x_bs));
     if (tab)
         GP_TRY(launch_finalize(h, m, N, np, u, do_adam, st, nullptr, nullptr, nullptr, tab->iter, tab->bc, tab->T,
                                tab->hist_base, tab->loss_base));
@@ -535,7 +546,7 @@ int gpimhip_destroy(gpimhip_handle h) {
     hipStreamSynchronize(h->stream);
     vfe_release(h);
     ws_release_matrix(h);
-    dev_free(h, &h->Ks, h->ks_batch * h->ks_rows * h->ks_cols);
+    dev_free(h, &h->Ks, h->ks_batch * h->ks_rows * (h->ks_cols + 16));
     dev_free(h, &h->colpart, h->ks_batch * (h->ks_rows / NB) * h->ks_cols);
     dev_free(h, &h->pred_tiles, h->pred_ntiles);
     dev_free(h, &h->mean_tmp, h->ks_batch * h->ks_cols);
@@ -629,7 +640,7 @@ static int fit_impl(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X, i
         GP_TRY(launch_fit_small(h, m, X, x_bs, y, (int)N, u, h->bc, h->bc + T, T, hist_out, loss_out, nullptr));
         return finish_and_check(h);
     }
-    GP_TRY(ws_ensure(h, N));
+    GP_TRY(ws_ensure_padded(h, N));
     HIP_TRY(hipMemsetAsync(h->adam_m, 0, (size_t)B * MAXP * sizeof(double), h->stream));
     HIP_TRY(hipMemsetAsync(h->adam_v, 0, (size_t)B * MAXP * sizeof(double), h->stream));
     HIP_TRY(hipMemsetAsync(h->iter, 0, (size_t)B * sizeof(int32_t), h->stream));     // iteration counters
@@ -677,7 +688,7 @@ static int predict_impl(gpimhip_ctx* h, const gpimhip_model_t* m, const double* 
                         double* var_out) {
     HIP_TRY(hipSetDevice(h->device));
     h->nbatch = B;
-    GP_TRY(ws_ensure(h, N));
+    GP_TRY(ws_ensure_padded(h, N));
     const int64_t np = h->np;
     const int nb = (int)(np / NB);
     HIP_TRY(hipMemsetAsync(h->info, 0, sizeof(int32_t), h->stream));
@@ -692,12 +703,13 @@ static int predict_impl(gpimhip_ctx* h, const gpimhip_model_t* m, const double* 
         const int64_t cnt = std::min(mc, M - m0);
         const int64_t cpad = pad_to(cnt, NB);
         // the test grid Xs is shared by all problems of the batch (z stride 0)
-        GP_TRY(launch_kmat(h, m, X, N, Xs + m0 * m->dim, cnt, h->theta, 0.0, 0, h->Ks, mc, np, cpad, 0, 0, x_bs, 0,
-                           np * mc));
-        GP_TRY(launch_gemv_t(h, h->Ks, mc, np, cpad, h->alpha, h->mean_tmp, 0, np * mc, np, mc));
+        const int64_t kld = mc + 16;
+        GP_TRY(launch_kmat(h, m, X, N, Xs + m0 * m->dim, cnt, h->theta, 0.0, 0, h->Ks, kld, np, cpad, 0, 0, x_bs, 0,
+                           np * kld));
+        GP_TRY(launch_gemv_t(h, h->Ks, kld, np, cpad, h->alpha, h->mean_tmp, 0, np * kld, np, mc));
         GP_TRY(launch_copy_slice(h, h->mean_tmp, mean_out + m0, cnt, mc, M));
-        GemmArgs g = gemm_args(h->A, np, h->Ks, mc, nullptr, 0, 1.0, 0.0, h->pred_tiles, 0);
-        g.sB = np * mc;
+        GemmArgs g = gemm_args(h->A, h->ld, h->Ks, kld, nullptr, 0, 1.0, 0.0, h->pred_tiles, 0, h->np);
+        g.sB = np * kld;
         g.chunk = 64;
         g.colpart = h->colpart;
         g.ld_colpart = mc;
@@ -722,7 +734,7 @@ int gpimhip_nll_grad(gpimhip_handle h, const gpimhip_model_t* m, const double* X
                                 loss_out, grad_out));
         return finish_and_check(h);
     }
-    GP_TRY(ws_ensure(h, N));
+    GP_TRY(ws_ensure_padded(h, N));
     GP_TRY(launch_pad_copy(h, y, N, h->ypad, h->np));
     AdamStep st;
     memset(&st, 0, sizeof(st));

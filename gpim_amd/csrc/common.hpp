@@ -82,6 +82,7 @@ struct gpimhip_ctx {
     std::vector<hipEvent_t> ev_pool;      // cross-stream ordering events (no timing)
     // workspace (sized for np = padded N)
     int64_t np = 0;                 // padded matrix order the buffers are sized for
+    int64_t ld = 0;                 // leading dimension (doubles) of A, B, Tm: np, or np + 16 (see ws_ensure_b)
     int nbatch = 1;                 // problems processed in lock-step by the current call (grid.y)
     int ws_batch = 0;               // number of problems the workspace is sized for
     double* A = nullptr;            // np x np : K -> L -> L^-1
@@ -139,6 +140,7 @@ struct GemmArgs {
     double alpha, beta;
     const TileDesc* tiles; int ntiles;
     int chunk;                             // XCD dealing: 0 = contiguous slices, >0 = round-robin chunks
+    int krev;                              // walk each tile's k-range from its end (ranges sharing their upper end)
     double* colpart; int64_t ld_colpart;   // EPI_COLSUMSQ: colpart[ci*ld + cj*128 + col]
     int64_t sA, sB, sC, sColpart;          // per-problem (blockIdx.y) strides in elements
 };

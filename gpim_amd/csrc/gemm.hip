@@ -116,10 +116,15 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_tiles_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
 
+    // krev: walk the k-range from its END.  Tiles of one 8x8 patch whose ranges share their upper
+    // end (K^-1 = L^-T L^-1: [ci, nb)) then sweep the same operand rows at the same time, so the
+    // panels they share are still in the XCD's L2 when the next tile asks for them.
+    const int64_t kfirst = g.krev ? (int64_t)(nsteps - 1) * GEMM_BK : 0;
+    const int64_t kstride = g.krev ? -GEMM_BK : GEMM_BK;
     d2 ra[1024 / NT], rb[1024 / NT];
     if (nsteps > 0) {
-        stage_load<A_KM, NT>(ra, g.A, g.lda, a_m0, a_k0, tid);
-        stage_load<B_KM, NT>(rb, g.B, g.ldb, b_n0, b_k0, tid);
+        stage_load<A_KM, NT>(ra, g.A, g.lda, a_m0, a_k0 + kfirst, tid);
+        stage_load<B_KM, NT>(rb, g.B, g.ldb, b_n0, b_k0 + kfirst, tid);
         stage_store<A_KM, NT>(ra, smem, tid);
         stage_store<B_KM, NT>(rb, smem + STAGE_ELEMS, tid);
     }
@@ -130,8 +135,8 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_tiles_kernel(GemmArgs g) {
         const double* Bs = As + STAGE_ELEMS;
         const bool more = (s + 1 < nsteps);
         if (more) {
-            stage_load<A_KM, NT>(ra, g.A, g.lda, a_m0, a_k0 + (int64_t)(s + 1) * GEMM_BK, tid);
-            stage_load<B_KM, NT>(rb, g.B, g.ldb, b_n0, b_k0 + (int64_t)(s + 1) * GEMM_BK, tid);
+            stage_load<A_KM, NT>(ra, g.A, g.lda, a_m0, a_k0 + kfirst + (int64_t)(s + 1) * kstride, tid);
+            stage_load<B_KM, NT>(rb, g.B, g.ldb, b_n0, b_k0 + kfirst + (int64_t)(s + 1) * kstride, tid);
         }
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
