@@ -30,6 +30,12 @@ class boptimizer:
     **kwargs)`` with kwargs verbose, use_gpu (ignored), learning_rate, jitter (default 1e-6),
     isotropic, precision, alpha, beta, xi, dscale, batch_dscale, batch_out_max, gamma, memory,
     exit_strategy, mask, extent, simulate_measurement, y_true, save_checkpoints, filename.
+
+    gpim_amd extension: ``shard_candidates=True`` (with torch.distributed initialised, one process
+    per GPU) makes every rank sweep only its contiguous block of the test grid; an all-gather of
+    each rank's top-``batch_size`` (value, index) pairs gives all ranks the same global ranking
+    (SURVEY 8(e)).  Training stays replicated -- it is deterministic, so all ranks hold the same
+    hyper-parameters -- and every rank evaluates the same next point.
     """
 
     def __init__(self, X_seed, y_seed, X_full, target_function, acquisition_function='cb',
@@ -71,6 +77,7 @@ class boptimizer:
         self.mask = kwargs.get("mask", None)
         self.save_checkpoints = kwargs.get("save_checkpoints", False)
         self.filename = kwargs.get("filename", "./boptim_results")
+        self.shard_candidates = kwargs.get("shard_candidates", False)
         self.indices_all, self.vals_all = [], []
         self.target_func_vals, self.gp_predictions = [y_seed.copy()], []
 
@@ -133,6 +140,14 @@ class boptimizer:
         sm = self.surrogate_model
         sm._last_acq = None
         af = self.acquisition_function
+        if self.shard_candidates and af in ('cb', 'ei', 'poi'):
+            vals_list, indices_list = self._next_point_sharded()
+            if not self.batch_update:
+                return vals_list, indices_list
+            radius = self.batch_dscale
+            if radius is None:
+                radius = sm.model.kernel.lengthscale.mean().item()
+            return self.update_points(vals_list, indices_list, radius)
         if af == 'cb':
             acq, pred = acqfunc.confidence_bound(sm, self.X_full, alpha=self.alpha, beta=self.beta)
         elif af == 'ei':
@@ -153,6 +168,55 @@ class boptimizer:
         if radius is None:
             radius = sm.model.kernel.lengthscale.mean().item()
         return self.update_points(vals_list, indices_list, radius)
+
+    def _next_point_sharded(self):
+        """Acquisition sweep over this rank's block of candidates + global top-k (RCCL all-gather)."""
+        from . import dist as gdist
+        sm = self.surrogate_model
+        handle = sm._handle
+        grid_shape = self.X_full.shape[1:]
+        Xflat = np.asarray(self.X_full).reshape(self.X_full.shape[0], -1)
+        M = Xflat.shape[1]
+        lo, hi = gdist.candidate_block(M)
+        Xblk = Xflat[:, lo:hi]
+        af = self.acquisition_function
+        if af == 'cb':
+            acq, pred = acqfunc.confidence_bound(sm, Xblk, alpha=self.alpha, beta=self.beta)
+        elif af == 'ei':
+            acq, pred = acqfunc.expected_improvement(sm, Xblk, self.X_sparse, xi=self.xi)
+        else:
+            acq, pred = acqfunc.probability_of_improvement(sm, Xblk, self.X_sparse, xi=self.xi)
+        acq_d = sm._last_acq
+        sm._last_acq = None
+        if acq_d is None:
+            acq_d = torch.as_tensor(np.ascontiguousarray(acq), dtype=_F64).reshape(-1).to(handle.device)
+        keep_nan = 1
+        if self.mask is not None:
+            mblk = np.asarray(self.mask).reshape(-1)[lo:hi]
+            acq_d = torch.as_tensor(np.ascontiguousarray(mblk), dtype=_F64).to(handle.device) * acq_d
+            keep_nan = 0
+        k = int(min(self.batch_size, M))
+        kl = int(min(k, max(hi - lo, 1)))
+        vals = torch.full((k,), float("-inf"), dtype=_F64, device=handle.device)
+        idx = torch.full((k,), -1, dtype=torch.int64, device=handle.device)
+        if hi > lo:
+            lv = torch.empty((kl,), dtype=_F64, device=handle.device)
+            li = torch.empty((kl,), dtype=torch.int64, device=handle.device)
+            cnt = torch.zeros((1,), dtype=torch.int64, device=handle.device)
+            _lib.check(handle.lib.gpimhip_topk(handle.h, _lib.ptr(acq_d.contiguous()), acq_d.numel(), kl, keep_nan,
+                                               _lib.ptr(lv), _lib.ptr(li), _lib.ptr(cnt)))
+            n = int(cnt.item())
+            vals[:n] = lv[:n]
+            idx[:n] = li[:n] + lo
+        gv, gi = gdist.global_topk(vals, idx, k, nan_first=bool(keep_nan))
+        # the stored GP prediction is the full map on every rank
+        mean_d, sd_d = sm._last_pred if sm._last_pred is not None else (None, None)
+        mean_full = gdist.all_gather_blocks(torch.as_tensor(pred[0], dtype=_F64).reshape(-1).to(handle.device), M)
+        sd_full = gdist.all_gather_blocks(torch.as_tensor(pred[1], dtype=_F64).reshape(-1).to(handle.device), M)
+        self.gp_predictions.append((mean_full.cpu().numpy().reshape(grid_shape),
+                                    sd_full.cpu().numpy().reshape(grid_shape)))
+        flat = gi.cpu().numpy()
+        return gv.cpu().numpy().tolist(), np.stack(np.unravel_index(flat, grid_shape), axis=-1).tolist()
 
     def update_points(self, acqfunc_values, indices, dscale):
         """Thin a ranked batch so that kept points are farther than ``dscale`` apart

@@ -151,10 +151,11 @@ def candidate_block(M, rank=None, world_size=None):
     return min(rank * per, M), min((rank + 1) * per, M)
 
 
-def global_topk(local_vals, local_idx, k):
+def global_topk(local_vals, local_idx, k, nan_first=False):
     """local_vals / local_idx: this rank's descending top-k (values, GLOBAL flat indices), padded
     with -inf / -1 to length k.  All-gathers the 2*k*world numbers and returns the global
-    descending top-k on every rank (ties: larger flat index first, as gpimhip_topk)."""
+    descending top-k on every rank (ties: larger flat index first, as gpimhip_topk; NaN values rank
+    above everything when nan_first, like the un-masked ranking of boptim.py:303-306)."""
     rank, ws = world()
     vals = torch.as_tensor(local_vals, dtype=torch.float64).reshape(-1)
     idx = torch.as_tensor(local_idx, dtype=torch.int64).reshape(-1).to(vals.device)
@@ -165,7 +166,29 @@ def global_topk(local_vals, local_idx, k):
         dist.all_gather(ix, idx)
         vals, idx = torch.cat(vs), torch.cat(ix)
     keep = idx >= 0
+    if not nan_first:
+        keep = keep & ~torch.isnan(vals)
     vals, idx = vals[keep], idx[keep]
-    order = sorted(range(len(vals)), key=lambda i: (vals[i].item(), idx[i].item()), reverse=True)[:k]
+    vl, il = vals.tolist(), idx.tolist()
+
+    def key(i):
+        v = vl[i]
+        return (float("inf") if v != v else v, 1 if v != v else 0, il[i])
+    order = sorted(range(len(vl)), key=key, reverse=True)[:k]
     order = torch.as_tensor(order, dtype=torch.int64, device=vals.device)
     return vals[order], idx[order]
+
+
+def all_gather_blocks(block, M):
+    """block: this rank's slice (candidate_block) of a length-M vector; returns the full vector on
+    every rank."""
+    rank, ws = world()
+    if ws == 1:
+        return block
+    per = (M + ws - 1) // ws
+    pad = torch.full((per,), float("nan"), dtype=block.dtype, device=block.device)
+    pad[:block.numel()] = block
+    parts = [torch.empty_like(pad) for _ in range(ws)]
+    dist.all_gather(parts, pad)
+    return torch.cat(parts)[:M] if per * ws == M else torch.cat(
+        [parts[r][:max(0, min(per, M - r * per))] for r in range(ws)])

@@ -58,6 +58,19 @@ def _worker(rank, world, port, ret):
     expect = np.argsort(acq, kind="stable")[::-1][:k]
     np.testing.assert_array_equal(gi.numpy(), expect)
     np.testing.assert_array_equal(gv.numpy(), acq[expect])
+    # NaN-first ranking (the un-masked path of boptimizer.next_point) and block re-assembly
+    acq2 = acq.copy()
+    acq2[[3, 77]] = np.nan
+    loc = acq2[lo:hi]
+    order = np.argsort(loc, kind="stable")[::-1][:k]           # NaNs first after reversal
+    lv = np.full(k, -np.inf)
+    li = np.full(k, -1, dtype=np.int64)
+    lv[:len(order)], li[:len(order)] = loc[order], order + lo
+    gv, gi = gd.global_topk(lv, li, k, nan_first=True)
+    expect = np.argsort(acq2, kind="stable")[::-1][:k]
+    np.testing.assert_array_equal(gi.numpy(), expect)
+    full = gd.all_gather_blocks(torch.from_numpy(acq[lo:hi].copy()), M)
+    np.testing.assert_array_equal(full.numpy(), acq)
     ret[rank] = True
     dist.barrier()
     dist.destroy_process_group()

@@ -189,3 +189,18 @@ def test_batched_small_n_and_distinct_x(gpim):
         bad[np.isnan(bad)][:1]
         bad[np.where(np.isnan(bad))[0][0], np.where(np.isnan(bad))[1][0]] = 0.5     # one more observation
         fit_predict_batch([Xs[0], gpim.utils.get_sparse_grid(bad)], [ys[0], bad], Xf, **kw)
+
+
+@pytest.mark.parametrize("acqf", ["ei", "cb"])
+def test_boptim_sharded_candidates_single_rank(gpim, acqf, golden_dir, tmp_path):
+    """shard_candidates=True goes through the block sweep + global top-k path (one rank here; the
+    2-rank merge itself is covered by tests/test_dist_gloo.py) and must still reproduce the
+    reference's golden vector and query order."""
+    trial_func, Z_sparse = bo_test_problem()
+    bo = gpim.boptimizer(gpim.utils.get_sparse_grid(Z_sparse), Z_sparse, gpim.utils.get_full_grid(Z_sparse),
+                         trial_func, acquisition_function=acqf, exploration_steps=20, verbose=0,
+                         shard_candidates=True, filename=str(tmp_path / "bo"))
+    bo.run()
+    assert_allclose(bo.target_func_vals[-1], np.load(os.path.join(golden_dir, "test_%s.npy" % acqf)))
+    assert [tuple(i) for i in bo.indices_all] == ORDER[acqf]
+    assert bo.gp_predictions[0][0].shape == (25, 25)
