@@ -128,8 +128,14 @@ def main():
 
     def fence():
         if world > 1:
-            dist.barrier()
+            dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
+
+    if world > 1:
+        # bring the RCCL communicators up outside the timed region even when --warmup 0
+        probe = torch.zeros(8, dtype=torch.float64, device=dev)
+        dist.all_gather([torch.empty_like(probe) for _ in range(world)], probe)
+        fence()
 
     for _ in range(args.warmup):
         step()
@@ -188,7 +194,7 @@ def main():
             out["cpu_baseline"] = None
         print(json.dumps(out))
     if world > 1:
-        dist.barrier()
+        dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
 
 
