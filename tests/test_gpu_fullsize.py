@@ -1,0 +1,104 @@
+"""
+Full-size checks on the MI355X (BASELINE.json config sizes):
+  * C1 (128x128 spiral twin, N = 4206, M = 16384): three Adam iterations + predict against the oracle
+    (the oracle needs ~2 s per iteration at this size on the GPU host);
+  * C2 size (N = 16384): size-independent identities of the blocked factorisation through the C ABI
+    -- L L^T = K on sampled rows -- and of the whole fit/predict (finite, loss decreasing, posterior
+    interpolates the data within the noise level);
+  * C3 (64 slices of 64x64): batched == stand-alone for sampled slices (bitwise).
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+from numpy.testing import assert_allclose
+
+pytestmark = pytest.mark.gpu
+
+from oracle import gpim_oracle as O
+from problems import hyperspectral_cube, lattice_image, spiral_image
+
+
+@pytest.fixture(scope="module")
+def gpim(ensure_built):
+    import gpim_amd
+    return gpim_amd
+
+
+def test_c1_full_size_vs_oracle(gpim):
+    R, _ = spiral_image()
+    X, Xf = gpim.utils.get_sparse_grid(R), gpim.utils.get_full_grid(R)
+    kw = dict(kernel="RBF", lengthscale=[[1., 1.], [4., 4.]], learning_rate=0.1, iterations=3, verbose=0)
+    mean, sd, hyper = gpim.reconstructor(X, R, Xf, **kw).run()
+    torch.set_num_threads(min(32, torch.get_num_threads() * 32))
+    mo, so, ho = O.reconstructor(X, R, Xf, **kw).run()
+    torch.set_num_threads(1)
+    assert_allclose(hyper["lengthscale"], ho["lengthscale"], rtol=1e-9)
+    assert_allclose(hyper["noise"], ho["noise"], rtol=1e-9)
+    assert np.sqrt(np.mean((mean - mo) ** 2)) < 1e-9
+    assert np.sqrt(np.mean((sd - so) ** 2)) < 1e-9
+
+
+def test_c2_size_factorisation_identity(gpim):
+    from gpim_amd import _lib
+    from gpim_amd.kernels import KernelSpec
+    H = _lib.Handle()
+    R, _ = lattice_image()
+    X, y = gpim.utils.prepare_training_data(gpim.utils.get_sparse_grid(R), R)
+    N = X.shape[0]
+    assert N == 16384
+    spec = KernelSpec("Matern52", 2, [[1., 1.], [20., 20.]])
+    m = spec.struct()
+    theta = torch.tensor([0.7, 3.0, 4.0, 1.0], dtype=torch.float64, device="cuda")
+    Xd = X.cuda().contiguous()
+    K = torch.empty((N, N), dtype=torch.float64, device="cuda")
+    _lib.check(H.lib.gpimhip_kmat(H.h, ctypes.byref(m), _lib.ptr(Xd), N, None, 0, _lib.ptr(theta), 1e-3, _lib.ptr(K), N))
+    torch.cuda.synchronize()
+    # (|a|^2 - 2 a.b) + |b|^2 is not bitwise symmetric in (a, b) -- neither is the reference's form
+    assert (K - K.T).abs().max().item() < 1e-11
+    L = K.clone()
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    _lib.check(H.lib.gpimhip_potrf(H.h, _lib.ptr(L), N, N, _lib.ptr(info)))
+    torch.cuda.synchronize()
+    assert info.item() == 0
+    Lt = torch.tril(L)
+    rows = torch.from_numpy(np.random.default_rng(0).choice(N, 96, replace=False)).cuda()
+    rec = Lt[rows] @ Lt.T                      # verification only (torch), not the product path
+    err = (rec - K[rows]).abs().max().item()
+    assert err < 1e-11 * K.abs().max().item() * np.sqrt(N), err
+    del K, L, Lt, rec
+    H.close()
+
+
+def test_c2_size_fit_predict_properties(gpim):
+    R, img = lattice_image()
+    X, Xf = gpim.utils.get_sparse_grid(R), gpim.utils.get_full_grid(R)
+    rec = gpim.reconstructor(X, R, Xf, kernel="Matern52", lengthscale=[[1., 1.], [20., 20.]], learning_rate=0.1,
+                             iterations=8, verbose=0)
+    mean, sd, hyper = rec.run()
+    assert mean.shape == R.shape and np.isfinite(mean).all() and np.isfinite(sd).all()
+    loss = np.array(rec.loss_all)
+    assert np.all(np.diff(loss) < 0)                       # Adam with lr 0.1 descends from the random start
+    obs = ~np.isnan(R)
+    noise = hyper["noise"][-1]
+    # at observed pixels the posterior mean is within a few predictive sd of the data, and the
+    # predictive sd there is close to the noise floor; away from data it is larger
+    z = np.abs(mean[obs] - R[obs]) / sd[obs]
+    assert np.percentile(z, 99) < 4.0
+    assert np.median(sd[obs]) < np.median(sd[~obs])
+    assert np.all(sd ** 2 >= noise * (1 - 1e-9))
+
+
+def test_c3_batched_equals_single_on_samples(gpim):
+    from gpim_amd import dist as gd
+    R, _ = hyperspectral_cube()
+    kw = dict(kernel="RBF", lengthscale=[[1., 1.], [20., 20.]], learning_rate=0.1, iterations=20)
+    mean, sd = gd.reconstruct_slices(R, axis=-1, batch=64, **kw)
+    assert mean.shape == R.shape and np.isfinite(mean).all()
+    for k in (0, 31, 63):
+        Rk = R[..., k]
+        m1, s1, _ = gpim.reconstructor(gpim.utils.get_sparse_grid(Rk), Rk, gpim.utils.get_full_grid(Rk), verbose=0,
+                                       **kw).run()
+        np.testing.assert_array_equal(mean[..., k], m1)
+        np.testing.assert_array_equal(sd[..., k], s1)
