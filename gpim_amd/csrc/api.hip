@@ -292,13 +292,14 @@ static GemmArgs gemm_args(const double* A, int64_t lda, const double* B, int64_t
 // current 512-wide outer panel; after the last column of an outer panel one SYRK-shaped trailing
 // update with k-depth 512 (keeps the update MFMA-bound instead of HBM-bound on the C tiles).
 //
-// Look-ahead: the panel chain (potf2 -> solve -> in-panel update, 3 small launches per column) is
-// latency-bound and would leave the chip idle, so it runs on a second, high-priority stream
-// concurrently with the bulk of the previous panel's trailing update:
-//   main  : trail_next(p) . E_p . trail_rest(p) ............ wait F_{p+1} . trail_next(p+1) ...
-//   panel :                 wait E_p . panel(p+1) . F_{p+1}
-// trail_next(p) touches exactly the columns panel(p+1) factors; trail_rest(p) touches the columns
-// to the right of them, so the two streams never write the same tile.
+// Look-ahead (large N): the panel chain (potf2 -> inverse -> solve -> in-panel update, 4 small
+// launches per column) is latency-bound and would leave the chip idle, so after panel p is final the
+// work forks:
+//   panel stream (high priority): trail_next(p) [update of the next panel's columns] . panel(p+1)
+//   bulk stream  (CU-masked)    : trail_rest(p) [everything to the right of them]
+// trail_next(p) touches exactly the columns panel(p+1) factors; trail_rest(p) touches the columns to
+// the right of them, so the two streams never write the same tile.  Both join the caller's stream
+// before the next round.
 static int panel_steps(gpimhip_ctx* h, double* A, int64_t ld, int32_t* info, int p0, int p1) {
     const LinalgPlan& P = h->plan;
     for (int k = p0; k < p1; ++k) {
@@ -306,6 +307,7 @@ static int panel_steps(gpimhip_ctx* h, double* A, int64_t ld, int32_t* info, int
         if (P.trsm[k].n) {
             GemmArgs g = gemm_args(A, ld, h->dinv, NB, A, ld, 1.0, 0.0, P.d_tiles + P.trsm[k].off, P.trsm[k].n, h->np);
             g.b_coff = -k;            // dinv is a (nb*128) x 128 matrix: block (k, 0)
+            g.inplace = 1;            // A[i,k] <- A[i,k] * Dinv^T overwrites its own operand
             g.sB = (h->np / NB) * NB * NB;
             GP_TRY(launch_gemm(h, false, false, EPI_STORE, g));
         }
@@ -341,36 +343,39 @@ int launch_potrf(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_t* inf
     for (int p = 0; p + 1 < npanel; ++p) {
         const int klast = std::min((p + 1) * OUTER_W, nb) - 1;      // last column of panel p
         const int q0 = (p + 1) * OUTER_W, q1 = std::min(q0 + OUTER_W, nb);
-        if (P.trail_next[klast].n) {
-            GemmArgs g = gemm_args(A, ld, A, ld, A, ld, -1.0, 1.0, P.d_tiles + P.trail_next[klast].off,
-                                   P.trail_next[klast].n, h->np);
-            GP_TRY(launch_gemm(h, false, false, EPI_STORE, g));
+        GemmArgs gn = gemm_args(A, ld, A, ld, A, ld, -1.0, 1.0, P.d_tiles + P.trail_next[klast].off,
+                                P.trail_next[klast].n, h->np);
+        GemmArgs gb = gemm_args(A, ld, A, ld, A, ld, -1.0, 1.0, P.d_tiles + P.trail[klast].off, P.trail[klast].n, h->np);
+        if (!(ahead && h->bulk_stream)) {
+            // in-order schedule (small / mid N, or no side streams)
+            if (gn.ntiles) GP_TRY(launch_gemm(h, false, false, EPI_STORE, gn));
+            if (gb.ntiles) GP_TRY(launch_gemm(h, false, false, EPI_STORE, gb));
+            GP_TRY(panel_steps(h, A, ld, info, q0, q1));
+            continue;
         }
-        if (ahead) {
-            HIP_TRY(hipEventRecord(evE(p), main_s));
-            HIP_TRY(hipStreamWaitEvent(h->panel_stream, evE(p), 0));
-            h->stream = h->panel_stream;
-            rc = panel_steps(h, A, ld, info, q0, q1);
+        // Panel p is final on the main stream here.  Fork:
+        //   panel stream (high priority): update of the next panel's columns, then its factorisation
+        //   bulk stream (CU-masked)     : the rest of the trailing update
+        // They write disjoint column ranges and only read panel p.  Join both before the next round
+        // (the next trail_next touches columns the bulk update of this round also wrote).
+        HIP_TRY(hipEventRecord(evE(p), main_s));
+        HIP_TRY(hipStreamWaitEvent(h->panel_stream, evE(p), 0));
+        h->stream = h->panel_stream;
+        rc = gn.ntiles ? launch_gemm(h, false, false, EPI_STORE, gn) : GPIMHIP_OK;
+        if (rc == GPIMHIP_OK) rc = panel_steps(h, A, ld, info, q0, q1);
+        h->stream = main_s;
+        GP_TRY(rc);
+        HIP_TRY(hipEventRecord(evF(p), h->panel_stream));
+        if (gb.ntiles) {
+            HIP_TRY(hipStreamWaitEvent(h->bulk_stream, evE(p), 0));
+            h->stream = h->bulk_stream;
+            rc = launch_gemm(h, false, false, EPI_STORE, gb);
             h->stream = main_s;
             GP_TRY(rc);
-            HIP_TRY(hipEventRecord(evF(p), h->panel_stream));
+            HIP_TRY(hipEventRecord(h->ev_pool[2 * npanel], h->bulk_stream));
+            HIP_TRY(hipStreamWaitEvent(main_s, h->ev_pool[2 * npanel], 0));
         }
-        if (P.trail[klast].n) {
-            GemmArgs g = gemm_args(A, ld, A, ld, A, ld, -1.0, 1.0, P.d_tiles + P.trail[klast].off, P.trail[klast].n, h->np);
-            if (ahead && h->bulk_stream) {
-                HIP_TRY(hipStreamWaitEvent(h->bulk_stream, evE(p), 0));
-                h->stream = h->bulk_stream;
-                rc = launch_gemm(h, false, false, EPI_STORE, g);
-                h->stream = main_s;
-                GP_TRY(rc);
-                HIP_TRY(hipEventRecord(h->ev_pool[2 * npanel], h->bulk_stream));
-                HIP_TRY(hipStreamWaitEvent(main_s, h->ev_pool[2 * npanel], 0));
-            } else {
-                GP_TRY(launch_gemm(h, false, false, EPI_STORE, g));
-            }
-        }
-        if (ahead) HIP_TRY(hipStreamWaitEvent(main_s, evF(p), 0));
-        else GP_TRY(panel_steps(h, A, ld, info, q0, q1));
+        HIP_TRY(hipStreamWaitEvent(main_s, evF(p), 0));
     }
     return GPIMHIP_OK;
 }

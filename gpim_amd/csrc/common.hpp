@@ -140,6 +140,7 @@ struct GemmArgs {
     double alpha, beta;
     const TileDesc* tiles; int ntiles;
     int chunk;                             // XCD dealing: 0 = contiguous slices, >0 = round-robin chunks
+    int inplace;                           // C aliases an operand tile (panel solve): one workgroup must own the whole tile
     int krev;                              // walk each tile's k-range from its end (ranges sharing their upper end)
     double* colpart; int64_t ld_colpart;   // EPI_COLSUMSQ: colpart[ci*ld + cj*128 + col]
     int64_t sA, sB, sC, sColpart;          // per-problem (blockIdx.y) strides in elements

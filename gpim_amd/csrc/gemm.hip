@@ -8,72 +8,83 @@
 // structural zeros) and the host can order the list for XCD/L2 locality.
 //
 // Tile engine: 256 threads = 4 waves (2x2), each wave owns a 64x64 sub-tile = 4x4
-// v_mfma_f64_16x16x4_f64 accumulators (128 VGPRs).  Operand tiles are staged
+// v_mfma_f64_16x16x4_f64 accumulators (128 VGPRs).  Two more shapes serve launches that cannot fill
+// the chip with one 4-wave workgroup per 128x128 tile: 8 waves per tile (two MFMA waves on every
+// SIMD of the tile's CU) and 64x64 sub-tiles (a 128x128 tile spread over 4 CUs) -- the panel
+// solves / in-panel updates of the Cholesky are latency-bound chains of such small launches.  Operand tiles are staged
 // global -> registers -> LDS (double-buffered, one barrier per 16-deep k-step) in the
 // layout of their source so that every global access is a coalesced 16-byte load:
 //   "MK" operand (row-major, k contiguous):  lds[128][16+2]   fragment read is bank-conflict free
 //   "KM" operand (row-major, m contiguous):  lds[16][128+16]  likewise
 // v_mfma_f64_16x16x4_f64 lane maps (cdna_hip_programming.md section 3):
 //   A[l&15][l>>4], B[l>>4][l&15], C/D col = l&15, row = (l>>4) + 4*reg.
+#include <stdlib.h>
 #include "common.hpp"
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
 
 #define LD_MK (GEMM_BK + 2)
-#define LD_KM (NB + 16)
-#define STAGE_ELEMS 2304            // 128*18 == 16*144
-static_assert(NB * LD_MK == STAGE_ELEMS && GEMM_BK * LD_KM == STAGE_ELEMS, "stage size");
 
-template <bool KM, int NT>
-__device__ __forceinline__ void stage_load(d2 (&r)[1024 / NT], const double* __restrict__ base, int64_t ld,
+// TS = tile side handled by one workgroup (128 or 64); NT = threads.  One staged operand tile is
+// TS x 16 doubles = 8*TS 16-byte chunks whatever its orientation.
+template <bool KM, int NT, int TS>
+__device__ __forceinline__ void stage_load(d2 (&r)[8 * TS / NT], const double* __restrict__ base, int64_t ld,
                                            int64_t mrow0, int64_t kcol0, int tid) {
     // MK: tile element (m,k) lives at base[(mrow0+m)*ld + kcol0 + k]
     // KM: tile element (k,m) lives at base[(kcol0+k)*ld + mrow0 + m]
 #pragma unroll
-    for (int i = 0; i < 1024 / NT; ++i) {
+    for (int i = 0; i < 8 * TS / NT; ++i) {
         const int c = tid + NT * i;
         if (!KM) {
             const int row = c >> 3, c16 = c & 7;
             r[i] = *reinterpret_cast<const d2*>(base + (mrow0 + row) * ld + kcol0 + c16 * 2);
         } else {
-            const int krow = c >> 6, c16 = c & 63;
+            const int krow = c / (TS / 2), c16 = c % (TS / 2);
             r[i] = *reinterpret_cast<const d2*>(base + (kcol0 + krow) * ld + mrow0 + c16 * 2);
         }
     }
 }
 
-template <bool KM, int NT>
-__device__ __forceinline__ void stage_store(const d2 (&r)[1024 / NT], double* lds, int tid) {
+template <bool KM, int NT, int TS>
+__device__ __forceinline__ void stage_store(const d2 (&r)[8 * TS / NT], double* lds, int tid) {
 #pragma unroll
-    for (int i = 0; i < 1024 / NT; ++i) {
+    for (int i = 0; i < 8 * TS / NT; ++i) {
         const int c = tid + NT * i;
         if (!KM) {
             const int row = c >> 3, c16 = c & 7;
             *reinterpret_cast<d2*>(lds + row * LD_MK + c16 * 2) = r[i];
         } else {
-            const int krow = c >> 6, c16 = c & 63;
-            *reinterpret_cast<d2*>(lds + krow * LD_KM + c16 * 2) = r[i];
+            const int krow = c / (TS / 2), c16 = c % (TS / 2);
+            *reinterpret_cast<d2*>(lds + krow * (TS + 16) + c16 * 2) = r[i];
         }
     }
 }
 
-template <bool KM>
+template <bool KM, int TS>
 __device__ __forceinline__ double frag(const double* lds, int m0, int kk, int lane) {
-    // element (m = m0 + (lane&15), k = kk*4 + (lane>>4)) of the staged tile
+    // element (m = m0 + (lane&15), k = kk*4 + (lane>>4)) of the staged tile; both layouts are
+    // bank-conflict free for ds_read_b64: [TS][18] (18 % 32 == 18 -> rows spread), [16][TS+16]
     if (!KM) return lds[(m0 + (lane & 15)) * LD_MK + kk * 4 + (lane >> 4)];
-    return lds[(kk * 4 + (lane >> 4)) * LD_KM + m0 + (lane & 15)];
+    return lds[(kk * 4 + (lane >> 4)) * (TS + 16) + m0 + (lane & 15)];
 }
 
-// NW = waves per workgroup: 4 (2x2 waves of 64x64, bulk launches: two workgroups share a CU) or
-// 8 (4x2 waves of 32x64, for launches with at most one tile per CU: puts 2 waves on every SIMD,
-// which a single fp64-MFMA wave cannot saturate on its own).
-template <bool A_KM, bool B_KM, int EPI, int NW>
+// NW = waves per workgroup, TS = tile side per workgroup:
+//   (4, 128)  2x2 waves of 64x64: bulk launches, two workgroups share a CU
+//   (8, 128)  4x2 waves of 32x64: at most one tile per CU -> still two MFMA waves per SIMD (a lone
+//             fp64-MFMA wave issues only every ~140 cycles)
+//   (4, 64)   2x2 waves of 32x32 on a 64x64 quadrant: <= 64 tiles, each spread over four CUs
+template <bool A_KM, bool B_KM, int EPI, int NW, int TS>
 __global__ __launch_bounds__(NW * 64, 2) void gemm_tiles_kernel(GemmArgs g) {
-    constexpr int NT = NW * 64;          // threads
-    constexpr int MT = 16 / NW;          // 16x16 row-tiles per wave: 4 or 2
-    constexpr int WROWS = MT * 16;       // rows per wave: 64 or 32
-    __shared__ __attribute__((aligned(16))) double smem[4 * STAGE_ELEMS];
+    constexpr int NT = NW * 64;             // threads
+    constexpr int WGM = NW / 2;             // waves along m (2 along n)
+    constexpr int WROWS = TS / WGM;         // rows per wave
+    constexpr int WCOLS = TS / 2;           // cols per wave
+    constexpr int MT = WROWS / 16;          // 16x16 accumulators per wave: MT x NTL
+    constexpr int NTL = WCOLS / 16;
+    constexpr int STAGE = (TS * LD_MK > GEMM_BK * (TS + 16)) ? TS * LD_MK : GEMM_BK * (TS + 16);
+    constexpr int NCH = 8 * TS / NT;        // 16-byte chunks per thread per operand stage
+    __shared__ __attribute__((aligned(16))) double smem[4 * STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
 
@@ -82,9 +93,12 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_tiles_kernel(GemmArgs g) {
     //              tiles cost the same (SYRK-shaped trailing updates).
     //  chunk  > 0: the list is dealt to the XCDs round-robin in chunks of that many tiles (one 8x8
     //              patch), so lists sorted by decreasing k-range stay balanced across XCDs.
-    const int n = g.ntiles, b = blockIdx.x;
+    constexpr int QUADS = (128 / TS) * (128 / TS);      // workgroups per 128x128 tile
+    const int n = g.ntiles, b = blockIdx.x / QUADS, quad = blockIdx.x % QUADS;
     int p;
-    if (g.chunk == 0) {
+    if (QUADS > 1) {
+        p = b;
+    } else if (g.chunk == 0) {
         const int q = n >> 3, r = n & 7, x = b & 7, yy = b >> 3;
         p = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + yy;
     } else {
@@ -98,6 +112,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_tiles_kernel(GemmArgs g) {
     }
     const TileDesc t = g.tiles[p];
     const int nsteps = (t.kb1 - t.kb0) * (NB / GEMM_BK);
+    const int qi = (QUADS > 1) ? (quad >> 1) * TS : 0, qj = (QUADS > 1) ? (quad & 1) * TS : 0;
     // batch: blockIdx.y selects the problem; operands advance by their per-problem strides
     g.A += blockIdx.y * g.sA;
     g.B += blockIdx.y * g.sB;
@@ -105,68 +120,68 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_tiles_kernel(GemmArgs g) {
     if (g.colpart) g.colpart += blockIdx.y * g.sColpart;
 
     // operand origins (element units)
-    const int64_t a_m0 = (int64_t)(t.ci + (A_KM ? g.a_coff : g.a_roff)) * NB;
+    const int64_t a_m0 = (int64_t)(t.ci + (A_KM ? g.a_coff : g.a_roff)) * NB + qi;
     const int64_t a_k0 = (int64_t)(t.kb0 + (A_KM ? g.a_roff : g.a_coff)) * NB;
-    const int64_t b_n0 = (int64_t)(t.cj + (B_KM ? g.b_coff : g.b_roff)) * NB;
+    const int64_t b_n0 = (int64_t)(t.cj + (B_KM ? g.b_coff : g.b_roff)) * NB + qj;
     const int64_t b_k0 = (int64_t)(t.kb0 + (B_KM ? g.b_roff : g.b_coff)) * NB;
 
-    d4 acc[MT][4];
+    d4 acc[MT][NTL];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+        for (int j = 0; j < NTL; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
 
-    // krev: walk the k-range from its END.  Tiles of one 8x8 patch whose ranges share their upper
-    // end (K^-1 = L^-T L^-1: [ci, nb)) then sweep the same operand rows at the same time, so the
-    // panels they share are still in the XCD's L2 when the next tile asks for them.
+    // krev: walk the k-range from its END.  Tiles of one patch whose ranges share their upper end
+    // (K^-1 = L^-T L^-1: [ci, nb)) then sweep the same operand rows at the same time, so the panels
+    // they share are still in the XCD's L2 when the next tile asks for them.
     const int64_t kfirst = g.krev ? (int64_t)(nsteps - 1) * GEMM_BK : 0;
     const int64_t kstride = g.krev ? -GEMM_BK : GEMM_BK;
-    d2 ra[1024 / NT], rb[1024 / NT];
+    d2 ra[NCH], rb[NCH];
     if (nsteps > 0) {
-        stage_load<A_KM, NT>(ra, g.A, g.lda, a_m0, a_k0 + kfirst, tid);
-        stage_load<B_KM, NT>(rb, g.B, g.ldb, b_n0, b_k0 + kfirst, tid);
-        stage_store<A_KM, NT>(ra, smem, tid);
-        stage_store<B_KM, NT>(rb, smem + STAGE_ELEMS, tid);
+        stage_load<A_KM, NT, TS>(ra, g.A, g.lda, a_m0, a_k0 + kfirst, tid);
+        stage_load<B_KM, NT, TS>(rb, g.B, g.ldb, b_n0, b_k0 + kfirst, tid);
+        stage_store<A_KM, NT, TS>(ra, smem, tid);
+        stage_store<B_KM, NT, TS>(rb, smem + STAGE, tid);
     }
     __syncthreads();
 
     for (int s = 0; s < nsteps; ++s) {
-        const double* As = smem + (s & 1) * 2 * STAGE_ELEMS;
-        const double* Bs = As + STAGE_ELEMS;
+        const double* As = smem + (s & 1) * 2 * STAGE;
+        const double* Bs = As + STAGE;
         const bool more = (s + 1 < nsteps);
         if (more) {
-            stage_load<A_KM, NT>(ra, g.A, g.lda, a_m0, a_k0 + kfirst + (int64_t)(s + 1) * kstride, tid);
-            stage_load<B_KM, NT>(rb, g.B, g.ldb, b_n0, b_k0 + kfirst + (int64_t)(s + 1) * kstride, tid);
+            stage_load<A_KM, NT, TS>(ra, g.A, g.lda, a_m0, a_k0 + kfirst + (int64_t)(s + 1) * kstride, tid);
+            stage_load<B_KM, NT, TS>(rb, g.B, g.ldb, b_n0, b_k0 + kfirst + (int64_t)(s + 1) * kstride, tid);
         }
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            double a[MT], bb[4];
+            double a[MT], bb[NTL];
 #pragma unroll
-            for (int i = 0; i < MT; ++i) a[i] = frag<A_KM>(As, wm * WROWS + i * 16, kk, lane);
+            for (int i = 0; i < MT; ++i) a[i] = frag<A_KM, TS>(As, wm * WROWS + i * 16, kk, lane);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bb[j] = frag<B_KM>(Bs, wn * 64 + j * 16, kk, lane);
+            for (int j = 0; j < NTL; ++j) bb[j] = frag<B_KM, TS>(Bs, wn * WCOLS + j * 16, kk, lane);
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < NTL; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bb[j], acc[i][j], 0, 0, 0);
         }
         if (more) {
-            double* An = smem + ((s + 1) & 1) * 2 * STAGE_ELEMS;
-            stage_store<A_KM, NT>(ra, An, tid);
-            stage_store<B_KM, NT>(rb, An + STAGE_ELEMS, tid);
+            double* An = smem + ((s + 1) & 1) * 2 * STAGE;
+            stage_store<A_KM, NT, TS>(ra, An, tid);
+            stage_store<B_KM, NT, TS>(rb, An + STAGE, tid);
         }
         __syncthreads();
     }
 
     if (EPI == EPI_STORE) {
-        const int64_t crow0 = (int64_t)(t.ci + g.c_roff) * NB + wm * WROWS + (lane >> 4);
-        const int64_t ccol0 = (int64_t)(t.cj + g.c_coff) * NB + wn * 64 + (lane & 15);
+        const int64_t crow0 = (int64_t)(t.ci + g.c_roff) * NB + qi + wm * WROWS + (lane >> 4);
+        const int64_t ccol0 = (int64_t)(t.cj + g.c_coff) * NB + qj + wn * WCOLS + (lane & 15);
         const double alpha = g.alpha, beta = g.beta;
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < NTL; ++j)
 #pragma unroll
                 for (int rg = 0; rg < 4; ++rg) {
                     double* cp = g.C + (crow0 + i * 16 + 4 * rg) * g.ldc + ccol0 + j * 16;
@@ -175,10 +190,10 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_tiles_kernel(GemmArgs g) {
                     *cp = v;
                 }
     } else {
-        // column sums of squares of the 128x128 product tile -> colpart[ci][cj*128 + col]
-        double* red = smem;      // [NW/2][128]; all waves are past the last barrier of the k-loop
+        // column sums of squares of the 128x128 product tile -> colpart[ci][cj*128 + col]  (TS == 128)
+        double* red = smem;      // [WGM][128]; all waves are past the last barrier of the k-loop
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NTL; ++j) {
             double s = 0.0;
 #pragma unroll
             for (int i = 0; i < MT; ++i)
@@ -186,13 +201,13 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_tiles_kernel(GemmArgs g) {
                 for (int rg = 0; rg < 4; ++rg) s += acc[i][j][rg] * acc[i][j][rg];
             s += __shfl_xor(s, 16);
             s += __shfl_xor(s, 32);
-            if (lane < 16) red[wm * 128 + wn * 64 + j * 16 + lane] = s;
+            if (lane < 16) red[wm * 128 + wn * WCOLS + j * 16 + lane] = s;
         }
         __syncthreads();
         if (tid < 128) {
             double tot = 0.0;
 #pragma unroll
-            for (int w = 0; w < NW / 2; ++w) tot += red[w * 128 + tid];
+            for (int w = 0; w < WGM; ++w) tot += red[w * 128 + tid];
             g.colpart[(int64_t)t.ci * g.ld_colpart + (int64_t)(t.cj + g.c_coff) * NB + tid] = tot;
         }
     }
@@ -201,11 +216,18 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_tiles_kernel(GemmArgs g) {
 template <bool A_KM, bool B_KM, int EPI>
 static int launch_one(gpimhip_ctx* h, const GemmArgs& g) {
     if (g.ntiles <= 0) return GPIMHIP_OK;
-    // at most one tile per CU: use the 8-wave workgroup so every SIMD still holds two MFMA waves
-    if ((int64_t)g.ntiles * h->nbatch <= 256)
-        hipLaunchKernelGGL((gemm_tiles_kernel<A_KM, B_KM, EPI, 8>), dim3(g.ntiles, h->nbatch), dim3(512), 0, h->stream, g);
+    const int64_t total = (int64_t)g.ntiles * h->nbatch;
+    if (EPI == EPI_STORE && total <= 256 && !g.inplace && !getenv("GPIMHIP_NO_TILE64"))
+        // few tiles: spread each over four CUs (64x64 quadrants)
+        hipLaunchKernelGGL((gemm_tiles_kernel<A_KM, B_KM, EPI_STORE, 4, 64>), dim3(g.ntiles * 4, h->nbatch), dim3(256), 0,
+                           h->stream, g);
+    else if (total <= 256)
+        // at most one tile per CU: 8-wave workgroup so every SIMD still holds two MFMA waves
+        hipLaunchKernelGGL((gemm_tiles_kernel<A_KM, B_KM, EPI, 8, 128>), dim3(g.ntiles, h->nbatch), dim3(512), 0,
+                           h->stream, g);
     else
-        hipLaunchKernelGGL((gemm_tiles_kernel<A_KM, B_KM, EPI, 4>), dim3(g.ntiles, h->nbatch), dim3(256), 0, h->stream, g);
+        hipLaunchKernelGGL((gemm_tiles_kernel<A_KM, B_KM, EPI, 4, 128>), dim3(g.ntiles, h->nbatch), dim3(256), 0,
+                           h->stream, g);
     HIP_TRY(hipGetLastError());
     return GPIMHIP_OK;
 }

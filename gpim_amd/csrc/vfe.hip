@@ -17,6 +17,7 @@
 // factorisations and triangular inverses reuse the blocked drivers of the exact path.
 #include <string.h>
 #include <math.h>
+#include <stdlib.h>
 #include <algorithm>
 #include <map>
 #include <mutex>
@@ -639,6 +640,31 @@ int gpimhip_fit_vfe(gpimhip_handle h, const gpimhip_model_t* m, const double* X,
     }
     HIP_TRY(hipMemcpyAsync(h->bc, h->bc_host.data(), 2 * (size_t)T * sizeof(double), hipMemcpyHostToDevice, h->stream));
     VfeIter it{h->iter, h->bc, T, hist_theta, hist_xu, loss_out};
+    // every iteration is the same ~90 launches (iteration index and bias corrections live on the
+    // device): capture one into a hipGraph and replay it
+    if (T >= 8 && h->capture_stream && !getenv("GPIMHIP_NO_GRAPH")) {
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        hipStream_t main_s = h->stream;
+        h->stream = h->capture_stream;
+        hipError_t e = hipStreamBeginCapture(h->capture_stream, hipStreamCaptureModeRelaxed);
+        int rc = GPIMHIP_OK;
+        if (e == hipSuccess) {
+            rc = vfe_loss_grad(h, *w, m, X, N, Mu, u_inout, P, 1, &it, nullptr, nullptr);
+            e = hipStreamEndCapture(h->capture_stream, &graph);
+        }
+        h->stream = main_s;
+        if (rc != GPIMHIP_OK) { if (graph) hipGraphDestroy(graph); return rc; }
+        if (e == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+            for (int t = 0; t < T; ++t) HIP_TRY(hipGraphLaunch(exec, main_s));
+            rc = vfe_finish_and_check(h);
+            hipGraphExecDestroy(exec);
+            hipGraphDestroy(graph);
+            return rc;
+        }
+        if (graph) hipGraphDestroy(graph);
+        (void)hipGetLastError();
+    }
     for (int t = 0; t < T; ++t) GP_TRY(vfe_loss_grad(h, *w, m, X, N, Mu, u_inout, P, 1, &it, nullptr, nullptr));
     return vfe_finish_and_check(h);
 }
