@@ -69,21 +69,24 @@ __device__ __forceinline__ double frag(const double* lds, int m0, int kk, int la
     return lds[(kk * 4 + (lane >> 4)) * (TS + 16) + m0 + (lane & 15)];
 }
 
-// NW = waves per workgroup, TS = tile side per workgroup:
-//   (4, 128)  2x2 waves of 64x64: bulk launches, two workgroups share a CU
-//   (8, 128)  4x2 waves of 32x64: at most one tile per CU -> still two MFMA waves per SIMD (a lone
-//             fp64-MFMA wave issues only every ~140 cycles)
-//   (4, 64)   2x2 waves of 32x32 on a 64x64 quadrant: <= 64 tiles, each spread over four CUs
-template <bool A_KM, bool B_KM, int EPI, int NW, int TS>
+// NW = waves per workgroup, TSM x TSN = the part of a 128x128 tile one workgroup computes:
+//   (4, 128, 128)  2x2 waves of 64x64: bulk launches, two workgroups share a CU
+//   (8, 128, 128)  4x2 waves of 32x64: at most one tile per CU -> still two MFMA waves per SIMD (a
+//                  lone fp64-MFMA wave issues only every ~140 cycles)
+//   (4,  64,  64)  2x2 waves of 32x32 on a quadrant: few tiles, each spread over four CUs
+//   (8,  64, 128)  4x2 waves of 16x64 on a row half: in-place panel solves (a workgroup must own
+//                  whole rows of the tile it overwrites), each tile spread over two CUs
+template <bool A_KM, bool B_KM, int EPI, int NW, int TSM, int TSN>
 __global__ __launch_bounds__(NW * 64, 2) void gemm_tiles_kernel(GemmArgs g) {
     constexpr int NT = NW * 64;             // threads
     constexpr int WGM = NW / 2;             // waves along m (2 along n)
-    constexpr int WROWS = TS / WGM;         // rows per wave
-    constexpr int WCOLS = TS / 2;           // cols per wave
+    constexpr int WROWS = TSM / WGM;        // rows per wave
+    constexpr int WCOLS = TSN / 2;          // cols per wave
     constexpr int MT = WROWS / 16;          // 16x16 accumulators per wave: MT x NTL
     constexpr int NTL = WCOLS / 16;
-    constexpr int STAGE = (TS * LD_MK > GEMM_BK * (TS + 16)) ? TS * LD_MK : GEMM_BK * (TS + 16);
-    constexpr int NCH = 8 * TS / NT;        // 16-byte chunks per thread per operand stage
+    constexpr int TSX = TSM > TSN ? TSM : TSN;
+    constexpr int STAGE = (TSX * LD_MK > GEMM_BK * (TSX + 16)) ? TSX * LD_MK : GEMM_BK * (TSX + 16);
+    constexpr int NCHA = 8 * TSM / NT, NCHB = 8 * TSN / NT;   // 16-byte chunks per thread per stage
     __shared__ __attribute__((aligned(16))) double smem[4 * STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -93,7 +96,8 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_tiles_kernel(GemmArgs g) {
     //              tiles cost the same (SYRK-shaped trailing updates).
     //  chunk  > 0: the list is dealt to the XCDs round-robin in chunks of that many tiles (one 8x8
     //              patch), so lists sorted by decreasing k-range stay balanced across XCDs.
-    constexpr int QUADS = (128 / TS) * (128 / TS);      // workgroups per 128x128 tile
+    constexpr int QN = 128 / TSN;                       // workgroups per tile along n
+    constexpr int QUADS = (128 / TSM) * QN;             // workgroups per 128x128 tile
     const int n = g.ntiles, b = blockIdx.x / QUADS, quad = blockIdx.x % QUADS;
     int p;
     if (QUADS > 1) {
@@ -112,7 +116,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_tiles_kernel(GemmArgs g) {
     }
     const TileDesc t = g.tiles[p];
     const int nsteps = (t.kb1 - t.kb0) * (NB / GEMM_BK);
-    const int qi = (QUADS > 1) ? (quad >> 1) * TS : 0, qj = (QUADS > 1) ? (quad & 1) * TS : 0;
+    const int qi = (quad / QN) * TSM, qj = (quad % QN) * TSN;
     // batch: blockIdx.y selects the problem; operands advance by their per-problem strides
     g.A += blockIdx.y * g.sA;
     g.B += blockIdx.y * g.sB;
@@ -136,12 +140,12 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_tiles_kernel(GemmArgs g) {
     // they share are still in the XCD's L2 when the next tile asks for them.
     const int64_t kfirst = g.krev ? (int64_t)(nsteps - 1) * GEMM_BK : 0;
     const int64_t kstride = g.krev ? -GEMM_BK : GEMM_BK;
-    d2 ra[NCH], rb[NCH];
+    d2 ra[NCHA], rb[NCHB];
     if (nsteps > 0) {
-        stage_load<A_KM, NT, TS>(ra, g.A, g.lda, a_m0, a_k0 + kfirst, tid);
-        stage_load<B_KM, NT, TS>(rb, g.B, g.ldb, b_n0, b_k0 + kfirst, tid);
-        stage_store<A_KM, NT, TS>(ra, smem, tid);
-        stage_store<B_KM, NT, TS>(rb, smem + STAGE, tid);
+        stage_load<A_KM, NT, TSM>(ra, g.A, g.lda, a_m0, a_k0 + kfirst, tid);
+        stage_load<B_KM, NT, TSN>(rb, g.B, g.ldb, b_n0, b_k0 + kfirst, tid);
+        stage_store<A_KM, NT, TSM>(ra, smem, tid);
+        stage_store<B_KM, NT, TSN>(rb, smem + STAGE, tid);
     }
     __syncthreads();
 
@@ -150,16 +154,16 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_tiles_kernel(GemmArgs g) {
         const double* Bs = As + STAGE;
         const bool more = (s + 1 < nsteps);
         if (more) {
-            stage_load<A_KM, NT, TS>(ra, g.A, g.lda, a_m0, a_k0 + kfirst + (int64_t)(s + 1) * kstride, tid);
-            stage_load<B_KM, NT, TS>(rb, g.B, g.ldb, b_n0, b_k0 + kfirst + (int64_t)(s + 1) * kstride, tid);
+            stage_load<A_KM, NT, TSM>(ra, g.A, g.lda, a_m0, a_k0 + kfirst + (int64_t)(s + 1) * kstride, tid);
+            stage_load<B_KM, NT, TSN>(rb, g.B, g.ldb, b_n0, b_k0 + kfirst + (int64_t)(s + 1) * kstride, tid);
         }
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             double a[MT], bb[NTL];
 #pragma unroll
-            for (int i = 0; i < MT; ++i) a[i] = frag<A_KM, TS>(As, wm * WROWS + i * 16, kk, lane);
+            for (int i = 0; i < MT; ++i) a[i] = frag<A_KM, TSM>(As, wm * WROWS + i * 16, kk, lane);
 #pragma unroll
-            for (int j = 0; j < NTL; ++j) bb[j] = frag<B_KM, TS>(Bs, wn * WCOLS + j * 16, kk, lane);
+            for (int j = 0; j < NTL; ++j) bb[j] = frag<B_KM, TSN>(Bs, wn * WCOLS + j * 16, kk, lane);
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -168,8 +172,8 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_tiles_kernel(GemmArgs g) {
         }
         if (more) {
             double* An = smem + ((s + 1) & 1) * 2 * STAGE;
-            stage_store<A_KM, NT, TS>(ra, An, tid);
-            stage_store<B_KM, NT, TS>(rb, An + STAGE, tid);
+            stage_store<A_KM, NT, TSM>(ra, An, tid);
+            stage_store<B_KM, NT, TSN>(rb, An + STAGE, tid);
         }
         __syncthreads();
     }
@@ -190,7 +194,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_tiles_kernel(GemmArgs g) {
                     *cp = v;
                 }
     } else {
-        // column sums of squares of the 128x128 product tile -> colpart[ci][cj*128 + col]  (TS == 128)
+        // column sums of squares of the 128x128 product tile -> colpart[ci][cj*128 + col]  (full tiles only)
         double* red = smem;      // [WGM][128]; all waves are past the last barrier of the k-loop
 #pragma unroll
         for (int j = 0; j < NTL; ++j) {
@@ -217,16 +221,21 @@ template <bool A_KM, bool B_KM, int EPI>
 static int launch_one(gpimhip_ctx* h, const GemmArgs& g) {
     if (g.ntiles <= 0) return GPIMHIP_OK;
     const int64_t total = (int64_t)g.ntiles * h->nbatch;
-    if (EPI == EPI_STORE && total <= 256 && !g.inplace && !getenv("GPIMHIP_NO_TILE64"))
+    const bool small = total <= 256 && !getenv("GPIMHIP_NO_TILE64");
+    if (EPI == EPI_STORE && small && !g.inplace)
         // few tiles: spread each over four CUs (64x64 quadrants)
-        hipLaunchKernelGGL((gemm_tiles_kernel<A_KM, B_KM, EPI_STORE, 4, 64>), dim3(g.ntiles * 4, h->nbatch), dim3(256), 0,
-                           h->stream, g);
+        hipLaunchKernelGGL((gemm_tiles_kernel<A_KM, B_KM, EPI_STORE, 4, 64, 64>), dim3(g.ntiles * 4, h->nbatch),
+                           dim3(256), 0, h->stream, g);
+    else if (EPI == EPI_STORE && small)
+        // in-place panel solve: row halves (the workgroup owns the rows it overwrites), 8 waves
+        hipLaunchKernelGGL((gemm_tiles_kernel<A_KM, B_KM, EPI_STORE, 8, 64, 128>), dim3(g.ntiles * 2, h->nbatch),
+                           dim3(512), 0, h->stream, g);
     else if (total <= 256)
         // at most one tile per CU: 8-wave workgroup so every SIMD still holds two MFMA waves
-        hipLaunchKernelGGL((gemm_tiles_kernel<A_KM, B_KM, EPI, 8, 128>), dim3(g.ntiles, h->nbatch), dim3(512), 0,
+        hipLaunchKernelGGL((gemm_tiles_kernel<A_KM, B_KM, EPI, 8, 128, 128>), dim3(g.ntiles, h->nbatch), dim3(512), 0,
                            h->stream, g);
     else
-        hipLaunchKernelGGL((gemm_tiles_kernel<A_KM, B_KM, EPI, 4, 128>), dim3(g.ntiles, h->nbatch), dim3(256), 0,
+        hipLaunchKernelGGL((gemm_tiles_kernel<A_KM, B_KM, EPI, 4, 128, 128>), dim3(g.ntiles, h->nbatch), dim3(256), 0,
                            h->stream, g);
     HIP_TRY(hipGetLastError());
     return GPIMHIP_OK;
