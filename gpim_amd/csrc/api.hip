@@ -74,7 +74,6 @@ static void ws_release_matrix(gpimhip_ctx* h) {
     dev_free(h, &h->B, B * np * h->ld);
     dev_free(h, &h->Tm, B * np * h->ld);
     dev_free(h, &h->dinv, B * nb * NB * NB);
-    dev_free(h, &h->linv16, B * nb * 8 * 256);
     dev_free(h, &h->ypad, B * np);
     dev_free(h, &h->z, B * np);
     dev_free(h, &h->alpha, B * np);
@@ -105,7 +104,6 @@ static int ws_ensure_b(gpimhip_ctx* h, int64_t N, int B, int padded) {
     GP_TRY(dev_alloc(h, &h->Tm, B * np * ld));
     h->ld = ld;
     GP_TRY(dev_alloc(h, &h->dinv, B * nb * NB * NB));
-    GP_TRY(dev_alloc(h, &h->linv16, B * nb * 8 * 256));
     GP_TRY(dev_alloc(h, &h->ypad, B * np));
     GP_TRY(dev_alloc(h, &h->z, B * np));
     GP_TRY(dev_alloc(h, &h->alpha, B * np));

@@ -113,13 +113,16 @@ __device__ __forceinline__ void load_block(double* D, const double* __restrict__
 __device__ inline void lds_factor(double* D, double* invd, int npan, int* s_bad, int tid) {
     const int lane = tid & 63, wave = tid >> 6;
     const int ns = npan * 16;
+    // The 16x16 register Cholesky of the next diagonal tile is the serial part.  It is overlapped with
+    // the trailing update: wave 0 updates tile (p+1,p+1) first and goes straight on to factor it
+    // while waves 1..7 update the other tiles of the step.
+    if (wave == 0) {
+        const int bad = chol16(D, invd, lane);
+        if (lane == 0 && bad && *s_bad == 0) *s_bad = bad;
+    }
+    __syncthreads();
     for (int p = 0; p < npan; ++p) {
         const int c0 = p * 16;
-        if (wave == 0) {
-            const int bad = chol16(D + c0 * LDD + c0, invd + c0, lane);
-            if (lane == 0 && bad && *s_bad == 0) *s_bad = c0 + bad;
-        }
-        __syncthreads();
         // panel solve, one thread per row below the diagonal tile: x L16^T = a
         {
             const int row = c0 + 16 + tid;
@@ -145,10 +148,11 @@ __device__ inline void lds_factor(double* D, double* invd, int npan, int* s_bad,
             }
         }
         __syncthreads();
-        // trailing update of the lower tiles (rt >= ct > p)
+        // trailing update of the lower tiles (rt >= ct > p); tile q = 0 is (p+1, p+1)
         const int m = npan - 1 - p;
         const int ntile = m * (m + 1) / 2;
-        for (int q = wave; q < ntile; q += NTH / 64) {
+        const int nworkers = NTH / 64 - 1;
+        for (int q = (wave == 0) ? 0 : wave; q < ntile; q += (wave == 0) ? ntile : nworkers) {
             int i = (int)((sqrtf(8.0f * q + 1.0f) - 1.0f) * 0.5f);
             while (i * (i + 1) / 2 > q) --i;
             while ((i + 1) * (i + 2) / 2 <= q) ++i;
@@ -163,6 +167,11 @@ __device__ inline void lds_factor(double* D, double* invd, int npan, int* s_bad,
                 acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
             }
             tile_write(C, acc, lane);
+        }
+        if (wave == 0 && p + 1 < npan) {
+            const int c1 = c0 + 16;
+            const int bad = chol16(D + c1 * LDD + c1, invd + c1, lane);
+            if (lane == 0 && bad && *s_bad == 0) *s_bad = c1 + bad;
         }
         __syncthreads();
     }

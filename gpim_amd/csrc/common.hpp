@@ -89,7 +89,6 @@ struct gpimhip_ctx {
     double* B = nullptr;            // np x np : K^-1 (lower)
     double* Tm = nullptr;           // np x np : trtri temporary
     double* dinv = nullptr;         // nb x 128 x 128 inverses of diagonal blocks
-    double* linv16 = nullptr;       // nb x 8 x 16 x 16 inverses of the 16x16 diagonal sub-blocks
     double* ypad = nullptr;         // np
     double* z = nullptr;            // np  (L^-1 y)
     double* alpha = nullptr;        // np  (K^-1 y)

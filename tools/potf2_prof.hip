@@ -16,29 +16,12 @@ int main() {
         hipMemcpy(dA, A.data(), n * n * 8, hipMemcpyHostToDevice);
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         hipEventRecord(e0);
-        hipLaunchKernelGGL(potf2_kernel, dim3(1), dim3(512), 0, 0, dA, (int64_t)n, 0, l16, ld, info, 1, prof);
+        hipLaunchKernelGGL(potf2_kernel, dim3(1), dim3(512), 0, 0, dA, (int64_t)n, 0, dinv, ld, info, 1, prof);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         hipMemcpy(hp, prof, 32 * 8, hipMemcpyDeviceToHost);
-        printf("rep %d: %.1f us total; cycles: load %lld", rep, ms * 1e3, hp[1] - hp[0]);
-        long long chol = 0, solve = 0, trail = 0;
-        for (int p = 0; p < 8; ++p) {
-            chol += hp[3 + 3 * p] - hp[2 + 3 * p];
-            solve += hp[4 + 3 * p] - hp[3 + 3 * p];
-            trail += (p < 7 ? hp[5 + 3 * p] : hp[26]) - hp[4 + 3 * p];
-        }
-        printf(" | chol16 %lld solve %lld trail %lld | writeL+inv16+logdet %lld | all %lld\n",
-               chol, solve, trail, hp[27] - hp[26], hp[27] - hp[0]);
-        {
-            hipEventRecord(e0);
-            hipLaunchKernelGGL(inv128_kernel, dim3(1), dim3(512), 0, 0, dA, (int64_t)n, 0, l16, dinv, 1);
-            hipEventRecord(e1); hipEventSynchronize(e1);
-            float ms2; hipEventElapsedTime(&ms2, e0, e1);
-            printf("   inv128: %.1f us\n", ms2 * 1e3);
-        }
-        printf("   chol16 per panel:"); for (int p = 0; p < 8; ++p) printf(" %lld", hp[3 + 3 * p] - hp[2 + 3 * p]);
-        printf("\n   trail per panel:"); for (int p = 0; p < 8; ++p) printf(" %lld", (p < 7 ? hp[5 + 3 * p] : hp[26]) - hp[4 + 3 * p]);
-        printf("\n");
+        printf("rep %d: %.1f us total; cycles: load %lld | factor %lld | write L + logdet %lld | inverse %lld | write inverse %lld | all %lld\n",
+               rep, ms * 1e3, hp[1] - hp[0], hp[2] - hp[1], hp[3] - hp[2], hp[4] - hp[3], hp[5] - hp[4], hp[5] - hp[0]);
     }
     std::vector<double> L(n * n);
     hipMemcpy(L.data(), dA, n * n * 8, hipMemcpyDeviceToHost);
