@@ -527,7 +527,9 @@ int gpimhip_create(gpimhip_handle* out, int device, void* hip_stream) {
         if (h->panel_stream && hipGetDeviceProperties(&prop, device) == hipSuccess && !getenv("GPIMHIP_NO_CUMASK")) {
             const int ncu = prop.multiProcessorCount;
             std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
-            for (int c = RESERVED_CUS; c < ncu; ++c) mask[c / 32] |= (1u << (c % 32));
+            int reserved = RESERVED_CUS;
+            if (const char* e = getenv("GPIMHIP_RESERVED_CUS")) reserved = std::max(1, std::min(ncu / 2, atoi(e)));
+            for (int c = reserved; c < ncu; ++c) mask[c / 32] |= (1u << (c % 32));
             if (hipExtStreamCreateWithCUMask(&h->bulk_stream, (uint32_t)mask.size(), mask.data()) != hipSuccess)
                 h->bulk_stream = nullptr;
         }
