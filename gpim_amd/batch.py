@@ -26,8 +26,6 @@ def fit_predict_batch(Xs_list, ys_list, Xtest, kernel='RBF', lengthscale=None, l
     and predict each on the shared grid Xtest.  All problems must have the same number of
     observations.  Returns (mean, sd, hist): arrays (B, *Xtest.shape[1:]) and the hyper-parameter
     history (B, iterations, P) in the order [variance, lengthscale.., noise(, alpha)]."""
-    if kwargs.get("precision", "double") != "double":
-        raise NotImplementedError("gpim_amd: only precision='double' is implemented")
     H = handle or _lib.Handle()
     dev = H.device
     B = len(ys_list)

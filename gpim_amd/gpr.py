@@ -16,7 +16,10 @@ Deliberate differences from the reference, all on the outside of the numerics:
   * no process-global side effects: torch's default tensor type is left alone.
   * a non-positive-definite covariance is reported at the end of ``train``/``predict`` (the
     device loop runs without host synchronisation) instead of at the failing iteration.
-  * ``precision='single'`` is not implemented yet and raises.
+  * ``precision='single'``: inputs are taken, the initial hyper-parameters drawn and the results
+    returned in float32 like the reference does, but the arithmetic in between stays fp64 (the
+    engine has no fp32 path; results are at least as accurate as a float32 run, not bit-comparable
+    to one).
 """
 import ctypes
 import time
@@ -116,8 +119,7 @@ class reconstructor:
                  indpoints=None, learning_rate=5e-2, iterations=1000, use_gpu=False,
                  verbose=1, seed=0, **kwargs):
         self.precision = kwargs.get("precision", "double")
-        if self.precision != "double":
-            raise NotImplementedError("gpim_amd: only precision='double' is implemented")
+        self._np_out = np.float32 if self.precision == "single" else np.float64
         self._handle = _lib.Handle()          # raises if there is no GPU / no library
         self._dev = self._handle.device
         self.verbose = verbose
@@ -135,7 +137,9 @@ class reconstructor:
                                 jitter=kwargs.get("jitter", 1.0e-5))
         # drawn from a private generator seeded like the global one: identical numbers, no race when
         # several reconstructors are built from different threads
-        self._u = self._spec.draw_initial_u(torch.Generator().manual_seed(seed)).to(self._dev)
+        self._u = self._spec.draw_initial_u(
+            torch.Generator().manual_seed(seed),
+            torch.float32 if self.precision == "single" else _F64).to(self._dev)
         self._mstruct = self._spec.struct()
         self._n_ind = 0
         if self.do_sparse:
@@ -274,8 +278,8 @@ class reconstructor:
         _lib.check(rc)
         sd = var.sqrt()
         self._last_pred = (mean, sd)
-        mean_h = mean.cpu().numpy().reshape(self.fulldims)
-        sd_h = sd.cpu().numpy().reshape(self.fulldims)
+        mean_h = mean.cpu().numpy().reshape(self.fulldims).astype(self._np_out, copy=False)
+        sd_h = sd.cpu().numpy().reshape(self.fulldims).astype(self._np_out, copy=False)
         if self.verbose:
             print("Done")
         return mean_h, sd_h
@@ -289,6 +293,12 @@ class reconstructor:
         self.train(learning_rate=self.learning_rate, iterations=self.iterations)
         mean, sd = self.predict()
         return mean, sd, self.hyperparams
+
+    def step(self, *args, **kwargs):
+        """Dead code in the reference (gpr.py:285-329 calls ``gprutils.acquisition``, which does not
+        exist, and fails with AttributeError); use ``boptimizer`` for exploration steps."""
+        raise AttributeError("module 'gpim.gprutils' has no attribute 'acquisition' "
+                             "(reconstructor.step is dead code in the reference; use boptimizer)")
 
     # ------------------------------------------------------------------ operator-level hooks
     def loss_and_grad(self):

@@ -51,15 +51,18 @@ class KernelSpec:
         self.jitter = float(jitter)
         self.n_params = 2 + self.n_ls + (1 if kernel_type == "RationalQuadratic" else 0)
 
-    def draw_initial_u(self, generator=None):
+    def draw_initial_u(self, generator=None, dtype=_F64):
         """The two prior draws mapped to u.  generator: a torch CPU Generator (default: the global
         one, which the caller has just seeded like gpr.py:101 does); a private generator seeded
-        with the same value yields the same numbers and is safe under threads."""
-        alo, ahi = torch.tensor(self.amp_lo, dtype=_F64), torch.tensor(self.amp_hi, dtype=_F64)
-        v0 = alo + torch.rand((), dtype=_F64, generator=generator) * (ahi - alo)
+        with the same value yields the same numbers and is safe under threads.  dtype: the
+        precision the reference would draw in (float32 for precision='single'); u itself is
+        always float64."""
+        alo, ahi = torch.tensor(self.amp_lo, dtype=dtype), torch.tensor(self.amp_hi, dtype=dtype)
+        v0 = (alo + torch.rand((), dtype=dtype, generator=generator) * (ahi - alo)).to(_F64)
         shape = () if self.isotropic else (self.n_ls,)
-        l0 = self.ls_lo.reshape(shape) + torch.rand(shape, dtype=_F64, generator=generator) * (
-            self.ls_hi - self.ls_lo).reshape(shape)
+        lo_, hi_ = self.ls_lo.reshape(shape).to(dtype), self.ls_hi.reshape(shape).to(dtype)
+        l0 = (lo_ + torch.rand(shape, dtype=dtype, generator=generator) * (hi_ - lo_)).to(_F64)
+        alo, ahi = alo.to(_F64), ahi.to(_F64)
         u = torch.zeros(self.n_params, dtype=_F64)          # noise = exp(0) = 1, alpha_rq = exp(0) = 1
         u[0] = _logit_clipped((v0 - alo) / (ahi - alo))
         u[1:1 + self.n_ls] = _logit_clipped((l0.reshape(-1) - self.ls_lo) / (self.ls_hi - self.ls_lo))
@@ -88,8 +91,7 @@ class KernelSpec:
 
 def get_kernel(kernel_type, input_dim, lengthscale, use_gpu=False, **kwargs):
     """Same call shape as the reference's pyro_kernels.get_kernel; ``use_gpu`` is accepted
-    and ignored (the engine is GPU-only), ``precision`` must be 'double'."""
-    if kwargs.get("precision", "double") != "double":
-        raise NotImplementedError("gpim_amd implements the double-precision path")
+    and ignored (the engine is GPU-only); ``precision`` only affects the dtype of the initial
+    draw (see reconstructor)."""
     return KernelSpec(kernel_type, input_dim, lengthscale, amplitude=kwargs.get("amplitude"),
                       jitter=kwargs.get("jitter", 1e-5))

@@ -204,3 +204,36 @@ def test_boptim_sharded_candidates_single_rank(gpim, acqf, golden_dir, tmp_path)
     assert_allclose(bo.target_func_vals[-1], np.load(os.path.join(golden_dir, "test_%s.npy" % acqf)))
     assert [tuple(i) for i in bo.indices_all] == ORDER[acqf]
     assert bo.gp_predictions[0][0].shape == (25, 25)
+
+
+def test_precision_single_interface(gpim):
+    """precision='single': float32 in / float32 out and a float32 initial draw; arithmetic stays
+    fp64, so the result is close to (not bit-equal with) the double run started from that draw."""
+    R = gpr_dummy_data(2)
+    X, Xf = gpim.utils.get_sparse_grid(R), gpim.utils.get_full_grid(R)
+    kw = dict(kernel="RBF", learning_rate=0.1, iterations=5, verbose=0)
+    m32, s32, h32 = gpim.reconstructor(X, R, Xf, precision="single", **kw).run()
+    assert m32.dtype == np.float32 and s32.dtype == np.float32 and m32.shape == R.shape
+    assert np.isfinite(m32).all() and np.isfinite(s32).all() and len(h32["noise"]) == 5
+    torch.manual_seed(0)
+    v32 = 1e-4 + torch.rand((), dtype=torch.float32) * (10.0 - 1e-4)
+    rec = gpim.reconstructor(X, R, Xf, precision="single", iterations=0, verbose=0)
+    assert_allclose(rec.model.kernel.variance.item(), v32.item(), rtol=1e-6)
+
+
+def test_boptim_sparse_surrogate_and_dead_step(gpim, tmp_path):
+    """boptimizer(sparse=True) runs on the VFE surrogate (inducing inputs persist across the
+    posterior updates); reconstructor.step is dead code in the reference and raises here too."""
+    trial_func, Z_sparse = bo_test_problem()
+    rng = np.random.default_rng(0)
+    for i, j in rng.integers(0, 25, size=(40, 2)):
+        Z_sparse[i, j] = trial_func((i, j))
+    bo = gpim.boptimizer(gpim.utils.get_sparse_grid(Z_sparse), Z_sparse, gpim.utils.get_full_grid(Z_sparse),
+                         trial_func, acquisition_function="cb", exploration_steps=2, sparse=True, indpoints=15,
+                         gp_iterations=30, verbose=0, filename=str(tmp_path / "bo"))
+    bo.run()
+    assert len(bo.indices_all) == 2 and bo.gp_predictions[0][0].shape == (25, 25)
+    assert np.isfinite(bo.gp_predictions[-1][1]).all()
+    assert len(bo.surrogate_model.hyperparams["inducing_points"]) == 90
+    with pytest.raises(AttributeError):
+        bo.surrogate_model.step()
