@@ -61,7 +61,7 @@ static int dev_alloc(gpimhip_ctx* h, T** p, int64_t count) {
 template <typename T>
 static void dev_free(gpimhip_ctx* h, T** p, int64_t count) {
     if (*p) {
-        hipFree(*p);
+        (void)hipFree(*p);
         h->bytes -= count * (int64_t)sizeof(T);
         *p = nullptr;
     }
@@ -201,7 +201,7 @@ static int tri_build(int lo, int hi, std::vector<std::vector<TriNode>>& levels) 
 int plan_ensure(gpimhip_ctx* h, int nb) {
     LinalgPlan& P = h->plan;
     if (P.nb == nb) return GPIMHIP_OK;
-    if (P.d_tiles) { hipFree(P.d_tiles); P.d_tiles = nullptr; }
+    if (P.d_tiles) { (void)hipFree(P.d_tiles); P.d_tiles = nullptr; }
     std::vector<TileDesc> tl;
     auto mark = [&](size_t start) { return PlanRange{(int64_t)start, (int32_t)(tl.size() - start)}; };
     P.trsm.assign(nb, {0, 0});
@@ -415,10 +415,10 @@ struct StageTimer {
         if (!h->timing) return;
         hipEvent_t e0;
         if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { e1 = nullptr; return; }
-        hipEventRecord(e0, h->stream);
+        (void)hipEventRecord(e0, h->stream);
         h->ev[stage].push_back({e0, e1});
     }
-    ~StageTimer() { if (e1) hipEventRecord(e1, h->stream); }
+    ~StageTimer() { if (e1) (void)hipEventRecord(e1, h->stream); }
 };
 
 // N <= 128: the fused single-workgroup trainer (smalln.hip) replaces the blocked path
@@ -515,7 +515,7 @@ int gpimhip_create(gpimhip_handle* out, int device, void* hip_stream) {
     h->stream = (hipStream_t)hip_stream;     // NULL = the device's default (null) stream
     {
         int lo = 0, hi = 0;
-        hipDeviceGetStreamPriorityRange(&lo, &hi);   // hi = numerically lowest = highest priority
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // hi = numerically lowest = highest priority
         if (hipStreamCreateWithPriority(&h->panel_stream, hipStreamNonBlocking, hi) != hipSuccess)
             h->panel_stream = nullptr;               // fall back to the in-order schedule
         // The bulk trailing updates run on a stream whose CU mask leaves RESERVED_CUS compute units
@@ -540,15 +540,15 @@ int gpimhip_create(gpimhip_handle* out, int device, void* hip_stream) {
         delete h;
         return rc;
     }
-    hipMemsetAsync(h->info, 0, 4 * sizeof(int32_t), h->stream);
+    (void)hipMemsetAsync(h->info, 0, 4 * sizeof(int32_t), h->stream);
     *out = h;
     return GPIMHIP_OK;
 }
 
 int gpimhip_destroy(gpimhip_handle h) {
     if (!h) return GPIMHIP_OK;
-    hipSetDevice(h->device);
-    hipStreamSynchronize(h->stream);
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
     vfe_release(h);
     ws_release_matrix(h);
     dev_free(h, &h->Ks, h->ks_batch * h->ks_rows * (h->ks_cols + 16));
@@ -560,11 +560,11 @@ int gpimhip_destroy(gpimhip_handle h) {
     dev_free(h, &h->theta1, 1);
     dev_free(h, &h->scratch, 4 * MAXP);
     dev_free(h, &h->info, 4);
-    if (h->plan.d_tiles) hipFree(h->plan.d_tiles);
-    for (auto e : h->ev_pool) hipEventDestroy(e);
-    if (h->panel_stream) hipStreamDestroy(h->panel_stream);
-    if (h->bulk_stream) hipStreamDestroy(h->bulk_stream);
-    if (h->capture_stream) hipStreamDestroy(h->capture_stream);
+    if (h->plan.d_tiles) (void)hipFree(h->plan.d_tiles);
+    for (auto e : h->ev_pool) (void)hipEventDestroy(e);
+    if (h->panel_stream) (void)hipStreamDestroy(h->panel_stream);
+    if (h->bulk_stream) (void)hipStreamDestroy(h->bulk_stream);
+    if (h->capture_stream) (void)hipStreamDestroy(h->capture_stream);
     delete h;
     return GPIMHIP_OK;
 }
@@ -583,10 +583,10 @@ int gpimhip_timing_read(gpimhip_handle h, int stage, double* total_ms, int64_t* 
     double tot = 0.0;
     for (auto& pr : h->ev[stage]) {
         float ms = 0.f;
-        hipEventElapsedTime(&ms, pr.first, pr.second);
+        (void)hipEventElapsedTime(&ms, pr.first, pr.second);
         tot += ms;
-        hipEventDestroy(pr.first);
-        hipEventDestroy(pr.second);
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
     }
     *total_ms = tot;
     *count = (int64_t)h->ev[stage].size();
@@ -672,15 +672,15 @@ static int fit_impl(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X, i
             e = hipStreamEndCapture(h->capture_stream, &graph);
         }
         h->stream = main_s;
-        if (rc != GPIMHIP_OK) { if (graph) hipGraphDestroy(graph); return rc; }
+        if (rc != GPIMHIP_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
         if (e == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
             for (int t = 0; t < T; ++t) HIP_TRY(hipGraphLaunch(exec, main_s));
             rc = finish_and_check(h);
-            hipGraphExecDestroy(exec);
-            hipGraphDestroy(graph);
+            (void)hipGraphExecDestroy(exec);
+            (void)hipGraphDestroy(graph);
             return rc;
         }
-        if (graph) hipGraphDestroy(graph);
+        if (graph) (void)hipGraphDestroy(graph);
         (void)hipGetLastError();                        // capture unavailable: plain launches below
     }
     for (int t = 0; t < T; ++t)

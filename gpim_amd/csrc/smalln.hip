@@ -34,7 +34,6 @@ __global__ __launch_bounds__(NTH, 1) void fit_small_kernel(SmallFitArgs a) {
     __shared__ double xs[NB][5];          // scaled coordinates + squared norm
     __shared__ double yv[NB], zv[NB], al[NB], invd[NB];
     __shared__ double red[NTH / 64][8];
-    __shared__ double S[8];
     __shared__ ThetaDev sth;
     __shared__ double su[MAXP], sm_[MAXP], sv_[MAXP];
     __shared__ int s_bad;

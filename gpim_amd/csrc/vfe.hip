@@ -83,7 +83,7 @@ static void vfe_free(VfeWs& w) {
                   w.part_rect, w.part_sym, w.xu_rect, w.xu_sym, w.adam_m, w.adam_v, w.tiles, w.Ks, w.Ws, w.LW,
                   w.ptiles};
     for (void* p : ps)
-        if (p) hipFree(p);
+        if (p) (void)hipFree(p);
     w = VfeWs();
 }
 void vfe_release(gpimhip_ctx* h) {
@@ -356,7 +356,7 @@ __device__ double vfe_block_sum(double v, double* red) {
 
 __global__ __launch_bounds__(256) void vfe_finalize_kernel(VfeFinalArgs a) {
     __shared__ double red[256];
-    __shared__ double R[8], Q[8], sc[8];
+    __shared__ double R[8], Q[8];
     __shared__ AdamStep sst;
     __shared__ int s_it;
     const int tid = threadIdx.x;
@@ -626,7 +626,7 @@ int gpimhip_fit_vfe(gpimhip_handle h, const gpimhip_model_t* m, const double* X,
     // Adam bias-correction table (same libm pow() values as every other path)
     if (h->bc_cap < 2 * (int64_t)T) {
         HIP_TRY(hipStreamSynchronize(h->stream));
-        if (h->bc) { hipFree(h->bc); h->bytes -= h->bc_cap * (int64_t)sizeof(double); h->bc = nullptr; }
+        if (h->bc) { (void)hipFree(h->bc); h->bytes -= h->bc_cap * (int64_t)sizeof(double); h->bc = nullptr; }
         void* q = nullptr;
         if (hipMalloc(&q, 2 * (size_t)T * sizeof(double)) != hipSuccess) return GPIMHIP_E_NOMEM;
         h->bc = (double*)q;
@@ -654,15 +654,15 @@ int gpimhip_fit_vfe(gpimhip_handle h, const gpimhip_model_t* m, const double* X,
             e = hipStreamEndCapture(h->capture_stream, &graph);
         }
         h->stream = main_s;
-        if (rc != GPIMHIP_OK) { if (graph) hipGraphDestroy(graph); return rc; }
+        if (rc != GPIMHIP_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
         if (e == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
             for (int t = 0; t < T; ++t) HIP_TRY(hipGraphLaunch(exec, main_s));
             rc = vfe_finish_and_check(h);
-            hipGraphExecDestroy(exec);
-            hipGraphDestroy(graph);
+            (void)hipGraphExecDestroy(exec);
+            (void)hipGraphDestroy(graph);
             return rc;
         }
-        if (graph) hipGraphDestroy(graph);
+        if (graph) (void)hipGraphDestroy(graph);
         (void)hipGetLastError();
     }
     for (int t = 0; t < T; ++t) GP_TRY(vfe_loss_grad(h, *w, m, X, N, Mu, u_inout, P, 1, &it, nullptr, nullptr));
@@ -684,10 +684,10 @@ int gpimhip_predict_vfe(gpimhip_handle h, const gpimhip_model_t* m, const double
     int64_t mc = std::min<int64_t>(pad_to(M, NB), std::max<int64_t>(NB, ((int64_t)1 << 26) / mp / NB * NB));
     if (w.mc != mc) {
         HIP_TRY(hipStreamSynchronize(h->stream));
-        if (w.Ks) hipFree(w.Ks);
-        if (w.Ws) hipFree(w.Ws);
-        if (w.LW) hipFree(w.LW);
-        if (w.ptiles) hipFree(w.ptiles);
+        if (w.Ks) (void)hipFree(w.Ks);
+        if (w.Ws) (void)hipFree(w.Ws);
+        if (w.LW) (void)hipFree(w.LW);
+        if (w.ptiles) (void)hipFree(w.ptiles);
         w.Ks = w.Ws = w.LW = nullptr; w.ptiles = nullptr; w.mc = 0;
         GP_TRY(valloc(&w.Ks, mp * mc)); GP_TRY(valloc(&w.Ws, mp * mc)); GP_TRY(valloc(&w.LW, mp * mc));
         std::vector<TileDesc> tl;
