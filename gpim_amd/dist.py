@@ -106,30 +106,45 @@ def run_units(units, unit_fn, out_shape, device=None, concurrency=1):
 
 
 def reconstruct_slices(cube, axis=-1, batch=16, return_hyperparams=False, **recon_kwargs):
-    """Independent 2D GP reconstruction of every slice of a 3D cube along `axis` (config C3 of
-    SURVEY 8(d)).  Slices are sharded over the ranks; on each GPU the owned slices with the same
+    """Independent GP reconstruction of every slice of a 3D / 4D cube along `axis` (configs C3 and
+    C5 of SURVEY 8(d)).  Slices are sharded over the ranks; on each GPU the owned slices with the same
     number of observations advance in lock-step, `batch` at a time, through the batched engine
     (gpim_amd.batch) -- a single ~1000-point fit is latency-bound and leaves most of the chip idle.
     Per-slice results are those of ``reconstructor(X_slice, R_slice, X_full, **recon_kwargs).run()``.
     Returns (mean, sd) cubes on rank 0 (None elsewhere)."""
     from . import gprutils
     from .batch import fit_predict_batch
+    from .gpr import reconstructor
     cube = np.moveaxis(np.asarray(cube), axis, 0)
     nunits = cube.shape[0]
     rank, ws = world()
     dev = torch.device("cuda", torch.cuda.current_device())
     owned = shard_units(nunits, rank, ws)
     Xf = gprutils.get_full_grid(cube[0])
-    by_n = {}
-    for i in owned:
-        by_n.setdefault(int(np.count_nonzero(~np.isnan(cube[i]))), []).append(i)
     mine, hyper = {}, {}
     recon_kwargs = dict(recon_kwargs)
     recon_kwargs.pop("verbose", None)
+
+    def grid_of(R):
+        # fully observed slices have no NaN pattern to encode (get_sparse_grid refuses them)
+        return gprutils.get_sparse_grid(R) if np.isnan(R).any() else gprutils.get_full_grid(R)
+
+    if recon_kwargs.get("sparse"):
+        # inducing-point models (config C5: slices of a 4D cube): one reconstructor per slice
+        for i in owned:
+            rec = reconstructor(grid_of(cube[i]), cube[i], Xf, verbose=0, **recon_kwargs)
+            rec.train()
+            rec.predict()
+            mine[i] = torch.stack(list(rec._last_pred)).reshape((2,) + tuple(cube.shape[1:]))
+            hyper[i] = rec.hyperparams
+        owned = []
+    by_n = {}
+    for i in owned:
+        by_n.setdefault(int(np.count_nonzero(~np.isnan(cube[i]))), []).append(i)
     for n_obs, idxs in sorted(by_n.items()):
         for s in range(0, len(idxs), batch):
             grp = idxs[s:s + batch]
-            Xs = [gprutils.get_sparse_grid(cube[i]) for i in grp]
+            Xs = [grid_of(cube[i]) for i in grp]
             mean, sd, hist = fit_predict_batch(Xs, [cube[i] for i in grp], Xf, **recon_kwargs)
             for k, i in enumerate(grp):
                 mine[i] = torch.stack([mean[k], sd[k]])

@@ -114,3 +114,23 @@ def test_sparse_default_indpoints_and_3d(gpim):
     mo, so = orc.predict()
     assert_allclose(m, mo, atol=1e-7)
     assert_allclose(s, so, atol=1e-7)
+
+
+def test_c5_shaped_4d_cube_slices_sparse(gpim):
+    """Config C5 in miniature: a 4D cube, one sparse-VFE GP per slice along the last axis (3D slices,
+    fully observed), each equal to a stand-alone reconstructor(sparse=True) and close to the oracle."""
+    from gpim_amd import dist as gd
+    rng = np.random.default_rng(5)
+    i, j, v = np.meshgrid(np.arange(6), np.arange(5), np.arange(8), indexing="ij")
+    cube = np.stack([np.sin(i / 2.0 + s) * np.cos(j / 2.0) * np.exp(-((v - 4.0) / 3.0) ** 2) for s in range(3)], -1)
+    cube = cube + 0.01 * rng.standard_normal(cube.shape)
+    kw = dict(kernel="RBF", sparse=True, indpoints=24, learning_rate=0.05, iterations=20)
+    mean, sd = gd.reconstruct_slices(cube, axis=-1, **kw)
+    assert mean.shape == cube.shape and np.isfinite(mean).all() and np.isfinite(sd).all()
+    R = cube[..., 1]
+    Xf = gpim.utils.get_full_grid(R)
+    m1, s1, _ = gpim.reconstructor(Xf, R, Xf, verbose=0, **kw).run()
+    np.testing.assert_array_equal(mean[..., 1], m1)
+    mo, so, _ = O.reconstructor(Xf, R, Xf, verbose=0, **kw).run()
+    assert_allclose(mean[..., 1], mo, atol=1e-7)
+    assert_allclose(sd[..., 1], so, atol=1e-7)
