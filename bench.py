@@ -14,7 +14,7 @@ N > 1   : one process per GPU (torchrun contract); every rank reconstructs its o
           stack (seed = rank) -- independent units, no collective on the data path -- and the
           (mean, sd) maps are gathered to rank 0 over RCCL inside the timed region.  Weak scaling.
 roofline: the dominant kernel is the fp64 MFMA tile engine; the instance timed live with HIP
-          events is the K^-1 = L^-T L^-1 launch (gemm_tiles_kernel<true,true,0>, exactly one
+          events is the K^-1 = L^-T L^-1 launch (gemm_tiles_kernel<true, true, 0, 4, 128, 128>, exactly one
           launch per Adam iteration, algorithmic N^3/3 flop), priced against the fp64 matrix
           peak of 78.6 TFLOP/s.
 cpu_baseline: the CPU oracle (torch fp64 + autograd restatement of the reference, kind "port")
@@ -184,7 +184,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": (achieved / FP64_MFMA_PEAK_TFLOPS) if achieved else None,
                          "traffic": traffic,
-                         "kernel": "gemm_tiles_kernel<true,true,0> (K^-1 = L^-T L^-1, N^3/3 flop per launch)",
+                         "kernel": "gemm_tiles_kernel<true, true, 0, 4, 128, 128> (K^-1 = L^-T L^-1, N^3/3 flop per launch)",
                          "launches": lau_n, "avg_launch_ms": lau_ms / max(lau_n, 1)},
             "stages_ms_per_call": {k: (v[0] / v[1] if v[1] else None) for k, v in stage_ms.items()},
         }
