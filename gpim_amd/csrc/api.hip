@@ -535,8 +535,7 @@ int gpimhip_create(gpimhip_handle* out, int device, void* hip_stream) {
         }
     }
     int rc = GPIMHIP_OK;
-    if ((rc = dev_alloc(h, &h->theta1, 1)) || (rc = dev_alloc(h, &h->scratch, 4 * MAXP)) ||
-        (rc = dev_alloc(h, &h->info, 4))) {
+    if ((rc = dev_alloc(h, &h->theta1, 1)) || (rc = dev_alloc(h, &h->info, 4))) {
         delete h;
         return rc;
     }
@@ -558,7 +557,6 @@ int gpimhip_destroy(gpimhip_handle h) {
     dev_free(h, &h->keys, h->keys_cap);
     dev_free(h, &h->bc, h->bc_cap);
     dev_free(h, &h->theta1, 1);
-    dev_free(h, &h->scratch, 4 * MAXP);
     dev_free(h, &h->info, 4);
     if (h->plan.d_tiles) (void)hipFree(h->plan.d_tiles);
     for (auto e : h->ev_pool) (void)hipEventDestroy(e);

@@ -94,13 +94,11 @@ struct gpimhip_ctx {
     double* alpha = nullptr;        // np  (K^-1 y)
     double* logdet_part = nullptr;  // nb
     double* grad_part = nullptr;    // ntiles_lower x 8
-    double* quad_part = nullptr;    // nb
     ThetaDev* theta = nullptr;      // [ws_batch]
     ThetaDev* theta1 = nullptr;     // single struct for the operator-level gpimhip_kmat
     int32_t* iter = nullptr;        // [ws_batch] device-side iteration counters
     double* adam_m = nullptr;       // MAXP
     double* adam_v = nullptr;       // MAXP
-    double* scratch = nullptr;      // small: loss, grad (MAXP+1)
     int32_t* info = nullptr;        // potrf status word
     // prediction workspace
     int64_t ks_rows = 0, ks_cols = 0, ks_batch = 0;

@@ -237,3 +237,22 @@ def test_boptim_sparse_surrogate_and_dead_step(gpim, tmp_path):
     assert len(bo.surrogate_model.hyperparams["inducing_points"]) == 90
     with pytest.raises(AttributeError):
         bo.surrogate_model.step()
+
+
+@pytest.mark.parametrize("n_obs", [1, 2, 3])
+def test_tiny_training_sets(gpim, n_obs):
+    """One to three observations (a BO run can start from a single seed) and a single test point."""
+    Z = np.full((6, 7), np.nan)
+    pts = [(1, 2), (4, 5), (2, 6)][:n_obs]
+    for k, p in enumerate(pts):
+        Z[p] = 0.3 + 0.2 * k
+    X, Xf = gpim.utils.get_sparse_grid(Z), gpim.utils.get_full_grid(Z)
+    kw = dict(kernel="RBF", learning_rate=0.05, iterations=20, verbose=0, jitter=1e-6)
+    mean, sd, hyper = gpim.reconstructor(X, Z, Xf, **kw).run()
+    mo, so, ho = O.reconstructor(X, Z, Xf, **kw).run()
+    assert_allclose(mean, mo, atol=1e-10)
+    assert_allclose(sd, so, atol=1e-10)
+    assert_allclose(hyper["noise"], ho["noise"], rtol=1e-10)
+    rec = gpim.reconstructor(X, Z, Xf, **kw)
+    m1, s1 = rec.predict(Xf[:, 3:4, 2:3])
+    assert m1.shape == (1, 1) and np.isfinite(m1).all() and np.isfinite(s1).all()
