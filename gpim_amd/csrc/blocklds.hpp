@@ -17,68 +17,195 @@ __device__ __forceinline__ double bcast_lane(double v, int srclane) {
     return __hiloint2double(hi, lo);
 }
 
-// 16x16 lower Cholesky by lanes 0..15 of one wave; D points at the (c0,c0) corner (stride LDD).
-// Writes L16 (lower) back and 1/L_jj to invd[0..15].  Returns 0 or 1 + first bad local column.
+// DPP lane permutation inside 16-lane rows (0xB1 / 0x4E: quad_perm xor 1 / xor 2, 0x141: row_half_mirror,
+// 0x140: row_mirror) -- VALU moves, no LDS crossbar round trip as with ds_bpermute (__shfl_xor)
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double quad_sum(double v) {
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    return v;
+}
+// sum over the 64 lanes, wave-uniform result, fixed order
+__device__ __forceinline__ double wave_sum(double v) {
+    v = quad_sum(v);
+    v += dpp_mov<0x141>(v);
+    v += dpp_mov<0x140>(v);
+    return (bcast_lane(v, 0) + bcast_lane(v, 16)) + (bcast_lane(v, 32) + bcast_lane(v, 48));
+}
+
+// sqrt(d) and 1/sqrt(d): v_rsq_f64 seed + two Newton steps on both (a third of the dependent
+// instruction chain of sqrt() followed by a divide)
+__device__ __forceinline__ void sqrt_rsqrt(double d, double& l, double& inv) {
+    inv = __builtin_amdgcn_rsq(d);
+    l = d * inv;
+    l = fma(0.5 * inv, fma(-l, l, d), l);
+    inv = fma(inv, fma(-l, inv, 1.0), inv);
+    l = fma(0.5 * inv, fma(-l, l, d), l);
+    inv = fma(inv, fma(-l, inv, 1.0), inv);
+}
+
+__device__ __forceinline__ double pick4(double v0, double v1, double v2, double v3, int i) {
+    double r = v0;
+    r = (i == 1) ? v1 : r;
+    r = (i == 2) ? v2 : r;
+    r = (i == 3) ? v3 : r;
+    return r;
+}
+
+// 16x16 lower Cholesky by one full wave; D points at the (c0,c0) corner (stride LDD, lower part
+// valid).  Writes L16 (lower) back and 1/L_jj to invd_out[0..15]; returns 0 or 1 + first bad
+// local column (wave-uniform).
+//
+// The tile lives in the MFMA accumulator layout of the symmetric matrix: lane l, register g holds
+// A[l&15][4g + (l>>4)], so register g *is* the 16x4 column panel g in f64 16x16x4 operand layout.
+// Per panel: the 4x4 diagonal block is factored and inverted in wave-uniform scalars (10 readlanes),
+// one MFMA forms the panel  L_p^T = W A_p^T  (W = L4^-1) and one MFMA applies  A -= L_p L_p^T.
 __device__ __forceinline__ int chol16(double* D, double* invd_out, int lane) {
-    const int r = lane & 15;
-    double a[16];
+    const int r = lane & 15, kq = lane >> 4, p = r & 3;
+    d4 acc, Lf;
 #pragma unroll
-    for (int c = 0; c < 16; ++c) a[c] = D[r * LDD + c];
+    for (int g = 0; g < 4; ++g) {
+        const int c = kq + 4 * g;
+        acc[g] = D[(r > c ? r : c) * LDD + (r > c ? c : r)];
+    }
     int bad = 0;
-    double myinv = 0.0;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const double djj = bcast_lane(a[j], j);
-        if (!(djj > 0.0) && bad == 0) bad = j + 1;
-        // 1/sqrt(d): v_rsq_f64 seed + Newton on both l = sqrt(d) and 1/l (a third of the dependent
-        // instruction chain of sqrt() followed by a divide)
-        double inv = __builtin_amdgcn_rsq(djj);
-        double ljj = djj * inv;
-        ljj = fma(0.5 * inv, fma(-ljj, ljj, djj), ljj);
-        inv = fma(inv, fma(-ljj, inv, 1.0), inv);
-        ljj = fma(0.5 * inv, fma(-ljj, ljj, djj), ljj);
-        inv = fma(inv, fma(-ljj, inv, 1.0), inv);
-        if (r == j) myinv = inv;
-        a[j] = (r == j) ? ljj : a[j] * inv;
-#pragma unroll
-        for (int c = j + 1; c < 16; ++c) {
-            const double lcj = bcast_lane(a[j], c);
-            a[c] = fma(-a[j], lcj, a[c]);
+    for (int jb = 0; jb < 4; ++jb) {
+        const double P = acc[jb];
+        const int b0 = 4 * jb;
+        // A'[b0+i][b0+q] sits in lane (b0+i) + 16 q
+        const double a00 = bcast_lane(P, b0), a10 = bcast_lane(P, b0 + 1), a20 = bcast_lane(P, b0 + 2),
+                     a30 = bcast_lane(P, b0 + 3), a11 = bcast_lane(P, b0 + 17), a21 = bcast_lane(P, b0 + 18),
+                     a31 = bcast_lane(P, b0 + 19), a22 = bcast_lane(P, b0 + 34), a32 = bcast_lane(P, b0 + 35),
+                     a33 = bcast_lane(P, b0 + 51);
+        double l00, l11, l22, l33, i0, i1, i2, i3;
+        sqrt_rsqrt(a00, l00, i0);
+        const double l10 = a10 * i0, l20 = a20 * i0, l30 = a30 * i0;
+        const double d1 = fma(-l10, l10, a11);
+        sqrt_rsqrt(d1, l11, i1);
+        const double l21 = fma(-l20, l10, a21) * i1, l31 = fma(-l30, l10, a31) * i1;
+        const double d2 = fma(-l21, l21, fma(-l20, l20, a22));
+        sqrt_rsqrt(d2, l22, i2);
+        const double l32 = fma(-l31, l21, fma(-l30, l20, a32)) * i2;
+        const double d3 = fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, a33)));
+        sqrt_rsqrt(d3, l33, i3);
+        if (bad == 0) {
+            if (!(a00 > 0.0)) bad = b0 + 1;
+            else if (!(d1 > 0.0)) bad = b0 + 2;
+            else if (!(d2 > 0.0)) bad = b0 + 3;
+            else if (!(d3 > 0.0)) bad = b0 + 4;
+        }
+        // W = L4^-1
+        const double w10 = -i1 * (l10 * i0), w21 = -i2 * (l21 * i1), w32 = -i3 * (l32 * i2);
+        const double w20 = -i2 * fma(l21, w10, l20 * i0), w31 = -i3 * fma(l32, w21, l31 * i1);
+        const double w30 = -i3 * fma(l32, w20, fma(l31, w10, l30 * i0));
+        // operand A of the panel MFMA: rows m = r < 4 of W, column k = kq
+        const double wsel = pick4(pick4(i0, w10, w20, w30, p), pick4(0.0, i1, w21, w31, p),
+                                  pick4(0.0, 0.0, i2, w32, p), (p == 3) ? i3 : 0.0, kq);
+        const d4 res = __builtin_amdgcn_mfma_f64_16x16x4f64((r < 4) ? wsel : 0.0, P, (d4){0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
+        // rows of the diagonal block take the scalar factor itself; rows above it are zero
+        const double lsel = pick4(pick4(l00, l10, l20, l30, p), pick4(0.0, l11, l21, l31, p),
+                                  pick4(0.0, 0.0, l22, l32, p), (p == 3) ? l33 : 0.0, kq);
+        double Lp = res[0];
+        Lp = ((r >> 2) == jb) ? lsel : Lp;
+        Lp = ((r >> 2) < jb) ? 0.0 : Lp;
+        Lf[jb] = Lp;
+        if (jb < 3) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Lp, Lp, acc, 0, 0, 0);
+        if (lane == 0) {
+            invd_out[b0] = i0;
+            invd_out[b0 + 1] = i1;
+            invd_out[b0 + 2] = i2;
+            invd_out[b0 + 3] = i3;
         }
     }
-    if (lane < 16) {
 #pragma unroll
-        for (int c = 0; c < 16; ++c)
-            if (c <= r) D[r * LDD + c] = a[c];
-        invd_out[r] = myinv;
+    for (int jb = 0; jb < 4; ++jb) {
+        const int c = 4 * jb + kq;
+        if (c <= r) D[r * LDD + c] = Lf[jb];
     }
     return bad;
 }
 
-// inverse of a 16x16 lower-triangular block held row-per-lane: lane c builds column c of X = L^-1
-//   X[r][c] = (delta_rc - sum_{k<r} L[r][k] X[k][c]) / L[r][r]
+// Inverse of a 16x16 lower-triangular block by one full wave: X = L^-1 written as a full tile
+// (zeros above the diagonal).  `out` may alias `L`.
+//
+// Recursive doubling on MFMA.  R(M)[s] = M[l&15][4s+(l>>4)] is the A-operand layout of k-step s,
+// C(M)[g] = M[(l>>4)+4g][l&15] the B-operand / accumulator layout; R(M) == C(M^T).  Level 0: every
+// lane back-substitutes the two columns of its own 4x4 diagonal block it needs.  Each level then is
+// X <- X - X (M X) with M the sub-diagonal blocks absorbed at that level; level 1 is also run
+// transposed so that level 2 has X in both layouts.
 __device__ __forceinline__ void trinv16(const double* L, int ldl, const double* invd, double* out, int ldo,
                                         int lane) {
-    const int r = lane & 15;
-    double a[16];
+    const int r = lane & 15, kq = lane >> 4, cb = r >> 2, p = r & 3;
+    const d4 zero = (d4){0.0, 0.0, 0.0, 0.0};
+    d4 RL, CL;
 #pragma unroll
-    for (int c = 0; c < 16; ++c) a[c] = (c <= r) ? L[r * ldl + c] : 0.0;
-    const double myinv = invd[r];
-    double xc[16];
-#pragma unroll
-    for (int rr = 0; rr < 16; ++rr) {
-        double s = (rr == r) ? 1.0 : 0.0;
-#pragma unroll
-        for (int k = 0; k < rr; ++k) {
-            const double lrk = bcast_lane(a[k], rr);
-            s = fma(-lrk, xc[k], s);
-        }
-        xc[rr] = s * bcast_lane(myinv, rr);
+    for (int s = 0; s < 4; ++s) {
+        const int c = 4 * s + kq;
+        RL[s] = (c <= r) ? L[r * ldl + c] : 0.0;       // L[r][4s+kq]
+        CL[s] = (r <= c) ? L[c * ldl + r] : 0.0;       // L[4s+kq][r]
     }
-    if (lane < 16) {
-#pragma unroll
-        for (int rr = 0; rr < 16; ++rr) out[rr * ldo + r] = (rr >= r) ? xc[rr] : 0.0;
+    const double* Lb = L + (4 * cb) * ldl + 4 * cb;
+    const double l10 = Lb[ldl], l20 = Lb[2 * ldl], l21 = Lb[2 * ldl + 1];
+    const double l30 = Lb[3 * ldl], l31 = Lb[3 * ldl + 1], l32 = Lb[3 * ldl + 2];
+    const double i0 = invd[4 * cb], i1 = invd[4 * cb + 1], i2 = invd[4 * cb + 2], i3 = invd[4 * cb + 3];
+    double valC, valR;
+    {   // column p of W_cb, row kq  -> C layout;  column kq, row p -> R layout
+        const double x0 = (p == 0) ? i0 : 0.0;
+        const double x1 = fma(-l10, x0, (p == 1) ? 1.0 : 0.0) * i1;
+        const double x2 = fma(-l21, x1, fma(-l20, x0, (p == 2) ? 1.0 : 0.0)) * i2;
+        const double x3 = fma(-l32, x2, fma(-l31, x1, fma(-l30, x0, (p == 3) ? 1.0 : 0.0))) * i3;
+        valC = pick4(x0, x1, x2, x3, kq);
+        const double y0 = (kq == 0) ? i0 : 0.0;
+        const double y1 = fma(-l10, y0, (kq == 1) ? 1.0 : 0.0) * i1;
+        const double y2 = fma(-l21, y1, fma(-l20, y0, (kq == 2) ? 1.0 : 0.0)) * i2;
+        const double y3 = fma(-l32, y2, fma(-l31, y1, fma(-l30, y0, (kq == 3) ? 1.0 : 0.0))) * i3;
+        valR = pick4(y0, y1, y2, y3, p);
     }
+    d4 XC, XR;      // C(X0), R(X0)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        XC[g] = (g == cb) ? valC : 0.0;
+        XR[g] = (g == cb) ? valR : 0.0;
+    }
+    // level 1: M1 = blocks (1,0), (3,2)
+    d4 X1, X1T;
+    {
+        d4 T = zero;
+#pragma unroll
+        for (int s = 0; s < 4; s += 2)      // M1 has column blocks 0, 2
+            T = __builtin_amdgcn_mfma_f64_16x16x4f64(((cb & 1) && s == cb - 1) ? RL[s] : 0.0, XC[s], T, 0, 0, 0);
+        X1 = XC;
+#pragma unroll
+        for (int s = 1; s < 4; s += 2)      // T has row blocks 1, 3
+            X1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-XR[s], T[s], X1, 0, 0, 0);
+        d4 Tt = zero;                       // M1^T X0^T: M1^T has column blocks 1, 3
+#pragma unroll
+        for (int s = 1; s < 4; s += 2)
+            Tt = __builtin_amdgcn_mfma_f64_16x16x4f64((cb == s - 1) ? CL[s] : 0.0, XR[s], Tt, 0, 0, 0);
+        X1T = XR;
+#pragma unroll
+        for (int s = 0; s < 4; s += 2)      // Tt has row blocks 0, 2
+            X1T = __builtin_amdgcn_mfma_f64_16x16x4f64(-XC[s], Tt[s], X1T, 0, 0, 0);
+    }
+    // level 2: M2 = rows 8..15 x columns 0..7
+    d4 X2 = X1;
+    {
+        d4 T = zero;
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+            T = __builtin_amdgcn_mfma_f64_16x16x4f64((cb >= 2) ? RL[s] : 0.0, X1[s], T, 0, 0, 0);
+#pragma unroll
+        for (int s = 2; s < 4; ++s)
+            X2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-X1T[s], T[s], X2, 0, 0, 0);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) out[(kq + 4 * g) * ldo + r] = X2[g];
 }
 
 __device__ __forceinline__ d4 tile_read(const double* C, int lane) {
@@ -110,7 +237,7 @@ __device__ __forceinline__ void load_block(double* D, const double* __restrict__
 
 // Cholesky of the leading npan*16 rows/cols of the block in D (lower part), in place.
 // invd[j] <- 1/L_jj.  *s_bad <- 1 + first non-positive pivot column (if any, first only).
-__device__ inline void lds_factor(double* D, double* invd, int npan, int* s_bad, int tid) {
+__device__ __forceinline__ void lds_factor(double* D, double* invd, int npan, int* s_bad, int tid) {
     const int lane = tid & 63, wave = tid >> 6;
     const int ns = npan * 16;
     // The 16x16 register Cholesky of the next diagonal tile is the serial part.  It is overlapped with
@@ -180,7 +307,7 @@ __device__ inline void lds_factor(double* D, double* invd, int npan, int* s_bad,
 // In-place inverse of the lower-triangular block (leading npan*16 rows) by recursive doubling.
 // Precondition: the 16x16 diagonal sub-blocks already hold their inverses with zeros above the
 // diagonal.  Only tiles whose rows lie inside the leading npan*16 rows are touched.
-__device__ inline void lds_invert_levels(double* D, int npan, int tid) {
+__device__ __forceinline__ void lds_invert_levels(double* D, int npan, int tid) {
     const int lane = tid & 63, wave = tid >> 6;
     const int ns = npan * 16;
     for (int half = 16; half < ns; half *= 2) {

@@ -483,7 +483,8 @@ __global__ __launch_bounds__(256) void finalize_kernel(gpimhip_model_t m, int64_
         hist_row = fi.hist_base ? fi.hist_base + (int64_t)it * P : nullptr;
         *fi.iter = it + 1;
     }
-    finalize_step(m, N, S, q2, lg, *th, u, adam_m, adam_v, do_adam, st, loss_out, grad_out, hist_row);
+    finalize_step(m, N, S, q2, lg, *th, u, adam_m, adam_v, do_adam, st, loss_out, grad_out, hist_row,
+                  prior_constant(m));
 }
 
 int launch_finalize(gpimhip_ctx* h, const gpimhip_model_t* m, int64_t N, int64_t np, double* u, int do_adam,

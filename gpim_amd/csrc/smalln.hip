@@ -26,16 +26,26 @@ struct SmallFitArgs {
     double* loss;          // T or null
     double* grad;          // P or null (only when T == 0: evaluate once, no update)
     int32_t* info;
+    long long* prof;       // SMALLN_PROFILE builds only
 };
+
+#ifdef SMALLN_PROFILE
+#define SSTAMP(i) do { if (threadIdx.x == 0 && it == 5) a.prof[i] = clock64(); } while (0)
+#else
+#define SSTAMP(i) do { } while (0)
+#endif
 
 template <int KIND>
 __global__ __launch_bounds__(NTH, 1) void fit_small_kernel(SmallFitArgs a) {
     __shared__ __attribute__((aligned(16))) double D[NB * LDD];
+    __shared__ double xr[NB][4];          // raw coordinates (loaded once)
     __shared__ double xs[NB][5];          // scaled coordinates + squared norm
     __shared__ double yv[NB], zv[NB], al[NB], invd[NB];
-    __shared__ double red[NTH / 64][8];
+    __shared__ double red[NTH / 64][12];
     __shared__ ThetaDev sth;
     __shared__ double su[MAXP], sm_[MAXP], sv_[MAXP];
+    __shared__ double s_prior;
+    __shared__ gpimhip_model_t smod;      // LDS copy: lane-indexed bounds would push the argument struct to scratch
     __shared__ int s_bad;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int N = a.N, d = a.m.dim;
@@ -55,86 +65,116 @@ __global__ __launch_bounds__(NTH, 1) void fit_small_kernel(SmallFitArgs a) {
         sm_[tid] = 0.0;
         sv_[tid] = 0.0;
     }
-    if (tid < NB) yv[tid] = (tid < N) ? a.y[tid] : 0.0;
-    if (tid == 0) s_bad = 0;
+    if (tid < NB) {
+        yv[tid] = (tid < N) ? a.y[tid] : 0.0;
+        for (int k = 0; k < GPIMHIP_MAX_DIM; ++k) xr[tid][k] = (k < d && tid < N) ? a.X[tid * d + k] : 0.0;
+    }
+    if (tid == 0) {
+        s_bad = 0;
+        smod = a.m;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        ThetaDev t0;
+        theta_from_u(smod, su, t0);
+        sth = t0;
+        s_prior = prior_constant(smod);
+    }
     __syncthreads();
 
     const int niter = a.T > 0 ? a.T : 1;
     for (int it = 0; it < niter; ++it) {
-        if (tid == 0) {
-            ThetaDev t;
-            theta_from_u(a.m, su, t);
-            sth = t;
-        }
-        __syncthreads();
-        const ThetaDev t = sth;
+        SSTAMP(0);
+        const ThetaDev t = sth;            // theta(u): set before the loop / by the previous finalize
+        // Adam scalars of this iteration, fetched now so that the load is long done at finalize
+        const double lr_it = a.T > 0 ? a.lr_over_bc1[it] : 0.0, bc2_it = a.T > 0 ? a.bc2_sqrt[it] : 1.0;
+        SSTAMP(1);
         if (tid < NB) {
             double s2 = 0.0;
+#pragma unroll
             for (int k = 0; k < GPIMHIP_MAX_DIM; ++k) {
-                double v = 0.0;
-                if (k < d && tid < N) v = a.X[tid * d + k] / t.ls[k];
+                const double v = (k < d && tid < N) ? xr[tid][k] / t.ls[k] : 0.0;
                 xs[tid][k] = v;
                 s2 += v * v;
             }
             xs[tid][4] = s2;
         }
         __syncthreads();
-        // K(X,X) + (jitter + noise) I, lower part of the leading ns x ns block; identity padding
-        for (int e = tid; e < ns * ns; e += NTH) {
-            const int i = e / ns, j = e - i * ns;
-            if (j > i) continue;
-            double k;
-            if (i >= N) {
-                k = (i == j) ? 1.0 : 0.0;
-            } else {
-                double dot = xs[i][0] * xs[j][0];
-                dot = fma(xs[i][1], xs[j][1], dot);
-                dot = fma(xs[i][2], xs[j][2], dot);
-                dot = fma(xs[i][3], xs[j][3], dot);
-                const double r2 = clamp0_nan((xs[i][4] - 2.0 * dot) + xs[j][4]);
-                k = t.var * kfun_value<KIND>(r2, t.alpha);
-                if (i == j) k += t.diag_add;
+        SSTAMP(2);
+        // K(X,X) + (jitter + noise) I, lower part of the leading ns x ns block, identity padding.
+        // One 16x16 tile per wave and round; with up to three tiles (N <= 32) four waves share a
+        // tile, one register group (four rows) each.  Same tile walk in the gradient phase below.
+        const int ntile = npan * (npan + 1) / 2;
+        const int split = (ntile <= 3) ? 4 : 1;
+        for (int w = wave; w < ntile * split; w += NTH / 64) {
+            const int q = (split == 4) ? (w >> 2) : w, rg_only = (split == 4) ? (w & 3) : -1;
+            int ti = (int)((sqrtf(8.0f * q + 1.0f) - 1.0f) * 0.5f);
+            while (ti * (ti + 1) / 2 > q) --ti;
+            while ((ti + 1) * (ti + 2) / 2 <= q) ++ti;
+            const int tj = q - ti * (ti + 1) / 2;
+            const int j = tj * 16 + (lane & 15);
+            const double xj0 = xs[j][0], xj1 = xs[j][1], xj2 = xs[j][2], xj3 = xs[j][3], xj4 = xs[j][4];
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int i = ti * 16 + (lane >> 4) + 4 * rg;
+                if (j > i || (rg_only >= 0 && rg != rg_only)) continue;
+                double k;
+                if (i >= N) {
+                    k = (i == j) ? 1.0 : 0.0;
+                } else {
+                    double dot = xs[i][0] * xj0;
+                    dot = fma(xs[i][1], xj1, dot);
+                    dot = fma(xs[i][2], xj2, dot);
+                    dot = fma(xs[i][3], xj3, dot);
+                    const double r2 = clamp0_nan((xs[i][4] - 2.0 * dot) + xj4);
+                    k = t.var * kfun_value<KIND>(r2, t.alpha);
+                    if (i == j) k += t.diag_add;
+                }
+                D[i * LDD + j] = k;
             }
-            D[i * LDD + j] = k;
         }
         __syncthreads();
+        SSTAMP(3);
         lds_factor(D, invd, npan, &s_bad, tid);
-        // log-determinant (fixed order: one wave, tree)
-        double lg = 0.0;
-        if (wave == 0) {
-            double v = 0.0;
-            for (int i = lane; i < ns; i += 64) v -= log(invd[i]);      // log L_ii = -log(1/L_ii)
-            v += __shfl_xor(v, 32);
-            v += __shfl_xor(v, 16);
-            v += __shfl_xor(v, 8);
-            v += __shfl_xor(v, 4);
-            v += __shfl_xor(v, 2);
-            v += __shfl_xor(v, 1);
-            lg = v;
-        }
+        SSTAMP(4);
         // triangular inverse in place: diagonal 16x16 blocks by one wave each, then doubling
         if (wave < npan) trinv16(D + wave * 16 * LDD + wave * 16, LDD, invd + wave * 16,
                                  D + wave * 16 * LDD + wave * 16, LDD, lane);
         __syncthreads();
+        SSTAMP(5);
         lds_invert_levels(D, npan, tid);
-        // z = L^-1 y (row-wise), then alpha = L^-T z (column-wise)
-        if (tid < ns) {
+        SSTAMP(6);
+        // z = L^-1 y: four threads per row (columns q, q+4, ...), quad reduction
+        {
+            const int i = tid >> 2, q = tid & 3;
             double s = 0.0;
-            for (int j = 0; j <= tid; ++j) s = fma(D[tid * LDD + j], yv[j], s);
-            zv[tid] = s;
+            if (i < ns)
+                for (int j = q; j <= i; j += 4) s = fma(D[i * LDD + j], yv[j], s);
+            s = quad_sum(s);
+            if (q == 0 && i < ns) zv[i] = s;
         }
         __syncthreads();
-        if (tid < ns) {
+        // alpha = L^-T z: four threads per column
+        {
+            const int j = tid >> 2, q = tid & 3;
             double s = 0.0;
-            for (int i = tid; i < ns; ++i) s = fma(D[i * LDD + tid], zv[i], s);
-            al[tid] = s;
+            if (j < ns)
+                for (int i = j + q; i < ns; i += 4) s = fma(D[i * LDD + j], zv[i], s);
+            s = quad_sum(s);
+            if (q == 0 && j < ns) al[j] = s;
         }
         __syncthreads();
+        SSTAMP(7);
         // K^-1 tiles (lower) = sum_{kt >= ti} Linv(kt,ti)^T Linv(kt,tj) on MFMA, consumed in registers
-        // by the gradient reduction (same sums as grad_reduce_kernel)
-        double acc7[7] = {0, 0, 0, 0, 0, 0, 0};
-        const int ntile = npan * (npan + 1) / 2;
-        for (int q = wave; q < ntile; q += NTH / 64) {
+        // by the gradient reduction (same sums as grad_reduce_kernel); components 7, 8 carry
+        // |z|^2 and sum log L_ii through the same reduction tree
+        double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (tid < ns) {
+            acc[7] = zv[tid] * zv[tid];
+            acc[8] = -log(invd[tid]);
+        }
+        for (int w = wave; w < ntile * split; w += NTH / 64) {
+            const int q = (split == 4) ? (w >> 2) : w, rg_only = (split == 4) ? (w & 3) : -1;
             int ti = (int)((sqrtf(8.0f * q + 1.0f) - 1.0f) * 0.5f);
             while (ti * (ti + 1) / 2 > q) --ti;
             while ((ti + 1) * (ti + 2) / 2 <= q) ++ti;
@@ -150,57 +190,51 @@ __global__ __launch_bounds__(NTH, 1) void fit_small_kernel(SmallFitArgs a) {
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
                 const int i = ti * 16 + (lane >> 4) + 4 * rg, j = tj * 16 + (lane & 15);
-                if (i >= N || j > i) continue;
+                if (i >= N || j > i || (rg_only >= 0 && rg != rg_only)) continue;
                 const double g = kin[rg] - al[i] * al[j];
-                const double w = (i == j) ? g : 2.0 * g;
+                const double wt = (i == j) ? g : 2.0 * g;
                 double dot = xs[i][0] * xs[j][0];
                 dot = fma(xs[i][1], xs[j][1], dot);
                 dot = fma(xs[i][2], xs[j][2], dot);
                 dot = fma(xs[i][3], xs[j][3], dot);
                 const double r2 = clamp0_nan((xs[i][4] - 2.0 * dot) + xs[j][4]);
                 const KVal kv = kfun_grad<KIND>(r2, t.alpha);
-                acc7[0] = fma(w, kv.e, acc7[0]);
-                const double wh = w * kv.h;
+                acc[0] = fma(wt, kv.e, acc[0]);
+                const double wh = wt * kv.h;
                 const double d0 = xs[i][0] - xs[j][0], d1 = xs[i][1] - xs[j][1];
                 const double d2_ = xs[i][2] - xs[j][2], d3 = xs[i][3] - xs[j][3];
-                acc7[1] = fma(wh, d0 * d0, acc7[1]);
-                acc7[2] = fma(wh, d1 * d1, acc7[2]);
-                acc7[3] = fma(wh, d2_ * d2_, acc7[3]);
-                acc7[4] = fma(wh, d3 * d3, acc7[4]);
-                if (i == j) acc7[5] += g;
-                if (KIND == GPIMHIP_KERNEL_RQ) acc7[6] = fma(w, kv.ga, acc7[6]);
+                acc[1] = fma(wh, d0 * d0, acc[1]);
+                acc[2] = fma(wh, d1 * d1, acc[2]);
+                acc[3] = fma(wh, d2_ * d2_, acc[3]);
+                acc[4] = fma(wh, d3 * d3, acc[4]);
+                if (i == j) acc[5] += g;
+                if (KIND == GPIMHIP_KERNEL_RQ) acc[6] = fma(wt, kv.ga, acc[6]);
             }
         }
+        SSTAMP(8);
 #pragma unroll
-        for (int k = 0; k < 7; ++k) {
-            double v = acc7[k];
-            v += __shfl_xor(v, 32);
-            v += __shfl_xor(v, 16);
-            v += __shfl_xor(v, 8);
-            v += __shfl_xor(v, 4);
-            v += __shfl_xor(v, 2);
-            v += __shfl_xor(v, 1);
+        for (int k = 0; k < 9; ++k) {
+            const double v = wave_sum(acc[k]);
             if (lane == 0) red[wave][k] = v;
         }
         __syncthreads();
-        if (tid == 0) {
-            double Sl[7];
-            for (int k = 0; k < 7; ++k) {
+        SSTAMP(9);
+        if (wave == 0) {
+            if (lane < 9) {
                 double v = 0.0;
-                for (int w = 0; w < NTH / 64; ++w) v += red[w][k];
-                Sl[k] = v;
+                for (int w = 0; w < NTH / 64; ++w) v += red[w][lane];
+                red[0][lane] = v;      // only wave 0 touches red here; lanes own distinct slots
             }
-            double q2 = 0.0;
-            for (int i = 0; i < ns; ++i) q2 = fma(zv[i], zv[i], q2);
             AdamStep st;
             st.beta1 = 0.9; st.beta2 = 0.999; st.eps = 1e-8;
-            st.lr_over_bc1 = a.T > 0 ? a.lr_over_bc1[it] : 0.0;
-            st.bc2_sqrt = a.T > 0 ? a.bc2_sqrt[it] : 1.0;
-            finalize_step(a.m, N, Sl, q2, lg, t, su, sm_, sv_, a.T > 0 ? 1 : 0, st,
-                          a.loss ? a.loss + it : nullptr, a.grad,
-                          (a.hist && a.T > 0) ? a.hist + (int64_t)it * P : nullptr);
+            st.lr_over_bc1 = lr_it;
+            st.bc2_sqrt = bc2_it;
+            finalize_lanes(smod, N, red[0], lane, &sth, su, sm_, sv_, a.T > 0 ? 1 : 0, st,
+                           a.loss ? a.loss + it : nullptr, a.grad,
+                           (a.hist && a.T > 0) ? a.hist + (int64_t)it * P : nullptr, s_prior);
         }
         __syncthreads();
+        SSTAMP(10);
     }
     if (tid < P && a.T > 0) a.u[tid] = su[tid];
     if (tid == 0 && s_bad != 0 && *a.info == 0) *a.info = s_bad;
@@ -212,7 +246,7 @@ int launch_fit_small(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X, 
     SmallFitArgs a;
     a.m = *m; a.X = X; a.x_bs = x_bs; a.y = y; a.N = N; a.T = T; a.u = u;
     a.lr_over_bc1 = lr_over_bc1; a.bc2_sqrt = bc2_sqrt;
-    a.hist = hist; a.loss = loss; a.grad = grad; a.info = h->info;
+    a.hist = hist; a.loss = loss; a.grad = grad; a.info = h->info; a.prof = nullptr;
     switch (m->kernel) {
         case GPIMHIP_KERNEL_RBF:
             hipLaunchKernelGGL((fit_small_kernel<GPIMHIP_KERNEL_RBF>), dim3(h->nbatch), dim3(NTH), 0, h->stream, a); break;

@@ -44,12 +44,18 @@ __device__ inline void theta_from_u(const gpimhip_model_t& m, const double* u, T
 
 
 // S[0..6]: reduced gradient sums (see grad_reduce_kernel), q2 = |L^-1 y|^2, lg = sum log L_ii
-__device__ inline void finalize_step(const gpimhip_model_t& m, int64_t N, const double* S, double q2, double lg,
-                                     const ThetaDev& t, double* u, double* adam_m, double* adam_v, int do_adam,
-                                     const AdamStep& st, double* loss_out, double* grad_out, double* hist_row) {
-    const int P = 2 + m.n_ls + (m.kernel == GPIMHIP_KERNEL_RQ ? 1 : 0);
+__device__ inline double prior_constant(const gpimhip_model_t& m) {
+    // -log prior of the Uniform priors (constant inside their support)
     double prior = log(m.amp_hi - m.amp_lo);
     for (int k = 0; k < m.n_ls; ++k) prior += log(m.ls_hi[k] - m.ls_lo[k]);
+    return prior;
+}
+
+__device__ inline void finalize_step(const gpimhip_model_t& m, int64_t N, const double* S, double q2, double lg,
+                                     const ThetaDev& t, double* u, double* adam_m, double* adam_v, int do_adam,
+                                     const AdamStep& st, double* loss_out, double* grad_out, double* hist_row,
+                                     double prior) {
+    const int P = 2 + m.n_ls + (m.kernel == GPIMHIP_KERNEL_RQ ? 1 : 0);
     const double loss = 0.5 * q2 + lg + 0.5 * (double)N * 1.8378770664093453 + prior;
     double g[MAXP];
     g[0] = 0.5 * S[0] * t.dvar_du;
@@ -83,5 +89,70 @@ __device__ inline void finalize_step(const gpimhip_model_t& m, int64_t N, const 
             hist_row[1 + m.n_ls] = tn.noise;
             if (m.kernel == GPIMHIP_KERNEL_RQ) hist_row[2 + m.n_ls] = tn.alpha;
         }
+    }
+}
+
+// Lane-parallel form of finalize_step for the fused small-N trainer: lane p of one wave owns
+// hyper-parameter p (chain rule, Adam step, theta of the stepped value), so the exp/divide/sqrt
+// chains of the P parameters run side by side.  Same expressions, in the same order, as above.
+// `t` is both the current theta (read) and the next one (written) -- it lives in LDS.
+__device__ inline void finalize_lanes(const gpimhip_model_t& m, int64_t N, const double* S, int lane, ThetaDev* t,
+                                      double* u, double* adam_m, double* adam_v, int do_adam, const AdamStep& st,
+                                      double* loss_out, double* grad_out, double* hist_row, double prior) {
+    const int P = 2 + m.n_ls + (m.kernel == GPIMHIP_KERNEL_RQ ? 1 : 0);
+    if (lane == 0 && loss_out) *loss_out = 0.5 * S[7] + S[8] + 0.5 * (double)N * 1.8378770664093453 + prior;
+    if (lane >= P) return;
+    const bool is_var = lane == 0, is_ls = lane >= 1 && lane <= m.n_ls, is_noise = lane == 1 + m.n_ls;
+    const int k = is_ls ? lane - 1 : 0;
+    double g;
+    if (is_var) {
+        g = 0.5 * S[0] * t->dvar_du;
+    } else if (is_ls) {
+        double s = S[1 + k];
+        if (m.n_ls == 1) {
+            s = 0.0;
+            for (int q = 0; q < m.dim; ++q) s += S[1 + q];
+        }
+        g = 0.5 * s * t->var / t->ls[k] * t->dls_du[k];
+    } else if (is_noise) {
+        g = 0.5 * S[5] * t->dnoise_du;
+    } else {
+        g = 0.5 * S[6] * t->var * t->dalpha_du;
+    }
+    if (grad_out) grad_out[lane] = g;
+    if (!do_adam) return;
+    double mm = adam_m[lane], vv = adam_v[lane];
+    mm = mm + (g - mm) * (1.0 - st.beta1);
+    vv = vv * st.beta2 + (1.0 - st.beta2) * g * g;
+    const double denom = sqrt(vv) / st.bc2_sqrt + st.eps;
+    const double un = u[lane] + (-st.lr_over_bc1) * (mm / denom);
+    u[lane] = un;
+    adam_m[lane] = mm;
+    adam_v[lane] = vv;
+    double val, dval;
+    if (is_var || is_ls) {
+        interval_map(un, is_var ? m.amp_lo : m.ls_lo[k], is_var ? m.amp_hi : m.ls_hi[k], val, dval);
+    } else {
+        val = exp(un);
+        dval = val;
+    }
+    if (hist_row) hist_row[lane] = val;
+    if (is_var) {
+        t->var = val;
+        t->dvar_du = dval;
+    } else if (is_ls) {
+        const double inv = 1.0 / val;
+        if (m.n_ls == 1) {
+            for (int q = 0; q < m.dim; ++q) { t->ls[q] = val; t->dls_du[q] = dval; t->inv_ls[q] = inv; }
+        } else {
+            t->ls[k] = val; t->dls_du[k] = dval; t->inv_ls[k] = inv;
+        }
+    } else if (is_noise) {
+        t->noise = val;
+        t->dnoise_du = val;
+        t->diag_add = m.jitter + val;
+    } else {
+        t->alpha = val;
+        t->dalpha_du = val;
     }
 }
