@@ -94,8 +94,8 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_tiles_kernel(GemmArgs g) {
     // XCD-aware bijective remap (block b runs on XCD b%8, in order b/8 on that XCD).
     //  chunk == 0: every XCD gets one contiguous slice of the tile list -- best L2 reuse when all
     //              tiles cost the same (SYRK-shaped trailing updates).
-    //  chunk  > 0: the list is dealt to the XCDs round-robin in chunks of that many tiles (one 8x8
-    //              patch), so lists sorted by decreasing k-range stay balanced across XCDs.
+    //  chunk  > 0: the list is dealt to the XCDs in chunks of that many tiles (one 8x8 patch), back
+    //              and forth, so lists sorted by decreasing k-range stay balanced across XCDs.
     constexpr int QN = 128 / TSN;                       // workgroups per tile along n
     constexpr int QUADS = (128 / TSM) * QN;             // workgroups per 128x128 tile
     const int n = g.ntiles, b = blockIdx.x / QUADS, quad = blockIdx.x % QUADS;
@@ -108,8 +108,10 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_tiles_kernel(GemmArgs g) {
     } else {
         const int C = g.chunk, full = (n / (8 * C)) * (8 * C);
         if (b < full) {
-            const int x = b & 7, y = b >> 3;
-            p = ((y / C) * 8 + x) * C + (y % C);
+            // serpentine: odd rounds deal in reverse, so that on a list sorted by cost no XCD always
+            // gets the most expensive chunk of the round (16 % spread between XCD 0 and 7 otherwise)
+            const int x = b & 7, y = b >> 3, round = y / C;
+            p = (round * 8 + ((round & 1) ? 7 - x : x)) * C + (y % C);
         } else {
             p = b;
         }
@@ -230,7 +232,7 @@ static int launch_one(gpimhip_ctx* h, const GemmArgs& g) {
         // in-place panel solve: row halves (the workgroup owns the rows it overwrites), 8 waves
         hipLaunchKernelGGL((gemm_tiles_kernel<A_KM, B_KM, EPI_STORE, 8, 64, 128>), dim3(g.ntiles * 2, h->nbatch),
                            dim3(512), 0, h->stream, g);
-    else if (total <= 256 || (!A_KM && !B_KM && !getenv("GPIMHIP_NT_4WAVE")))
+    else if (total <= 256 || (!A_KM && !B_KM && !getenv("GPIMHIP_NT_4WAVE")) || getenv("GPIMHIP_ALL_8WAVE"))
         // (also every SYRK-shaped update of the Cholesky: measured 8 % faster factorisation at N = 16384,
         // the 512-thread workgroups interleave better with the concurrent panel chain)
         // at most one tile per CU: 8-wave workgroup so every SIMD still holds two MFMA waves

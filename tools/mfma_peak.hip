@@ -5,7 +5,7 @@
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 template <int NACC>
-__global__ __launch_bounds__(256) void mfma_loop(double* out, int iters, double a0, double b0) {
+__global__ __launch_bounds__(1024) void mfma_loop(double* out, int iters, double a0, double b0) {
     d4 acc[NACC];
 #pragma unroll
     for (int i = 0; i < NACC; ++i) acc[i] = (d4){0, 0, 0, 0};
@@ -44,6 +44,9 @@ void run(int blocks, int threads, int iters, const char* tag) {
 }
 
 int main() {
+    run<16>(256, 512, 5000, "2 waves/SIMD (1 WG/CU), 16 acc");
+    run<8>(256, 1024, 10000, "4 waves/SIMD (1 WG/CU), 8 acc");
+    run<16>(256, 1024, 5000, "4 waves/SIMD (1 WG/CU), 16 acc");
     run<4>(256, 256, 20000, "1 wave/SIMD, 4 acc");
     run<16>(256, 256, 5000, "1 wave/SIMD, 16 acc");
     run<4>(512, 256, 20000, "2 waves/SIMD, 4 acc");
