@@ -235,18 +235,30 @@ int plan_ensure(gpimhip_ctx* h, int nb) {
     tri_build(0, nb, levels);
     P.tri_t.clear();
     P.tri_x.clear();
+    // Levels with several nodes: node after node, each longest-first, is a saw-tooth of costs and the
+    // launch ends on the long tail of whichever workgroup slots drew the long tiles last (model in
+    // tools/sched_model.py: 12 % / 40 % over the ideal makespan for 2 / 4 nodes).  One list sorted by
+    // k-length instead: equal lengths are one tile column (T) or row (X) of every node, which still
+    // share an operand panel.
+    auto sort_longest_first = [&](size_t nnodes, size_t start) {
+        if (nnodes < 2) return;
+        std::stable_sort(tl.begin() + start, tl.end(),
+                         [](const TileDesc& a, const TileDesc& b) { return a.kb1 - a.kb0 > b.kb1 - b.kb0; });
+    };
     for (auto& lv : levels) {
         size_t s = tl.size();
         // T = L21 * X11: k-range [cj, mid) -- longest for the leftmost columns
         for (auto& nd : lv)
             rect_patch_order(tl, nd.mid, nd.hi, nd.lo, nd.mid, false, true,
                              [&](int, int cj, int& k0, int& k1) { k0 = cj; k1 = nd.mid; });
+        sort_longest_first(lv.size(), s);
         P.tri_t.push_back(mark(s));
         s = tl.size();
         // X21 = -X22 * T: k-range [mid, ci] -- longest for the bottom rows
         for (auto& nd : lv)
             rect_patch_order(tl, nd.mid, nd.hi, nd.lo, nd.mid, true, false,
                              [&](int ci, int, int& k0, int& k1) { k0 = nd.mid; k1 = ci + 1; });
+        sort_longest_first(lv.size(), s);
         P.tri_x.push_back(mark(s));
     }
     // K^-1 = L^-T L^-1 (lower): k-range [ci, nb), longest first.  Patches are 2 rows x 32 columns:
@@ -298,6 +310,42 @@ static GemmArgs gemm_args(const double* A, int64_t lda, const double* B, int64_t
 // trail_next(p) touches exactly the columns panel(p+1) factors; trail_rest(p) touches the columns to
 // the right of them, so the two streams never write the same tile.  Both join the caller's stream
 // before the next round.
+// Side streams are created on first use: a process only has a few hardware queues (four by
+// default), and once more streams exist than queues the panel and bulk streams of the look-ahead
+// schedule end up sharing one and serialise (measured: +7 ms per factorisation at N = 16384 with one
+// extra stream).  Handles that only ever run the fused small-N trainer create none.
+static void ensure_lookahead_streams(gpimhip_ctx* h) {
+    if (h->side_streams_tried) return;
+    h->side_streams_tried = true;
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // hi = numerically lowest = highest priority
+    if (hipStreamCreateWithPriority(&h->panel_stream, hipStreamNonBlocking, hi) != hipSuccess) {
+        h->panel_stream = nullptr;                   // fall back to the in-order schedule
+        return;
+    }
+    // The bulk trailing updates run on a stream whose CU mask leaves RESERVED_CUS compute units
+    // free (the mask is interleaved over the XCDs: 16 reserved = 2 per XCD, tools/cumask_probe.hip):
+    // potf2 needs ~135 KB of LDS, i.e. a whole CU, and would otherwise wait until the bulk kernel
+    // (2 x 74 KB per CU, thousands of workgroups queued) has drained.
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && !getenv("GPIMHIP_NO_CUMASK")) {
+        const int ncu = prop.multiProcessorCount;
+        std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+        int reserved = RESERVED_CUS;
+        if (const char* e = getenv("GPIMHIP_RESERVED_CUS")) reserved = std::max(1, std::min(ncu / 2, atoi(e)));
+        for (int c = reserved; c < ncu; ++c) mask[c / 32] |= (1u << (c % 32));
+        if (hipExtStreamCreateWithCUMask(&h->bulk_stream, (uint32_t)mask.size(), mask.data()) != hipSuccess)
+            h->bulk_stream = nullptr;
+    }
+}
+hipStream_t ensure_capture_stream(gpimhip_ctx* h) {
+    if (!h->capture_stream && !h->capture_stream_tried) {
+        h->capture_stream_tried = true;
+        if (hipStreamCreateWithFlags(&h->capture_stream, hipStreamNonBlocking) != hipSuccess) h->capture_stream = nullptr;
+    }
+    return h->capture_stream;
+}
+
 static int panel_steps(gpimhip_ctx* h, double* A, int64_t ld, int32_t* info, int p0, int p1) {
     const LinalgPlan& P = h->plan;
     for (int k = p0; k < p1; ++k) {
@@ -325,16 +373,16 @@ int launch_potrf(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_t* inf
     hipStream_t main_s = h->stream;
     // below ~12k unknowns the trailing updates are too short to hide a panel chain behind them and
     // the extra cross-stream traffic costs more than it saves
+    if (npanel >= LOOKAHEAD_MIN_PANELS) ensure_lookahead_streams(h);
     const bool ahead = (h->panel_stream != nullptr) && npanel >= LOOKAHEAD_MIN_PANELS;
-    if ((int)h->ev_pool.size() < 2 * npanel + 1) {
-        while ((int)h->ev_pool.size() < 2 * npanel + 1) {
-            hipEvent_t e;
-            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            h->ev_pool.push_back(e);
-        }
+    while ((int)h->ev_pool.size() < 2 * npanel + 2) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        h->ev_pool.push_back(e);
     }
-    auto evE = [&](int p) { return h->ev_pool[2 * p]; };
-    auto evF = [&](int p) { return h->ev_pool[2 * p + 1]; };
+    auto evF = [&](int p) { return h->ev_pool[2 * p]; };        // panel p+1 factored (panel stream)
+    auto evB = [&](int p) { return h->ev_pool[2 * p + 1]; };    // bulk update with panel p done
+    hipEvent_t ev0 = h->ev_pool[2 * npanel];                    // panel 0 factored (caller's stream)
     int rc = GPIMHIP_OK;
     // panel 0 has nothing to overlap with
     GP_TRY(panel_steps(h, A, ld, info, 0, std::min(OUTER_W, nb)));
@@ -351,29 +399,38 @@ int launch_potrf(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_t* inf
             GP_TRY(panel_steps(h, A, ld, info, q0, q1));
             continue;
         }
-        // Panel p is final on the main stream here.  Fork:
-        //   panel stream (high priority): update of the next panel's columns, then its factorisation
-        //   bulk stream (CU-masked)     : the rest of the trailing update
-        // They write disjoint column ranges and only read panel p.  Join both before the next round
-        // (the next trail_next touches columns the bulk update of this round also wrote).
-        HIP_TRY(hipEventRecord(evE(p), main_s));
-        HIP_TRY(hipStreamWaitEvent(h->panel_stream, evE(p), 0));
+        // Panel p is final (ev0 / evF(p-1)).  Two chains, ordered by events between the two side
+        // streams only -- the caller's stream joins once at the end, not every round (a round trip
+        // through it cost ~90 us per round):
+        //   panel stream (high priority): trail_next(p) [columns of panel p+1], then factor panel p+1.
+        //       trail_next(p) also needs bulk(p-1) done: both accumulate into the columns of panel p+1.
+        //   bulk stream (CU-masked): bulk(p) [columns right of panel p+1]; needs panel p, and follows
+        //       bulk(p-1) in stream order.
+        // bulk(p) and the panel chain of the same round write disjoint columns and only read panel p.
+        hipStream_t bs = h->bulk_stream;
+        if (p == 0) {
+            HIP_TRY(hipEventRecord(ev0, main_s));
+            HIP_TRY(hipStreamWaitEvent(h->panel_stream, ev0, 0));
+            HIP_TRY(hipStreamWaitEvent(bs, ev0, 0));
+        } else {
+            HIP_TRY(hipStreamWaitEvent(h->panel_stream, evB(p - 1), 0));
+            HIP_TRY(hipStreamWaitEvent(bs, evF(p - 1), 0));
+        }
         h->stream = h->panel_stream;
         rc = gn.ntiles ? launch_gemm(h, false, false, EPI_STORE, gn) : GPIMHIP_OK;
         if (rc == GPIMHIP_OK) rc = panel_steps(h, A, ld, info, q0, q1);
         h->stream = main_s;
         GP_TRY(rc);
         HIP_TRY(hipEventRecord(evF(p), h->panel_stream));
-        if (gb.ntiles) {
-            HIP_TRY(hipStreamWaitEvent(h->bulk_stream, evE(p), 0));
-            h->stream = h->bulk_stream;
-            rc = launch_gemm(h, false, false, EPI_STORE, gb);
-            h->stream = main_s;
-            GP_TRY(rc);
-            HIP_TRY(hipEventRecord(h->ev_pool[2 * npanel], h->bulk_stream));
-            HIP_TRY(hipStreamWaitEvent(main_s, h->ev_pool[2 * npanel], 0));
+        h->stream = bs;
+        rc = gb.ntiles ? launch_gemm(h, false, false, EPI_STORE, gb) : GPIMHIP_OK;
+        h->stream = main_s;
+        GP_TRY(rc);
+        HIP_TRY(hipEventRecord(evB(p), bs));
+        if (p + 2 == npanel) {
+            HIP_TRY(hipStreamWaitEvent(main_s, evF(p), 0));
+            HIP_TRY(hipStreamWaitEvent(main_s, evB(p), 0));
         }
-        HIP_TRY(hipStreamWaitEvent(main_s, evF(p), 0));
     }
     return GPIMHIP_OK;
 }
@@ -513,27 +570,6 @@ int gpimhip_create(gpimhip_handle* out, int device, void* hip_stream) {
     gpimhip_ctx* h = new gpimhip_ctx();
     h->device = device;
     h->stream = (hipStream_t)hip_stream;     // NULL = the device's default (null) stream
-    {
-        int lo = 0, hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // hi = numerically lowest = highest priority
-        if (hipStreamCreateWithPriority(&h->panel_stream, hipStreamNonBlocking, hi) != hipSuccess)
-            h->panel_stream = nullptr;               // fall back to the in-order schedule
-        // The bulk trailing updates run on a stream whose CU mask leaves RESERVED_CUS compute units
-        // free: potf2 needs ~150 KB of LDS, i.e. a whole CU, and would otherwise wait until the bulk
-        // kernel (2 x 74 KB per CU, thousands of workgroups queued) has drained.
-        if (hipStreamCreateWithFlags(&h->capture_stream, hipStreamNonBlocking) != hipSuccess)
-            h->capture_stream = nullptr;
-        hipDeviceProp_t prop;
-        if (h->panel_stream && hipGetDeviceProperties(&prop, device) == hipSuccess && !getenv("GPIMHIP_NO_CUMASK")) {
-            const int ncu = prop.multiProcessorCount;
-            std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
-            int reserved = RESERVED_CUS;
-            if (const char* e = getenv("GPIMHIP_RESERVED_CUS")) reserved = std::max(1, std::min(ncu / 2, atoi(e)));
-            for (int c = reserved; c < ncu; ++c) mask[c / 32] |= (1u << (c % 32));
-            if (hipExtStreamCreateWithCUMask(&h->bulk_stream, (uint32_t)mask.size(), mask.data()) != hipSuccess)
-                h->bulk_stream = nullptr;
-        }
-    }
     int rc = GPIMHIP_OK;
     if ((rc = dev_alloc(h, &h->theta1, 1)) || (rc = dev_alloc(h, &h->info, 4))) {
         delete h;
@@ -656,7 +692,7 @@ static int fit_impl(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X, i
     // of one launch call per kernel.  Not used with the multi-stream look-ahead schedule (large N,
     // where launch cost is irrelevant), while stage timing is on, or for very short fits.
     const int npanel = (int)((h->np / NB + OUTER_W - 1) / OUTER_W);
-    bool use_graph = T >= 8 && !h->timing && npanel < LOOKAHEAD_MIN_PANELS && h->capture_stream &&
+    bool use_graph = T >= 8 && !h->timing && npanel < LOOKAHEAD_MIN_PANELS && ensure_capture_stream(h) &&
                      !getenv("GPIMHIP_NO_GRAPH");
     if (use_graph) {
         hipGraph_t graph = nullptr;

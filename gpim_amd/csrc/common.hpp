@@ -78,6 +78,7 @@ struct gpimhip_ctx {
     hipStream_t stream = nullptr;
     hipStream_t panel_stream = nullptr;   // high-priority side stream for the Cholesky panel chain
     hipStream_t capture_stream = nullptr; // internal stream used only to capture one iteration into a hipGraph
+    bool side_streams_tried = false, capture_stream_tried = false;   // side streams are created on first use
     hipStream_t bulk_stream = nullptr;    // CU-masked stream for the bulk trailing updates (look-ahead)
     std::vector<hipEvent_t> ev_pool;      // cross-stream ordering events (no timing)
     // workspace (sized for np = padded N)

@@ -263,22 +263,40 @@ __global__ __launch_bounds__(256) void trmv_lower_kernel(const double* __restric
 }
 
 // out[j] = sum_{i >= i0(j)} A[i][j] * x[i] for 64 columns per workgroup; tri != 0 starts at the
-// diagonal block of the column (A lower triangular), else at row 0.
-__global__ __launch_bounds__(256) void gemv_t_kernel(const double* __restrict__ A, int64_t ld, int64_t nrows,
-                                                     const double* __restrict__ x, double* __restrict__ out,
-                                                     int tri, int64_t a_bs, int64_t x_bs, int64_t o_bs) {
-    __shared__ double red[4][64];
+// diagonal block of the column (A lower triangular), else at row 0.  HBM-bound (8 B per entry of
+// A): 16 waves per workgroup, each with four 512-byte row segments in flight; fixed summation order.
+#define GEMVT_WAVES 16
+__global__ __launch_bounds__(GEMVT_WAVES * 64) void gemv_t_kernel(const double* __restrict__ A, int64_t ld,
+                                                                 int64_t nrows, const double* __restrict__ x,
+                                                                 double* __restrict__ out, int tri, int64_t a_bs,
+                                                                 int64_t x_bs, int64_t o_bs) {
+    __shared__ double red[GEMVT_WAVES][64];
     A += blockIdx.y * a_bs;
     x += blockIdx.y * x_bs;
     out += blockIdx.y * o_bs;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t j = (int64_t)blockIdx.x * 64 + lane;
     const int64_t i0 = tri ? ((int64_t)blockIdx.x * 64 / NB) * NB : 0;
-    double s = 0.0;
-    for (int64_t i = i0 + wave; i < nrows; i += 4) s = fma(A[i * ld + j], x[i], s);
-    red[wave][lane] = s;
+    const double* col = A + j;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int64_t i = i0 + wave;
+    for (; i + 3 * GEMVT_WAVES < nrows; i += 4 * GEMVT_WAVES) {
+        const double a0 = col[i * ld], a1 = col[(i + GEMVT_WAVES) * ld];
+        const double a2 = col[(i + 2 * GEMVT_WAVES) * ld], a3 = col[(i + 3 * GEMVT_WAVES) * ld];
+        s0 = fma(a0, x[i], s0);
+        s1 = fma(a1, x[i + GEMVT_WAVES], s1);
+        s2 = fma(a2, x[i + 2 * GEMVT_WAVES], s2);
+        s3 = fma(a3, x[i + 3 * GEMVT_WAVES], s3);
+    }
+    for (; i < nrows; i += GEMVT_WAVES) s0 = fma(col[i * ld], x[i], s0);
+    red[wave][lane] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (wave == 0) out[j] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    if (wave == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < GEMVT_WAVES; ++w) t += red[w][lane];
+        out[j] = t;
+    }
 }
 
 int launch_trmv_lower(gpimhip_ctx* h, const double* L, int64_t ld, int64_t np, const double* y, double* z) {
@@ -289,7 +307,7 @@ int launch_trmv_lower(gpimhip_ctx* h, const double* L, int64_t ld, int64_t np, c
 }
 int launch_gemv_t(gpimhip_ctx* h, const double* A, int64_t ld, int64_t nrows, int64_t ncols, const double* x,
                   double* out, int tri, int64_t a_bs, int64_t x_bs, int64_t o_bs) {
-    hipLaunchKernelGGL(gemv_t_kernel, dim3((unsigned)(ncols / 64), h->nbatch), dim3(256), 0, h->stream, A, ld, nrows,
+    hipLaunchKernelGGL(gemv_t_kernel, dim3((unsigned)(ncols / 64), h->nbatch), dim3(GEMVT_WAVES * 64), 0, h->stream, A, ld, nrows,
                        x, out, tri, a_bs, x_bs, o_bs);
     HIP_TRY(hipGetLastError());
     return GPIMHIP_OK;

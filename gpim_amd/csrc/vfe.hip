@@ -34,6 +34,7 @@ int launch_potrf(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_t* inf
 int launch_trtri(gpimhip_ctx* h, double* A, double* Tm, int64_t np, int64_t ld);
 int launch_lauum(gpimhip_ctx* h, const double* A, double* B, int64_t np, int64_t ld);
 int launch_trmv_lower(gpimhip_ctx* h, const double* L, int64_t ld, int64_t np, const double* y, double* z);
+hipStream_t ensure_capture_stream(gpimhip_ctx* h);
 int launch_gemv_t(gpimhip_ctx* h, const double* A, int64_t ld, int64_t nrows, int64_t ncols, const double* x,
                   double* out, int tri, int64_t a_bs, int64_t x_bs, int64_t o_bs);
 int launch_pad_copy(gpimhip_ctx* h, const double* src, int64_t n, double* dst, int64_t np);
@@ -642,7 +643,7 @@ int gpimhip_fit_vfe(gpimhip_handle h, const gpimhip_model_t* m, const double* X,
     VfeIter it{h->iter, h->bc, T, hist_theta, hist_xu, loss_out};
     // every iteration is the same ~90 launches (iteration index and bias corrections live on the
     // device): capture one into a hipGraph and replay it
-    if (T >= 8 && h->capture_stream && !getenv("GPIMHIP_NO_GRAPH")) {
+    if (T >= 8 && !getenv("GPIMHIP_NO_GRAPH") && ensure_capture_stream(h)) {
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;
         hipStream_t main_s = h->stream;
