@@ -35,4 +35,12 @@ if M:
         _lib.check(lib.gpimhip_predict_exact(H.h, ctypes.byref(m), _lib.ptr(Xd), _lib.ptr(yd), N, _lib.ptr(u), _lib.ptr(Xs), M, _lib.ptr(mean), _lib.ptr(var)))
         dt = time.time() - t
         print(f"predict N={N} M={M}: {dt*1e3:.2f} ms, {(N*N*M + N**3*2/3)/dt/1e12:.2f} TFLOP/s")
+if os.environ.get("PROF_STAGES"):
+    lib.gpimhip_timing_enable(H.h, 1)
+    _lib.check(lib.gpimhip_fit_exact(H.h, ctypes.byref(m), _lib.ptr(Xd), _lib.ptr(yd), N, _lib.ptr(u), 0.1, T, _lib.ptr(hist), None))
+    for st, nm in enumerate(["potrf", "trtri", "lauum"]):
+        ms, cnt = ctypes.c_double(), ctypes.c_int64()
+        lib.gpimhip_timing_read(H.h, st, ctypes.byref(ms), ctypes.byref(cnt))
+        print("  stage %-6s %.3f ms per call (%d calls)" % (nm, ms.value / max(cnt.value, 1), cnt.value))
+    lib.gpimhip_timing_enable(H.h, 0)
 print("workspace GiB", lib.gpimhip_workspace_bytes(H.h) / 2**30)
