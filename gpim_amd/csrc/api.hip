@@ -271,6 +271,8 @@ int plan_ensure(gpimhip_ctx* h, int nb) {
     // read once per XCD), neighbouring rows differ by one block only.
     {
         size_t s = tl.size();
+        // (measured at N = 16384: 1x64 / 2x32 / 4x16 22.0-22.2 ms, 8x8 22.7, 16x4 23.2; L2-miss traffic
+        // 61-67 GB for all of them)
         const int PR = 2, PC = 32;
         for (int ig = 0; ig <= (nb - 1) / PR; ++ig)
             for (int jg = 0; jg * PC <= std::min(nb - 1, ig * PR + PR - 1); ++jg)
