@@ -67,16 +67,42 @@ def test_potrf(eng, n):
         assert out[0, n - 1].item() == 123.0
 
 
-def test_potrf_not_pd(eng):
+@pytest.mark.parametrize("n,col", [(200, 150), (1, 0), (40, 0), (40, 1), (40, 6), (40, 15), (40, 16), (40, 39),
+                                   (300, 127), (300, 128), (300, 131), (300, 299), (700, 513)])
+def test_potrf_not_pd(eng, n, col):
+    """first failing column, wherever it falls inside the 4x4 / 16x16 / 128x128 blocking"""
     _lib, H = eng
-    n = 200
     A = torch.eye(n, dtype=torch.float64)
-    A[150, 150] = -1.0
+    A[col, col] = -1.0
+    if col + 3 < n:
+        A[col + 3, col + 3] = -2.0                  # a later bad pivot must not win
     Ad = A.cuda()
     info = torch.zeros(1, dtype=torch.int32, device="cuda")
     _lib.check(H.lib.gpimhip_potrf(H.h, _lib.ptr(Ad), n, n, _lib.ptr(info)))
     torch.cuda.synchronize()
-    assert info.item() == 151                       # 1 + first failing column, like LAPACK
+    assert info.item() == col + 1                   # 1 + first failing column, like LAPACK
+
+
+@pytest.mark.parametrize("n,noise", [(60, 1e-4), (128, 1e-6), (200, 1e-6), (500, 1e-8)])
+def test_potrf_ill_conditioned_kernel_matrix(eng, n, noise):
+    """smooth RBF kernel matrix with a small nugget (condition number up to ~1e11): the blocked
+    factorisation must stay backward stable -- judged by the residual, not by L itself"""
+    _lib, H = eng
+    x = torch.linspace(0, 10, n, dtype=torch.float64)
+    A = torch.exp(-0.5 * (x[:, None] - x[None, :]) ** 2 / 4.0) + noise * torch.eye(n, dtype=torch.float64)
+    Ad = A.cuda().contiguous()
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    _lib.check(H.lib.gpimhip_potrf(H.h, _lib.ptr(Ad), n, n, _lib.ptr(info)))
+    torch.cuda.synchronize()
+    assert info.item() == 0
+    L = torch.tril(Ad.cpu())
+    resid = (L @ L.T - A).abs().max().item()
+    ref = torch.linalg.cholesky(A)
+    resid_ref = (ref @ ref.T - A).abs().max().item()
+    assert resid <= max(4 * resid_ref, 1e-14 * n)
+    # log-determinant agrees with LAPACK's to the conditioning-limited accuracy
+    assert_allclose(torch.log(torch.diagonal(L)).sum().item(), torch.log(torch.diagonal(ref)).sum().item(),
+                    rtol=1e-9)
 
 
 CASES = [("RBF", 7, 2, False), ("RBF", 130, 3, False), ("RBF", 300, 2, True),
