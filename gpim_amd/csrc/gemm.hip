@@ -184,17 +184,33 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_tiles_kernel(GemmArgs g) {
         const int64_t crow0 = (int64_t)(t.ci + g.c_roff) * NB + qi + wm * WROWS + (lane >> 4);
         const int64_t ccol0 = (int64_t)(t.cj + g.c_coff) * NB + qj + wn * WCOLS + (lane & 15);
         const double alpha = g.alpha, beta = g.beta;
+        if (beta != 0.0) {
+            // accumulate into C: fetch one 16-row band of the wave's sub-tile (NTL x 4 values per lane)
+            // with all loads in flight, then combine and store -- element by element the loads and
+            // stores serialise into 2 x 64 memory round trips per tile
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+            for (int i = 0; i < MT; ++i) {
+                double cv[NTL][4];
 #pragma unroll
-            for (int j = 0; j < NTL; ++j)
+                for (int j = 0; j < NTL; ++j)
 #pragma unroll
-                for (int rg = 0; rg < 4; ++rg) {
-                    double* cp = g.C + (crow0 + i * 16 + 4 * rg) * g.ldc + ccol0 + j * 16;
-                    double v = alpha * acc[i][j][rg];
-                    if (beta != 0.0) v += beta * (*cp);
-                    *cp = v;
-                }
+                    for (int rg = 0; rg < 4; ++rg)
+                        cv[j][rg] = g.C[(crow0 + i * 16 + 4 * rg) * g.ldc + ccol0 + j * 16];
+#pragma unroll
+                for (int j = 0; j < NTL; ++j)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg)
+                        g.C[(crow0 + i * 16 + 4 * rg) * g.ldc + ccol0 + j * 16] = alpha * acc[i][j][rg] + beta * cv[j][rg];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NTL; ++j)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg)
+                        g.C[(crow0 + i * 16 + 4 * rg) * g.ldc + ccol0 + j * 16] = alpha * acc[i][j][rg];
+        }
     } else {
         // column sums of squares of the 128x128 product tile -> colpart[ci][cj*128 + col]  (full tiles only)
         double* red = smem;      // [WGM][128]; all waves are past the last barrier of the k-loop
