@@ -1,0 +1,16 @@
+#!/bin/bash
+# Collects the rocprofv3 summaries committed under profiles/ (run on the MI355X box through gpurun;
+# outputs land in gpurun_out/prof_final and are copied into profiles/ by hand).
+cd /tmp; export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/prof_final
+rm -rf $O; mkdir -p $O
+# 1. kernel stats of the bench command itself (+ the JSON lines with and without the profiler)
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_stats -- python $R/bench.py > $O/bench_line_profiled.json 2> $O/bench_profiled.err
+python $R/bench.py > $O/bench_line.json 2> $O/bench.err
+# 2. PMC passes on two training iterations at the bench size (separate runs, kernel trace only)
+for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE"; do
+  tag=$(echo $set | cut -d' ' -f1)
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/pmc_$tag -- python $R/tests/tools/prof_fit.py 16384 2 0 Matern52 > /dev/null 2>&1
+done
+find $O -name "*.csv" | head -30
