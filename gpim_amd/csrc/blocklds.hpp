@@ -1,6 +1,6 @@
 // blocklds.hpp -- device helpers for a (<=128)x(<=128) lower-triangular block resident in LDS:
-// 16x16 register Cholesky / triangular inverse by one wave, MFMA tile access, and the panel-wise
-// factorisation + recursive-doubling inverse built from them.  Shared by potf2.hip (diagonal steps of
+// 16x16 Cholesky / triangular inverse by one wave on MFMA, tile access, and the panel-wise
+// factorisation with the row-wise inverse built from them.  Shared by potf2.hip (diagonal steps of
 // the blocked Cholesky) and smalln.hip (fused trainer for N <= 128).  512-thread workgroups.
 #pragma once
 #include "common.hpp"
@@ -139,8 +139,7 @@ __device__ __forceinline__ int chol16(double* D, double* invd_out, int lane) {
 // lane back-substitutes the two columns of its own 4x4 diagonal block it needs.  Each level then is
 // X <- X - X (M X) with M the sub-diagonal blocks absorbed at that level; level 1 is also run
 // transposed so that level 2 has X in both layouts.
-__device__ __forceinline__ void trinv16(const double* L, int ldl, const double* invd, double* out, int ldo,
-                                        int lane) {
+__device__ __forceinline__ d4 trinv16_regs(const double* L, int ldl, const double* invd, int lane) {
     const int r = lane & 15, kq = lane >> 4, cb = r >> 2, p = r & 3;
     const d4 zero = (d4){0.0, 0.0, 0.0, 0.0};
     d4 RL, CL;
@@ -204,8 +203,13 @@ __device__ __forceinline__ void trinv16(const double* L, int ldl, const double* 
         for (int s = 2; s < 4; ++s)
             X2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-X1T[s], T[s], X2, 0, 0, 0);
     }
+    return X2;      // accumulator layout: X[(lane>>4) + 4g][lane & 15]
+}
+__device__ __forceinline__ void trinv16(const double* L, int ldl, const double* invd, double* out, int ldo,
+                                        int lane) {
+    const d4 X = trinv16_regs(L, ldl, invd, lane);
 #pragma unroll
-    for (int g = 0; g < 4; ++g) out[(kq + 4 * g) * ldo + r] = X2[g];
+    for (int g = 0; g < 4; ++g) out[((lane >> 4) + 4 * g) * ldo + (lane & 15)] = X[g];
 }
 
 __device__ __forceinline__ d4 tile_read(const double* C, int lane) {
@@ -235,23 +239,47 @@ __device__ __forceinline__ void load_block(double* D, const double* __restrict__
 }
 
 
-// Cholesky of the leading npan*16 rows/cols of the block in D (lower part), in place.
-// invd[j] <- 1/L_jj.  *s_bad <- 1 + first non-positive pivot column (if any, first only).
-__device__ __forceinline__ void lds_factor(double* D, double* invd, int npan, int* s_bad, int tid) {
+// Cholesky AND inverse of the leading npan*16 rows/cols of the block in D, in place: on return D holds
+// X = L^-1 (lower; the diagonal 16x16 tiles with zeros above the diagonal), invd[j] = 1/L_jj.
+// Right-looking factorisation in 16-column panels: the 16x16 register Cholesky of the next diagonal
+// tile is the serial part and is overlapped with the trailing update (wave 0 updates tile (p+1,p+1)
+// first and goes straight on to factor it while the other waves update the rest); substitution
+// panel solve, one thread per row.  The inverse is built block row by block row in the shadow of
+// the factorisation instead of afterwards:
+//   X(i,i) = L(i,i)^-1,   X(i,j) = -X(i,i) * sum_{k=j}^{i-1} L(i,k) X(k,j)      (j < i)
+// Block row i of L is final once step i-1 is over.  During step i
+//   panel-solve phase : wave 4 inverts L(i,i) (registers + the Xs scratch tile); the five worker waves first
+//                       store block row i-1 of X (held in registers since the previous step) over
+//                       L(i-1,.), then sink(i, t) lets them export block row i of L;
+//   update phase      : next to their trailing tiles, the workers form T(i,j) = sum_k L(i,k) X(k,j) on
+//                       MFMA and multiply by -X(i,i) (T is already in B-operand layout); the results
+//                       stay in registers until the next step so that no wave overwrites an L(i,k)
+//                       another one still reads.  The row-inverse work grows as the trailing
+//                       update shrinks, and both hide behind wave 0's 16x16 factorisation.
+// Waves 0/1 (panel solve, next diagonal factorisation = the critical path) are not touched.
+#define XS_LD 18
+#define SINK_THREADS 320      // sink(i, t) is called by the five worker waves: t = 0..319
+template <typename Sink>
+__device__ __forceinline__ void lds_factor_inv(double* D, double* invd, double* Xs, int npan, int* s_bad, int tid,
+                                               Sink sink) {
     const int lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, kq = lane >> 4;
     const int ns = npan * 16;
-    // The 16x16 register Cholesky of the next diagonal tile is the serial part.  It is overlapped with
-    // the trailing update: wave 0 updates tile (p+1,p+1) first and goes straight on to factor it
-    // while waves 1..7 update the other tiles of the step.
+    const d4 zero = (d4){0.0, 0.0, 0.0, 0.0};
+    // row-inverse workers: waves 2, 3, 5, 6, 7; the diagonal inverses go to wave 4, which shares its
+    // SIMD with wave 0 -- busy there only while wave 0 runs the (MFMA-free) panel solve
+    const int widx = (wave >= 5) ? wave - 3 : wave - 2;      // 0..4 for the workers
+    const bool worker = wave >= 2 && wave != 4;
     if (wave == 0) {
         const int bad = chol16(D, invd, lane);
         if (lane == 0 && bad && *s_bad == 0) *s_bad = bad;
     }
     __syncthreads();
-    for (int p = 0; p < npan; ++p) {
+    d4 xd = zero, keep[2] = {zero, zero};       // block row p-1 of X, carried into step p
+    for (int p = 0; p <= npan; ++p) {
         const int c0 = p * 16;
-        // panel solve, one thread per row below the diagonal tile: x L16^T = a
-        {
+        if (wave < 2) {
+            // panel solve, one thread per row below the diagonal tile: x L16^T = a
             const int row = c0 + 16 + tid;
             if (row < ns) {
                 double x[16];
@@ -265,16 +293,51 @@ __device__ __forceinline__ void lds_factor(double* D, double* invd, int npan, in
                 const double* Lp = D + c0 * LDD + c0;
 #pragma unroll
                 for (int c = 0; c < 16; ++c) {
-                    double s = x[c];
+                    double sacc = x[c];
 #pragma unroll
-                    for (int k = 0; k < c; ++k) s = fma(-x[k], Lp[c * LDD + k], s);
-                    x[c] = s * invd[c0 + c];
+                    for (int k = 0; k < c; ++k) sacc = fma(-x[k], Lp[c * LDD + k], sacc);
+                    x[c] = sacc * invd[c0 + c];
                 }
 #pragma unroll
                 for (int c = 0; c < 16; c += 2) *reinterpret_cast<d2*>(px + c) = (d2){x[c], x[c + 1]};
             }
+        } else if (wave == 4) {
+            if (p > 0) tile_write(D + (c0 - 16) * LDD + (c0 - 16), xd, lane);
+            if (p < npan) {
+                xd = trinv16_regs(D + c0 * LDD + c0, LDD, invd + c0, lane);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) Xs[(kq + 4 * g) * XS_LD + r] = xd[g];
+            }
+        } else {
+#pragma unroll
+            for (int cnt = 0; cnt < 2; ++cnt) {
+                const int j = widx + 5 * cnt;
+                if (j < p - 1) tile_write(D + (c0 - 16) * LDD + j * 16, keep[cnt], lane);
+            }
+            if (p < npan) sink(p, widx * 64 + lane);
         }
         __syncthreads();
+        if (p == npan) break;
+        if (worker) {
+#pragma unroll
+            for (int cnt = 0; cnt < 2; ++cnt) {
+                const int j = widx + 5 * cnt;
+                if (j >= p) continue;
+                d4 t = zero;
+                for (int k = j; k < p; ++k)
+#pragma unroll
+                    for (int sft = 0; sft < 16; sft += 4) {
+                        const double a = D[(c0 + r) * LDD + k * 16 + sft + kq];
+                        const double b = D[(k * 16 + sft + kq) * LDD + j * 16 + r];
+                        t = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, t, 0, 0, 0);
+                    }
+                d4 x = zero;
+#pragma unroll
+                for (int sft = 0; sft < 4; ++sft)
+                    x = __builtin_amdgcn_mfma_f64_16x16x4f64(-Xs[r * XS_LD + 4 * sft + kq], t[sft], x, 0, 0, 0);
+                keep[cnt] = x;
+            }
+        }
         // trailing update of the lower tiles (rt >= ct > p); tile q = 0 is (p+1, p+1)
         const int m = npan - 1 - p;
         const int ntile = m * (m + 1) / 2;
@@ -288,9 +351,9 @@ __device__ __forceinline__ void lds_factor(double* D, double* invd, int npan, in
             double* C = D + rt * 16 * LDD + ct * 16;
             d4 acc = tile_read(C, lane);
 #pragma unroll
-            for (int s = 0; s < 16; s += 4) {
-                const double a = -D[(rt * 16 + (lane & 15)) * LDD + c0 + s + (lane >> 4)];
-                const double b = D[(ct * 16 + (lane & 15)) * LDD + c0 + s + (lane >> 4)];
+            for (int sft = 0; sft < 16; sft += 4) {
+                const double a = -D[(rt * 16 + (lane & 15)) * LDD + c0 + sft + (lane >> 4)];
+                const double b = D[(ct * 16 + (lane & 15)) * LDD + c0 + sft + (lane >> 4)];
                 acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
             }
             tile_write(C, acc, lane);
@@ -300,68 +363,6 @@ __device__ __forceinline__ void lds_factor(double* D, double* invd, int npan, in
             const int bad = chol16(D + c1 * LDD + c1, invd + c1, lane);
             if (lane == 0 && bad && *s_bad == 0) *s_bad = c1 + bad;
         }
-        __syncthreads();
-    }
-}
-
-// In-place inverse of the lower-triangular block (leading npan*16 rows) by recursive doubling.
-// Precondition: the 16x16 diagonal sub-blocks already hold their inverses with zeros above the
-// diagonal.  Only tiles whose rows lie inside the leading npan*16 rows are touched.
-__device__ __forceinline__ void lds_invert_levels(double* D, int npan, int tid) {
-    const int lane = tid & 63, wave = tid >> 6;
-    const int ns = npan * 16;
-    for (int half = 16; half < ns; half *= 2) {
-        const int ht = half / 16;               // tiles per side of one sub-block
-        const int tiles_per_pair = ht * ht;
-        const int ntile = (NB / (2 * half)) * tiles_per_pair;   // 4, 8, 16  (<= 2 per wave)
-        d4 keep[2];
-        int ti2[2], tj2[2], r02[2], c02[2];
-        bool on2[2];
-#pragma unroll
-        for (int cnt = 0; cnt < 2; ++cnt) {
-            const int q = wave + 8 * cnt;
-            const int pr = q / tiles_per_pair, w = q % tiles_per_pair;
-            ti2[cnt] = w / ht;
-            tj2[cnt] = w % ht;
-            r02[cnt] = (2 * pr + 1) * half;
-            c02[cnt] = 2 * pr * half;
-            on2[cnt] = (q < ntile) && (r02[cnt] + ti2[cnt] * 16 < ns);
-            keep[cnt] = (d4){0.0, 0.0, 0.0, 0.0};
-        }
-        // phase 1: T = L21 * X11 (X11 lower: k-tiles kt >= tj); results stay in registers until every
-        // wave has finished reading L21, then overwrite it
-        for (int kt = 0; kt < ht; ++kt)
-#pragma unroll
-            for (int sft = 0; sft < 16; sft += 4)
-#pragma unroll
-                for (int cnt = 0; cnt < 2; ++cnt) {
-                    if (!on2[cnt] || kt < tj2[cnt]) continue;
-                    const double a = D[(r02[cnt] + ti2[cnt] * 16 + (lane & 15)) * LDD + c02[cnt] + kt * 16 + sft + (lane >> 4)];
-                    const double b = D[(c02[cnt] + kt * 16 + sft + (lane >> 4)) * LDD + c02[cnt] + tj2[cnt] * 16 + (lane & 15)];
-                    keep[cnt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, keep[cnt], 0, 0, 0);
-                }
-        __syncthreads();
-#pragma unroll
-        for (int cnt = 0; cnt < 2; ++cnt)
-            if (on2[cnt]) tile_write(D + (r02[cnt] + ti2[cnt] * 16) * LDD + c02[cnt] + tj2[cnt] * 16, keep[cnt], lane);
-        __syncthreads();
-        // phase 2: X21 = -X22 * T (X22 lower: k-tiles kt <= ti)
-#pragma unroll
-        for (int cnt = 0; cnt < 2; ++cnt) keep[cnt] = (d4){0.0, 0.0, 0.0, 0.0};
-        for (int kt = 0; kt < ht; ++kt)
-#pragma unroll
-            for (int sft = 0; sft < 16; sft += 4)
-#pragma unroll
-                for (int cnt = 0; cnt < 2; ++cnt) {
-                    if (!on2[cnt] || kt > ti2[cnt]) continue;
-                    const double a = -D[(r02[cnt] + ti2[cnt] * 16 + (lane & 15)) * LDD + r02[cnt] + kt * 16 + sft + (lane >> 4)];
-                    const double b = D[(r02[cnt] + kt * 16 + sft + (lane >> 4)) * LDD + c02[cnt] + tj2[cnt] * 16 + (lane & 15)];
-                    keep[cnt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, keep[cnt], 0, 0, 0);
-                }
-        __syncthreads();
-#pragma unroll
-        for (int cnt = 0; cnt < 2; ++cnt)
-            if (on2[cnt]) tile_write(D + (r02[cnt] + ti2[cnt] * 16) * LDD + c02[cnt] + tj2[cnt] * 16, keep[cnt], lane);
         __syncthreads();
     }
 }

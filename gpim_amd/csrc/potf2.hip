@@ -33,7 +33,8 @@ __global__ __launch_bounds__(NTH, 1) void potf2_kernel(double* __restrict__ A, i
                                                        int32_t* __restrict__ info, int nb PROF_ARG) {
     __shared__ __attribute__((aligned(16))) double D[NB * LDD];
     __shared__ double invd[NB];
-    __shared__ double red[128];
+    __shared__ double Xs[16 * XS_LD];
+    __shared__ double red[2];
     __shared__ int s_bad;
     A += (int64_t)blockIdx.y * nb * NB * ld;
     dinv_all += (int64_t)blockIdx.y * nb * NB * NB;
@@ -45,33 +46,29 @@ __global__ __launch_bounds__(NTH, 1) void potf2_kernel(double* __restrict__ A, i
     load_block(D, Ablk, ld, tid);
     __syncthreads();
     STAMP(1);
-    lds_factor(D, invd, 8, &s_bad, tid);
+    // factor and invert in one sweep; block row i of L goes back to HBM (zeros above the diagonal)
+    // during step i, just before the inverse overwrites it in LDS
+    lds_factor_inv(D, invd, Xs, 8, &s_bad, tid, [&](int i, int t) {
+        for (int e = t; e < 16 * 64; e += SINK_THREADS) {
+            const int r = i * 16 + (e >> 6), c = (e & 63) * 2;
+            d2 v;
+            v[0] = (c <= r) ? D[r * LDD + c] : 0.0;
+            v[1] = (c + 1 <= r) ? D[r * LDD + c + 1] : 0.0;
+            *reinterpret_cast<d2*>(Ablk + (int64_t)r * ld + c) = v;
+        }
+    });
     STAMP(2);
-    // L back to HBM (zeros above the diagonal)
-    for (int e = tid; e < NB * NB / 2; e += NTH) {
-        const int r = e >> 6, c = (e & 63) * 2;
-        d2 v;
-        v[0] = (c <= r) ? D[r * LDD + c] : 0.0;
-        v[1] = (c + 1 <= r) ? D[r * LDD + c + 1] : 0.0;
-        *reinterpret_cast<d2*>(Ablk + (int64_t)r * ld + c) = v;
+    // log-determinant partial (fixed order) from the reciprocal pivots
+    if (wave < 2) {
+        const double v = wave_sum(-log(invd[tid]));
+        if (lane == 0) red[wave] = v;
     }
-    // log-determinant partial (fixed tree) from the reciprocal pivots
-    if (tid < 128) red[tid] = -log(invd[tid]);
     __syncthreads();
-    for (int s = 64; s > 0; s >>= 1) {
-        if (tid < s) red[tid] += red[tid + s];
-        __syncthreads();
-    }
     if (tid == 0) {
-        logdet_out[kblk] = red[0];
+        logdet_out[kblk] = red[0] + red[1];
         if (s_bad != 0 && *info == 0) *info = kblk * NB + s_bad;
     }
     STAMP(3);
-    // explicit inverse of the block, in place in LDS: the eight 16x16 diagonal sub-blocks by one wave
-    // each (registers), then recursive doubling 16 -> 32 -> 64 -> 128 on MFMA
-    trinv16(D + wave * 16 * LDD + wave * 16, LDD, invd + wave * 16, D + wave * 16 * LDD + wave * 16, LDD, lane);
-    __syncthreads();
-    lds_invert_levels(D, 8, tid);
     STAMP(4);
     double* dinv = dinv_all + (int64_t)kblk * NB * NB;
     for (int e = tid; e < NB * NB / 2; e += NTH) {

@@ -41,6 +41,7 @@ __global__ __launch_bounds__(NTH, 1) void fit_small_kernel(SmallFitArgs a) {
     __shared__ double xr[NB][4];          // raw coordinates (loaded once)
     __shared__ double xs[NB][5];          // scaled coordinates + squared norm
     __shared__ double yv[NB], zv[NB], al[NB], invd[NB];
+    __shared__ double Xs[16 * XS_LD];         // scratch tile of lds_factor_inv
     __shared__ double red[NTH / 64][12];
     __shared__ ThetaDev sth;
     __shared__ double su[MAXP], sm_[MAXP], sv_[MAXP];
@@ -135,14 +136,11 @@ __global__ __launch_bounds__(NTH, 1) void fit_small_kernel(SmallFitArgs a) {
         }
         __syncthreads();
         SSTAMP(3);
-        lds_factor(D, invd, npan, &s_bad, tid);
+        // Cholesky and triangular inverse in one sweep (the inverse is built block row by block row
+        // behind the factorisation); D holds L^-1 afterwards
+        lds_factor_inv(D, invd, Xs, npan, &s_bad, tid, [](int, int) {});
         SSTAMP(4);
-        // triangular inverse in place: diagonal 16x16 blocks by one wave each, then doubling
-        if (wave < npan) trinv16(D + wave * 16 * LDD + wave * 16, LDD, invd + wave * 16,
-                                 D + wave * 16 * LDD + wave * 16, LDD, lane);
-        __syncthreads();
         SSTAMP(5);
-        lds_invert_levels(D, npan, tid);
         SSTAMP(6);
         // z = L^-1 y: four threads per row (columns q, q+4, ...), quad reduction
         {

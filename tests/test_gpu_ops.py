@@ -100,9 +100,11 @@ def test_potrf_ill_conditioned_kernel_matrix(eng, n, noise):
     ref = torch.linalg.cholesky(A)
     resid_ref = (ref @ ref.T - A).abs().max().item()
     assert resid <= max(4 * resid_ref, 1e-14 * n)
-    # log-determinant agrees with LAPACK's to the conditioning-limited accuracy
+    # the log-determinant is a forward quantity: its error is limited by the conditioning (two backward
+    # stable factorisations -- LAPACK's and this one -- differ by 1e-13 ... 1e-8 relative on these
+    # matrices, tests/tools/illcond_probe.py), so only that much agreement is asked for
     assert_allclose(torch.log(torch.diagonal(L)).sum().item(), torch.log(torch.diagonal(ref)).sum().item(),
-                    rtol=1e-9)
+                    rtol=1e-7)
 
 
 CASES = [("RBF", 7, 2, False), ("RBF", 130, 3, False), ("RBF", 300, 2, True),
