@@ -223,8 +223,12 @@ __device__ __forceinline__ void tile_write(double* C, d4 v, int lane) {
     for (int rg = 0; rg < 4; ++rg) C[((lane >> 4) + 4 * rg) * LDD + (lane & 15)] = v[rg];
 }
 
-__device__ __forceinline__ void load_block(double* D, const double* __restrict__ Ablk, int64_t ld, int tid) {
-    // 128x128 doubles = 8192 16-byte chunks, 16 per thread, all loads in flight before the first store
+// Loads the 128x128 block into D AND factors its first 16x16 tile: all 16 loads of a thread are put in
+// flight, the two chunks that make up rows 0..15 are stored as soon as they arrive, and wave 0 runs
+// chol16 on them while the rest of the block is still on its way (it stores its own remaining
+// chunks afterwards).  Pairs with lds_factor_inv<.., true>.
+__device__ __forceinline__ void load_block_chol0(double* D, double* invd, int* s_bad,
+                                                 const double* __restrict__ Ablk, int64_t ld, int tid) {
     d2 r[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -232,10 +236,21 @@ __device__ __forceinline__ void load_block(double* D, const double* __restrict__
         r[i] = *reinterpret_cast<const d2*>(Ablk + (int64_t)row * ld + c2);
     }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < 2; ++i) {
         const int e = tid + NTH * i, row = e >> 6, c2 = (e & 63) * 2;
         *reinterpret_cast<d2*>(D + row * LDD + c2) = r[i];
     }
+    __syncthreads();
+    if (tid < 64) {
+        const int bad = chol16(D, invd, tid);
+        if (tid == 0 && bad && *s_bad == 0) *s_bad = bad;
+    }
+#pragma unroll
+    for (int i = 2; i < 16; ++i) {
+        const int e = tid + NTH * i, row = e >> 6, c2 = (e & 63) * 2;
+        *reinterpret_cast<d2*>(D + row * LDD + c2) = r[i];
+    }
+    __syncthreads();
 }
 
 
@@ -259,7 +274,8 @@ __device__ __forceinline__ void load_block(double* D, const double* __restrict__
 // Waves 0/1 (panel solve, next diagonal factorisation = the critical path) are not touched.
 #define XS_LD 18
 #define SINK_THREADS 320      // sink(i, t) is called by the five worker waves: t = 0..319
-template <typename Sink>
+// FIRST_DONE: the caller has already factored the first diagonal tile (load_block_chol0).
+template <typename Sink, bool FIRST_DONE = false>
 __device__ __forceinline__ void lds_factor_inv(double* D, double* invd, double* Xs, int npan, int* s_bad, int tid,
                                                Sink sink) {
     const int lane = tid & 63, wave = tid >> 6;
@@ -270,11 +286,13 @@ __device__ __forceinline__ void lds_factor_inv(double* D, double* invd, double* 
     // SIMD with wave 0 -- busy there only while wave 0 runs the (MFMA-free) panel solve
     const int widx = (wave >= 5) ? wave - 3 : wave - 2;      // 0..4 for the workers
     const bool worker = wave >= 2 && wave != 4;
-    if (wave == 0) {
-        const int bad = chol16(D, invd, lane);
-        if (lane == 0 && bad && *s_bad == 0) *s_bad = bad;
+    if (!FIRST_DONE) {
+        if (wave == 0) {
+            const int bad = chol16(D, invd, lane);
+            if (lane == 0 && bad && *s_bad == 0) *s_bad = bad;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     d4 xd = zero, keep[2] = {zero, zero};       // block row p-1 of X, carried into step p
     for (int p = 0; p <= npan; ++p) {
         const int c0 = p * 16;

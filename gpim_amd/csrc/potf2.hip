@@ -42,13 +42,13 @@ __global__ __launch_bounds__(NTH, 1) void potf2_kernel(double* __restrict__ A, i
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double* Ablk = A + ((int64_t)kblk * NB) * ld + (int64_t)kblk * NB;
     if (tid == 0) s_bad = 0;
-    STAMP(0);
-    load_block(D, Ablk, ld, tid);
     __syncthreads();
+    STAMP(0);
+    load_block_chol0(D, invd, &s_bad, Ablk, ld, tid);
     STAMP(1);
     // factor and invert in one sweep; block row i of L goes back to HBM (zeros above the diagonal)
     // during step i, just before the inverse overwrites it in LDS
-    lds_factor_inv(D, invd, Xs, 8, &s_bad, tid, [&](int i, int t) {
+    auto export_row = [&](int i, int t) {
         for (int e = t; e < 16 * 64; e += SINK_THREADS) {
             const int r = i * 16 + (e >> 6), c = (e & 63) * 2;
             d2 v;
@@ -56,7 +56,8 @@ __global__ __launch_bounds__(NTH, 1) void potf2_kernel(double* __restrict__ A, i
             v[1] = (c + 1 <= r) ? D[r * LDD + c + 1] : 0.0;
             *reinterpret_cast<d2*>(Ablk + (int64_t)r * ld + c) = v;
         }
-    });
+    };
+    lds_factor_inv<decltype(export_row), true>(D, invd, Xs, 8, &s_bad, tid, export_row);
     STAMP(2);
     // log-determinant partial (fixed order) from the reciprocal pivots
     if (wave < 2) {
