@@ -28,9 +28,10 @@
  *     (pyro_kernels.py:81-94 Uniform priors -> interval constraints)
  *   - three regimes behind gpimhip_fit_exact, same arithmetic: N <= 128 one fused launch per
  *     training (one workgroup, K/L/L^-1 resident in LDS); mid N the blocked path with one iteration
- *     captured in a hipGraph and replayed; N >~ 12k the blocked path with a look-ahead panel
- *     stream.  Environment switches for A/B testing: GPIMHIP_NO_SMALLN, GPIMHIP_NO_GRAPH,
- *     GPIMHIP_NO_CUMASK (any value disables the respective mechanism).
+ *     captured in a hipGraph and replayed; N >= 6144 the blocked path with a look-ahead panel
+ *     stream (side streams are created on first use).  Environment switches for A/B testing:
+ *     GPIMHIP_NO_SMALLN, GPIMHIP_NO_GRAPH, GPIMHIP_NO_CUMASK (any value disables the respective
+ *     mechanism), GPIMHIP_LOOKAHEAD_MIN_PANELS, GPIMHIP_RESERVED_CUS.
  */
 #ifndef GPIMHIP_H
 #define GPIMHIP_H
