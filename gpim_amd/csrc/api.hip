@@ -41,6 +41,10 @@ void gpim_set_error(const std::string& s) { g_err = s; }
 
 #define RESERVED_CUS 16
 #define LOOKAHEAD_MIN_PANELS_DEFAULT 12
+static int deal_chunk() {
+    static const int v = getenv("GPIMHIP_CHUNK") ? atoi(getenv("GPIMHIP_CHUNK")) : 64;
+    return v;
+}
 static int lookahead_min_panels() {
     static const int v = getenv("GPIMHIP_LOOKAHEAD_MIN_PANELS") ? atoi(getenv("GPIMHIP_LOOKAHEAD_MIN_PANELS")) : LOOKAHEAD_MIN_PANELS_DEFAULT;
     return v;
@@ -453,11 +457,11 @@ int launch_trtri(gpimhip_ctx* h, double* A, double* Tm, int64_t np, int64_t ld) 
     GP_TRY(launch_diag_inv_copy(h, A, ld, nb));
     for (size_t lv = 0; lv < P.tri_t.size(); ++lv) {
         GemmArgs g1 = gemm_args(A, ld, A, ld, Tm, ld, 1.0, 0.0, P.d_tiles + P.tri_t[lv].off, P.tri_t[lv].n, h->np);
-        g1.chunk = 64;
+        g1.chunk = deal_chunk();
         g1.krev = 1;              // ranges [cj, mid) share their end
         GP_TRY(launch_gemm(h, false, true, EPI_STORE, g1));
         GemmArgs g2 = gemm_args(A, ld, Tm, ld, A, ld, -1.0, 0.0, P.d_tiles + P.tri_x[lv].off, P.tri_x[lv].n, h->np);
-        g2.chunk = 64;
+        g2.chunk = deal_chunk();
         GP_TRY(launch_gemm(h, false, true, EPI_STORE, g2));
     }
     return GPIMHIP_OK;
@@ -469,7 +473,7 @@ int launch_lauum(gpimhip_ctx* h, const double* A, double* B, int64_t np, int64_t
     GP_TRY(plan_ensure(h, nb));
     const LinalgPlan& P = h->plan;
     GemmArgs g = gemm_args(A, ld, A, ld, B, ld, 1.0, 0.0, P.d_tiles + P.lauum.off, P.lauum.n, h->np);
-    g.chunk = 64;
+    g.chunk = deal_chunk();
     g.krev = 1;                   // ranges [ci, nb) share their end
     return launch_gemm(h, true, true, EPI_STORE, g);
 }
@@ -758,7 +762,7 @@ static int predict_impl(gpimhip_ctx* h, const gpimhip_model_t* m, const double* 
         GP_TRY(launch_copy_slice(h, h->mean_tmp, mean_out + m0, cnt, mc, M));
         GemmArgs g = gemm_args(h->A, h->ld, h->Ks, kld, nullptr, 0, 1.0, 0.0, h->pred_tiles, 0, h->np);
         g.sB = np * kld;
-        g.chunk = 64;
+        g.chunk = deal_chunk();
         g.colpart = h->colpart;
         g.ld_colpart = mc;
         g.sColpart = (int64_t)nb * mc;

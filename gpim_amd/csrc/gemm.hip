@@ -186,6 +186,10 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_tiles_kernel(GemmArgs g) {
             if (BDIR) stage_direct_km<NW>(g.B, g.ldb, b_n0, b_k0 + koff, An + STAGE, wave, lane);
             else stage_load<B_KM, NT, TSN>(rb, g.B, g.ldb, b_n0, b_k0 + koff, tid);
         }
+        // The MFMA block runs at raised wave priority: the arbiter then prefers this wave's MFMAs and
+        // fragment reads over the other resident wave's staging instructions, which otherwise steal
+        // issue slots from the matrix pipe (tools/gemm_ablate.hip: 66.1 -> 71.2 TFLOP/s for this loop).
+        __builtin_amdgcn_s_setprio(3);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             double a[MT], bb[NTL];
@@ -199,6 +203,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_tiles_kernel(GemmArgs g) {
                 for (int j = 0; j < NTL; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bb[j], acc[i][j], 0, 0, 0);
         }
+        __builtin_amdgcn_s_setprio(0);
         if (more) {
             double* An = smem + ((s + 1) & 1) * 2 * STAGE;
             if (!ADIR) stage_store<A_KM, NT, TSM>(ra, An, tid);

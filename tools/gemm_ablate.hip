@@ -25,14 +25,14 @@ __global__ __launch_bounds__(256, 2) void loop(const double* __restrict__ G, dou
     for (int s = 0; s < steps; ++s) {
         const double* As = smem + (s & 1) * 2 * STAGE;
         const double* Bs = As + STAGE;
-        if (MODE == 3 || MODE == 4 || MODE == 7) {
+        if (MODE == 3 || MODE == 4 || MODE == 7 || MODE == 8) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 ra[i] = *reinterpret_cast<const d2*>(gp + ((s * 8 + i) & 63) * 512);
                 rb[i] = *reinterpret_cast<const d2*>(gp + ((s * 8 + 4 + i) & 63) * 512);
             }
         }
-        if (MODE == 5) {
+        if (MODE == 5 || MODE == 9) {
             // direct global -> LDS: each wave fills whole 1 KB k-rows of the next stage
             double* An = smem + ((s + 1) & 1) * 2 * STAGE;
 #pragma unroll
@@ -44,6 +44,7 @@ __global__ __launch_bounds__(256, 2) void loop(const double* __restrict__ G, dou
                                                  (__attribute__((address_space(3))) void*)(An + STAGE + krow * 144), 16, 0, 0);
             }
         }
+        if (MODE >= 8) __builtin_amdgcn_s_setprio(3);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             double a[4], b[4];
@@ -75,7 +76,8 @@ __global__ __launch_bounds__(256, 2) void loop(const double* __restrict__ G, dou
 #pragma unroll
             for (int i = 0; i < 4; ++i) asm volatile("" :: "v"(ra[i]), "v"(rb[i]));
         }
-        if (MODE == 3 || MODE == 6) {
+        if (MODE >= 8) __builtin_amdgcn_s_setprio(0);
+        if (MODE == 3 || MODE == 6 || MODE == 8) {
             double* An = smem + ((s + 1) & 1) * 2 * STAGE;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -122,6 +124,8 @@ int main() {
         run<7>("barrier + global loads only (no LDS stores)", G, out, wgs);
         run<4>("full loop, LDS stores after kk=1", G, out, wgs);
         run<5>("full loop, direct global->LDS loads", G, out, wgs);
+        run<8>("full loop + s_setprio 3 around the MFMA block", G, out, wgs);
+        run<9>("direct loads + s_setprio 3 around the MFMA block", G, out, wgs);
     }
     return 0;
 }
