@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256, 2) void loop(const double* __restrict__ G, dou
     for (int s = 0; s < steps; ++s) {
         const double* As = smem + (s & 1) * 2 * STAGE;
         const double* Bs = As + STAGE;
-        if (MODE == 3 || MODE == 4 || MODE == 7 || MODE == 8) {
+        if (MODE == 3 || MODE == 4 || MODE == 7 || MODE == 8 || MODE == 10) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 ra[i] = *reinterpret_cast<const d2*>(gp + ((s * 8 + i) & 63) * 512);
@@ -44,7 +44,8 @@ __global__ __launch_bounds__(256, 2) void loop(const double* __restrict__ G, dou
                                                  (__attribute__((address_space(3))) void*)(An + STAGE + krow * 144), 16, 0, 0);
             }
         }
-        if (MODE >= 8) __builtin_amdgcn_s_setprio(3);
+        if (MODE == 8 || MODE == 9) __builtin_amdgcn_s_setprio(3);
+        if (MODE == 10) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             double a[4], b[4];
@@ -76,8 +77,9 @@ __global__ __launch_bounds__(256, 2) void loop(const double* __restrict__ G, dou
 #pragma unroll
             for (int i = 0; i < 4; ++i) asm volatile("" :: "v"(ra[i]), "v"(rb[i]));
         }
-        if (MODE >= 8) __builtin_amdgcn_s_setprio(0);
-        if (MODE == 3 || MODE == 6 || MODE == 8) {
+        if (MODE == 8 || MODE == 9) __builtin_amdgcn_s_setprio(0);
+        if (MODE == 10) __builtin_amdgcn_s_setprio(3);
+        if (MODE == 3 || MODE == 6 || MODE == 8 || MODE == 10) {
             double* An = smem + ((s + 1) & 1) * 2 * STAGE;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -126,6 +128,7 @@ int main() {
         run<5>("full loop, direct global->LDS loads", G, out, wgs);
         run<8>("full loop + s_setprio 3 around the MFMA block", G, out, wgs);
         run<9>("direct loads + s_setprio 3 around the MFMA block", G, out, wgs);
+        run<10>("full loop, staging at prio 3, MFMA block at prio 0", G, out, wgs);
     }
     return 0;
 }
