@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256, 2) void loop(const double* __restrict__ G, dou
                 rb[i] = *reinterpret_cast<const d2*>(gp + ((s * 8 + 4 + i) & 63) * 512);
             }
         }
-        if (MODE == 5 || MODE == 9) {
+        if (MODE == 5 || MODE == 9 || MODE == 11) {
             // direct global -> LDS: each wave fills whole 1 KB k-rows of the next stage
             double* An = smem + ((s + 1) & 1) * 2 * STAGE;
 #pragma unroll
@@ -44,14 +44,20 @@ __global__ __launch_bounds__(256, 2) void loop(const double* __restrict__ G, dou
                                                  (__attribute__((address_space(3))) void*)(An + STAGE + krow * 144), 16, 0, 0);
             }
         }
-        if (MODE == 8 || MODE == 9) __builtin_amdgcn_s_setprio(3);
+        if (MODE == 8 || MODE == 9 || MODE == 11) __builtin_amdgcn_s_setprio(3);
         if (MODE == 10) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             double a[4], b[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                if (MODE >= 1) {
+                if (MODE == 11) {
+                    // k-contiguous tile staged by direct loads: [m/8][(m%8)*8 + ((k/2) ^ (m%8))][k%2]
+                    const int k = kk * 4 + (lane >> 4);
+                    const int ma = wm * 64 + i * 16 + (lane & 15), mb = wn * 64 + i * 16 + (lane & 15);
+                    a[i] = As[(ma >> 3) * 128 + ((ma & 7) * 8 + ((k >> 1) ^ (ma & 7))) * 2 + (k & 1)];
+                    b[i] = Bs[(mb >> 3) * 128 + ((mb & 7) * 8 + ((k >> 1) ^ (mb & 7))) * 2 + (k & 1)];
+                } else if (MODE >= 1) {
                     a[i] = As[(kk * 4 + (lane >> 4)) * 144 + wm * 64 + i * 16 + (lane & 15)];
                     b[i] = Bs[(kk * 4 + (lane >> 4)) * 144 + wn * 64 + i * 16 + (lane & 15)];
                 } else {
@@ -77,7 +83,7 @@ __global__ __launch_bounds__(256, 2) void loop(const double* __restrict__ G, dou
 #pragma unroll
             for (int i = 0; i < 4; ++i) asm volatile("" :: "v"(ra[i]), "v"(rb[i]));
         }
-        if (MODE == 8 || MODE == 9) __builtin_amdgcn_s_setprio(0);
+        if (MODE == 8 || MODE == 9 || MODE == 11) __builtin_amdgcn_s_setprio(0);
         if (MODE == 10) __builtin_amdgcn_s_setprio(3);
         if (MODE == 3 || MODE == 6 || MODE == 8 || MODE == 10) {
             double* An = smem + ((s + 1) & 1) * 2 * STAGE;
@@ -129,6 +135,7 @@ int main() {
         run<8>("full loop + s_setprio 3 around the MFMA block", G, out, wgs);
         run<9>("direct loads + s_setprio 3 around the MFMA block", G, out, wgs);
         run<10>("full loop, staging at prio 3, MFMA block at prio 0", G, out, wgs);
+        run<11>("direct loads + setprio, XOR-swizzled k-contiguous fragment reads", G, out, wgs);
     }
     return 0;
 }
