@@ -301,3 +301,48 @@ def test_nanmax_and_topk(eng):
     _lib.check(H.lib.gpimhip_topk(H.h, _lib.ptr(yd), 500, 10, 0, _lib.ptr(vals), _lib.ptr(idx), _lib.ptr(cnt)))
     assert cnt.item() == 3
     assert idx.cpu().numpy()[:3].tolist() == [410, 3, 77]      # tie: larger flat index first
+
+
+def _fit_once(_lib, H, N, T, seed):
+    """T Adam iterations on a seeded problem through one handle; returns (history, final u)."""
+    from gpim_amd.kernels import KernelSpec
+    X, y = scattered(N, 2, seed=seed, grid=64 if N <= 3000 else 128)
+    torch.manual_seed(seed)
+    spec = KernelSpec("RBF", 2, [[1., 1.], [20., 20.]], jitter=1e-5)
+    u = spec.draw_initial_u().cuda()
+    m = spec.struct()
+    Xd, yd = X.cuda().contiguous(), y.cuda().contiguous()
+    hist = torch.empty(T, spec.n_params, dtype=torch.float64, device="cuda")
+    _lib.check(H.lib.gpimhip_fit_exact(H.h, ctypes.byref(m), _lib.ptr(Xd), _lib.ptr(yd), len(X), _lib.ptr(u),
+                                       0.1, T, _lib.ptr(hist), None))
+    return hist.cpu().numpy(), u.cpu().numpy()
+
+
+def test_handle_reuse_across_sizes_and_regimes(eng):
+    """One handle walks through the three regimes (fused small-N trainer, graph-replayed blocked path,
+    plain launches, look-ahead factorisation on side streams) in growing and shrinking order -- workspace, tile plans and lazily created streams
+    are re-used or rebuilt -- and every result is bit-identical to the one of a fresh handle."""
+    _lib, H = eng
+    sizes = [(100, 12), (700, 10), (1500, 4), (300, 10), (6200, 2), (60, 12), (1500, 4), (6200, 2)]
+    for N, T in sizes:
+        got = _fit_once(_lib, H, N, T, seed=N)
+        fresh = _lib.Handle()
+        try:
+            want = _fit_once(_lib, fresh, N, T, seed=N)
+        finally:
+            fresh.close()
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), N
+
+
+def test_two_handles_interleaved(eng):
+    """Handles share no state: alternating calls on two of them give what each gives alone."""
+    _lib, H = eng
+    H2 = _lib.Handle()
+    try:
+        a1 = _fit_once(_lib, H, 400, 6, seed=1)
+        b1 = _fit_once(_lib, H2, 900, 6, seed=2)
+        a2 = _fit_once(_lib, H, 400, 6, seed=1)
+        b2 = _fit_once(_lib, H2, 900, 6, seed=2)
+    finally:
+        H2.close()
+    assert np.array_equal(a1[0], a2[0]) and np.array_equal(b1[0], b2[0])
