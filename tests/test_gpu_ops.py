@@ -346,3 +346,20 @@ def test_two_handles_interleaved(eng):
     finally:
         H2.close()
     assert np.array_equal(a1[0], a2[0]) and np.array_equal(b1[0], b2[0])
+
+
+@pytest.mark.parametrize("N,T", [(90, 10), (800, 10), (6200, 2)])
+def test_user_stream_matches_default_stream(eng, N, T):
+    """A handle created under a non-default torch stream runs on that stream (fork/join of the
+    look-ahead side streams included) and returns the same bits as one on the default stream."""
+    _lib, H = eng
+    want = _fit_once(_lib, H, N, T, seed=7)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        H2 = _lib.Handle()
+        try:
+            got = _fit_once(_lib, H2, N, T, seed=7)
+        finally:
+            H2.close()
+    s.synchronize()
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
