@@ -79,6 +79,37 @@ __device__ __forceinline__ void stage_direct_km(const double* __restrict__ base,
     }
 }
 
+// The same for a k-contiguous ("MK") operand tile with TS = 128 rows of 16 doubles (128 B): one wave-wide
+// load fetches 8 rows x 8 sixteen-byte chunks (fully coalesced: whole 128-byte lines) and lands as one
+// contiguous 1 KB group in LDS.  LDS position p = lane of the group holds row p>>3, chunk (p&7) ^ (p>>3):
+// the XOR swizzle spreads the fragment reads over the banks (element (m,k) sits at
+// (m>>3)*128 + ((m&7)*8 + ((k>>1) ^ (m&7)))*2 + (k&1); two rows 8 apart share a bank, nothing worse --
+// 0.4 TFLOP/s in tools/gemm_ablate.hip against the padded [128][18] layout it replaces).
+template <int NW>
+__device__ __forceinline__ void stage_direct_mk(const double* __restrict__ base, int64_t ld, int64_t mrow0,
+                                                int64_t kcol0, double* lds, int wave, int lane) {
+    constexpr int GROUPS = 16 / NW;         // 8-row groups per wave
+    const int r8 = lane >> 3, c8 = (lane & 7) ^ r8;
+#pragma unroll
+    for (int i = 0; i < GROUPS; ++i) {
+        const int q = wave * GROUPS + i;
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(base + (mrow0 + q * 8 + r8) * ld + kcol0 + c8 * 2),
+            (__attribute__((address_space(3))) void*)(lds + q * 128), 16, 0, 0);
+    }
+}
+__device__ __forceinline__ double frag_mk_swz(const double* lds, int m0, int kk, int lane) {
+    const int m = m0 + (lane & 15), k = kk * 4 + (lane >> 4);
+    return lds[(m >> 3) * 128 + ((m & 7) * 8 + ((k >> 1) ^ (m & 7))) * 2 + (k & 1)];
+}
+
+template <bool KM, int NW>
+__device__ __forceinline__ void stage_direct(const double* __restrict__ base, int64_t ld, int64_t mrow0, int64_t kcol0,
+                                             double* lds, int wave, int lane) {
+    if (KM) stage_direct_km<NW>(base, ld, mrow0, kcol0, lds, wave, lane);
+    else stage_direct_mk<NW>(base, ld, mrow0, kcol0, lds, wave, lane);
+}
+
 template <bool KM, int TS>
 __device__ __forceinline__ double frag(const double* lds, int m0, int kk, int lane) {
     // element (m = m0 + (lane&15), k = kk*4 + (lane>>4)) of the staged tile; both layouts are
@@ -105,7 +136,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_tiles_kernel(GemmArgs g) {
     constexpr int TSX = TSM > TSN ? TSM : TSN;
     constexpr int STAGE = (TSX * LD_MK > GEMM_BK * (TSX + 16)) ? TSX * LD_MK : GEMM_BK * (TSX + 16);
     constexpr int NCHA = 8 * TSM / NT, NCHB = 8 * TSN / NT;   // 16-byte chunks per thread per stage
-    constexpr bool ADIR = A_KM && TSM == 128, BDIR = B_KM && TSN == 128;   // staged straight into LDS
+    constexpr bool ADIR = TSM == 128, BDIR = TSN == 128;   // 128-wide operand tiles are staged straight into LDS
     __shared__ __attribute__((aligned(16))) double smem[4 * STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -163,9 +194,9 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_tiles_kernel(GemmArgs g) {
     const int64_t kstride = g.krev ? -GEMM_BK : GEMM_BK;
     d2 ra[NCHA], rb[NCHB];
     if (nsteps > 0) {
-        if (ADIR) stage_direct_km<NW>(g.A, g.lda, a_m0, a_k0 + kfirst, smem, wave, lane);
+        if (ADIR) stage_direct<A_KM, NW>(g.A, g.lda, a_m0, a_k0 + kfirst, smem, wave, lane);
         else stage_load<A_KM, NT, TSM>(ra, g.A, g.lda, a_m0, a_k0 + kfirst, tid);
-        if (BDIR) stage_direct_km<NW>(g.B, g.ldb, b_n0, b_k0 + kfirst, smem + STAGE, wave, lane);
+        if (BDIR) stage_direct<B_KM, NW>(g.B, g.ldb, b_n0, b_k0 + kfirst, smem + STAGE, wave, lane);
         else stage_load<B_KM, NT, TSN>(rb, g.B, g.ldb, b_n0, b_k0 + kfirst, tid);
         if (!ADIR) stage_store<A_KM, NT, TSM>(ra, smem, tid);
         if (!BDIR) stage_store<B_KM, NT, TSN>(rb, smem + STAGE, tid);
@@ -181,9 +212,9 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_tiles_kernel(GemmArgs g) {
             // the other stage buffer was last read in step s-1: every wave is past that barrier
             double* An = smem + ((s + 1) & 1) * 2 * STAGE;
             const int64_t koff = kfirst + (int64_t)(s + 1) * kstride;
-            if (ADIR) stage_direct_km<NW>(g.A, g.lda, a_m0, a_k0 + koff, An, wave, lane);
+            if (ADIR) stage_direct<A_KM, NW>(g.A, g.lda, a_m0, a_k0 + koff, An, wave, lane);
             else stage_load<A_KM, NT, TSM>(ra, g.A, g.lda, a_m0, a_k0 + koff, tid);
-            if (BDIR) stage_direct_km<NW>(g.B, g.ldb, b_n0, b_k0 + koff, An + STAGE, wave, lane);
+            if (BDIR) stage_direct<B_KM, NW>(g.B, g.ldb, b_n0, b_k0 + koff, An + STAGE, wave, lane);
             else stage_load<B_KM, NT, TSN>(rb, g.B, g.ldb, b_n0, b_k0 + koff, tid);
         }
         // The MFMA block runs at raised wave priority: the arbiter then prefers this wave's MFMAs and
@@ -194,9 +225,13 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_tiles_kernel(GemmArgs g) {
         for (int kk = 0; kk < 4; ++kk) {
             double a[MT], bb[NTL];
 #pragma unroll
-            for (int i = 0; i < MT; ++i) a[i] = frag<A_KM, TSM>(As, wm * WROWS + i * 16, kk, lane);
+            for (int i = 0; i < MT; ++i)
+                a[i] = (ADIR && !A_KM) ? frag_mk_swz(As, wm * WROWS + i * 16, kk, lane)
+                                       : frag<A_KM, TSM>(As, wm * WROWS + i * 16, kk, lane);
 #pragma unroll
-            for (int j = 0; j < NTL; ++j) bb[j] = frag<B_KM, TSN>(Bs, wn * WCOLS + j * 16, kk, lane);
+            for (int j = 0; j < NTL; ++j)
+                bb[j] = (BDIR && !B_KM) ? frag_mk_swz(Bs, wn * WCOLS + j * 16, kk, lane)
+                                        : frag<B_KM, TSN>(Bs, wn * WCOLS + j * 16, kk, lane);
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
