@@ -1,6 +1,8 @@
 #!/bin/bash
 # Collects the rocprofv3 summaries committed under profiles/ (run on the MI355X box through gpurun;
-# outputs land in gpurun_out/prof_final and are copied into profiles/ by hand).
+# outputs land in gpurun_out/prof_final -- delete that directory on the dev box first, gpurun merges into it and
+# rocprofv3 names its files by process id -- and are copied into profiles/ by hand, then
+# tools/summarize_profiles.py regenerates the derived tables).
 cd /tmp; export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/prof_final
