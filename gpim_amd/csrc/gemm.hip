@@ -11,11 +11,15 @@
 // v_mfma_f64_16x16x4_f64 accumulators (128 VGPRs).  Two more shapes serve launches that cannot fill
 // the chip with one 4-wave workgroup per 128x128 tile: 8 waves per tile (two MFMA waves on every
 // SIMD of the tile's CU) and 64x64 sub-tiles (a 128x128 tile spread over 4 CUs) -- the panel
-// solves / in-panel updates of the Cholesky are latency-bound chains of such small launches.  Operand tiles are staged
-// global -> registers -> LDS (double-buffered, one barrier per 16-deep k-step) in the
-// layout of their source so that every global access is a coalesced 16-byte load:
-//   "MK" operand (row-major, k contiguous):  lds[128][16+2]   fragment read is bank-conflict free
-//   "KM" operand (row-major, m contiguous):  lds[16][128+16]  likewise
+// solves / in-panel updates of the Cholesky are latency-bound chains of such small launches.
+// Operand tiles are double-buffered in LDS, one barrier per 16-deep k-step.  128-wide tiles are staged
+// global -> LDS directly (global_load_lds_dwordx4, one wave-wide 16-byte load per 1 KB of LDS, no
+// VGPR staging and no ds_write); 64-wide tiles go global -> registers -> LDS.  Every global access is
+// a coalesced 16-byte load whatever the transpose:
+//   "KM" operand (row-major, m contiguous):  lds[16][128+16]; one load per k-row
+//   "MK" operand (row-major, k contiguous):  1 KB groups of 8 rows x 8 chunks, chunk index XOR row
+//                                            (direct), or lds[64][16+2] (through registers)
+// The MFMA block of a k-step runs at raised wave priority (s_setprio).
 // v_mfma_f64_16x16x4_f64 lane maps (cdna_hip_programming.md section 3):
 //   A[l&15][l>>4], B[l>>4][l&15], C/D col = l&15, row = (l>>4) + 4*reg.
 #include <stdlib.h>
