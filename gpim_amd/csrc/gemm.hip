@@ -89,10 +89,10 @@ __device__ __forceinline__ void stage_direct_km(const double* __restrict__ base,
 // the XOR swizzle spreads the fragment reads over the banks (element (m,k) sits at
 // (m>>3)*128 + ((m&7)*8 + ((k>>1) ^ (m&7)))*2 + (k&1); two rows 8 apart share a bank, nothing worse --
 // 0.4 TFLOP/s in tools/gemm_ablate.hip against the padded [128][18] layout it replaces).
-template <int NW>
+template <int NW, int TS>
 __device__ __forceinline__ void stage_direct_mk(const double* __restrict__ base, int64_t ld, int64_t mrow0,
                                                 int64_t kcol0, double* lds, int wave, int lane) {
-    constexpr int GROUPS = 16 / NW;         // 8-row groups per wave
+    constexpr int GROUPS = (TS / 8) / NW;   // 8-row groups per wave
     const int r8 = lane >> 3, c8 = (lane & 7) ^ r8;
 #pragma unroll
     for (int i = 0; i < GROUPS; ++i) {
@@ -107,11 +107,11 @@ __device__ __forceinline__ double frag_mk_swz(const double* lds, int m0, int kk,
     return lds[(m >> 3) * 128 + ((m & 7) * 8 + ((k >> 1) ^ (m & 7))) * 2 + (k & 1)];
 }
 
-template <bool KM, int NW>
+template <bool KM, int NW, int TS>
 __device__ __forceinline__ void stage_direct(const double* __restrict__ base, int64_t ld, int64_t mrow0, int64_t kcol0,
                                              double* lds, int wave, int lane) {
     if (KM) stage_direct_km<NW>(base, ld, mrow0, kcol0, lds, wave, lane);
-    else stage_direct_mk<NW>(base, ld, mrow0, kcol0, lds, wave, lane);
+    else stage_direct_mk<NW, TS>(base, ld, mrow0, kcol0, lds, wave, lane);
 }
 
 template <bool KM, int TS>
@@ -140,7 +140,9 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_tiles_kernel(GemmArgs g) {
     constexpr int TSX = TSM > TSN ? TSM : TSN;
     constexpr int STAGE = (TSX * LD_MK > GEMM_BK * (TSX + 16)) ? TSX * LD_MK : GEMM_BK * (TSX + 16);
     constexpr int NCHA = 8 * TSM / NT, NCHB = 8 * TSN / NT;   // 16-byte chunks per thread per stage
-    constexpr bool ADIR = TSM == 128, BDIR = TSN == 128;   // 128-wide operand tiles are staged straight into LDS
+    // staged straight into LDS: every 128-wide operand tile, and 64-wide k-contiguous ones (a 64-wide
+    // m-contiguous k-row is only half a wave-wide load)
+    constexpr bool ADIR = TSM == 128 || !A_KM, BDIR = TSN == 128 || !B_KM;
     __shared__ __attribute__((aligned(16))) double smem[4 * STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -198,9 +200,9 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_tiles_kernel(GemmArgs g) {
     const int64_t kstride = g.krev ? -GEMM_BK : GEMM_BK;
     d2 ra[NCHA], rb[NCHB];
     if (nsteps > 0) {
-        if (ADIR) stage_direct<A_KM, NW>(g.A, g.lda, a_m0, a_k0 + kfirst, smem, wave, lane);
+        if (ADIR) stage_direct<A_KM, NW, TSM>(g.A, g.lda, a_m0, a_k0 + kfirst, smem, wave, lane);
         else stage_load<A_KM, NT, TSM>(ra, g.A, g.lda, a_m0, a_k0 + kfirst, tid);
-        if (BDIR) stage_direct<B_KM, NW>(g.B, g.ldb, b_n0, b_k0 + kfirst, smem + STAGE, wave, lane);
+        if (BDIR) stage_direct<B_KM, NW, TSN>(g.B, g.ldb, b_n0, b_k0 + kfirst, smem + STAGE, wave, lane);
         else stage_load<B_KM, NT, TSN>(rb, g.B, g.ldb, b_n0, b_k0 + kfirst, tid);
         if (!ADIR) stage_store<A_KM, NT, TSM>(ra, smem, tid);
         if (!BDIR) stage_store<B_KM, NT, TSN>(rb, smem + STAGE, tid);
@@ -216,9 +218,9 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_tiles_kernel(GemmArgs g) {
             // the other stage buffer was last read in step s-1: every wave is past that barrier
             double* An = smem + ((s + 1) & 1) * 2 * STAGE;
             const int64_t koff = kfirst + (int64_t)(s + 1) * kstride;
-            if (ADIR) stage_direct<A_KM, NW>(g.A, g.lda, a_m0, a_k0 + koff, An, wave, lane);
+            if (ADIR) stage_direct<A_KM, NW, TSM>(g.A, g.lda, a_m0, a_k0 + koff, An, wave, lane);
             else stage_load<A_KM, NT, TSM>(ra, g.A, g.lda, a_m0, a_k0 + koff, tid);
-            if (BDIR) stage_direct<B_KM, NW>(g.B, g.ldb, b_n0, b_k0 + koff, An + STAGE, wave, lane);
+            if (BDIR) stage_direct<B_KM, NW, TSN>(g.B, g.ldb, b_n0, b_k0 + koff, An + STAGE, wave, lane);
             else stage_load<B_KM, NT, TSN>(rb, g.B, g.ldb, b_n0, b_k0 + koff, tid);
         }
         // The MFMA block runs at raised wave priority: the arbiter then prefers this wave's MFMAs and
