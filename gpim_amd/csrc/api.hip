@@ -505,15 +505,23 @@ static int check_model(const gpimhip_model_t* m) {
 
 // Everything needed at the current u: theta, K, L, L^-1, z, alpha.  (Shared by fit and predict.)
 // x_bs: per-problem stride of X in elements (0 when all problems of a batch share one X).
+// z = L^-1 y, alpha = L^-T z (two HBM-bound passes over L^-1).
+static int solve_vectors(gpimhip_ctx* h) {
+    const int64_t np = h->np, ld = h->ld;
+    GP_TRY(launch_trmv_lower(h, h->A, ld, np, h->ypad, h->z));
+    GP_TRY(launch_gemv_t(h, h->A, ld, np, np, h->z, h->alpha, 1, np * ld, np, np));
+    return GPIMHIP_OK;
+}
+
+// K(u) -> L -> L^-1 (in h->A), and unless `defer_vectors` also z and alpha.
 static int factor_at_u(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X, int64_t x_bs, int64_t N,
-                       const double* u) {
+                       const double* u, bool defer_vectors = false) {
     const int64_t np = h->np, ld = h->ld;
     GP_TRY(launch_theta(h, m, u));
     GP_TRY(launch_kmat(h, m, X, N, nullptr, N, h->theta, 0.0, 1, h->A, ld, np, np, 1, 1, x_bs, x_bs, np * ld));
     { StageTimer t(h, 0); GP_TRY(launch_potrf(h, h->A, np, ld, h->info)); }
     { StageTimer t(h, 1); GP_TRY(launch_trtri(h, h->A, h->Tm, np, ld)); }
-    GP_TRY(launch_trmv_lower(h, h->A, ld, np, h->ypad, h->z));
-    GP_TRY(launch_gemv_t(h, h->A, ld, np, np, h->z, h->alpha, 1, np * ld, np, np));
+    if (!defer_vectors) GP_TRY(solve_vectors(h));
     return GPIMHIP_OK;
 }
 
@@ -523,8 +531,27 @@ static int loss_grad_at_u(gpimhip_ctx* h, const gpimhip_model_t* m, const double
                           double* u, int do_adam, AdamStep st, double* loss_out, double* grad_out,
                           double* hist_row, const IterTable* tab = nullptr) {
     const int64_t np = h->np;
-    GP_TRY(factor_at_u(h, m, X, x_bs, N, u));
-    { StageTimer t(h, 2); GP_TRY(launch_lauum(h, h->A, h->B, np, h->ld)); }
+    // In the look-ahead regime the panel stream exists and is idle after the factorisation: the two
+    // HBM-bound mat-vecs over L^-1 run there, next to the MFMA-bound K^-1 product (both only read L^-1).
+    const bool side = h->panel_stream != nullptr && (int)((np / NB + OUTER_W - 1) / OUTER_W) >= LOOKAHEAD_MIN_PANELS &&
+                      h->ev_pool.size() >= 2;
+    GP_TRY(factor_at_u(h, m, X, x_bs, N, u, side));
+    if (side) {
+        hipStream_t main_s = h->stream;
+        hipEvent_t ev_in = h->ev_pool[0], ev_out = h->ev_pool[1];    // free again once launch_potrf has joined
+        HIP_TRY(hipEventRecord(ev_in, main_s));
+        HIP_TRY(hipStreamWaitEvent(h->panel_stream, ev_in, 0));
+        h->stream = h->panel_stream;
+        const int rc = solve_vectors(h);
+        h->stream = main_s;
+        GP_TRY(rc);
+        HIP_TRY(hipEventRecord(ev_out, h->panel_stream));
+        { StageTimer t(h, 2); GP_TRY(launch_lauum(h, h->A, h->B, np, h->ld)); }
+        HIP_TRY(hipStreamWaitEvent(main_s, ev_out, 0));
+    } else {
+        StageTimer t(h, 2);
+        GP_TRY(launch_lauum(h, h->A, h->B, np, h->ld));
+    }
     GP_TRY(launch_grad_reduce(h, m, h->B, h->ld, X, N, (int)(np / NB), h->alpha, x_bs));
     if (tab)
         GP_TRY(launch_finalize(h, m, N, np, u, do_adam, st, nullptr, nullptr, nullptr, tab->iter, tab->bc, tab->T,
