@@ -37,6 +37,7 @@ _PROTOS = {
     "gpimhip_version": (ctypes.c_int, []),
     "gpimhip_workspace_bytes": (ctypes.c_int64, [ctypes.c_void_p]),
     "gpimhip_sync": (ctypes.c_int, [ctypes.c_void_p]),
+    "gpimhip_fit_completed": (ctypes.c_int, [ctypes.c_void_p]),
     "gpimhip_timing_enable": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "gpimhip_timing_read": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_double),
                                            ctypes.POINTER(ctypes.c_int64)]),

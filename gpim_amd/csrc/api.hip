@@ -108,22 +108,22 @@ static int ws_ensure_b(gpimhip_ctx* h, int64_t N, int B, int padded) {
     HIP_TRY(hipStreamSynchronize(h->stream));
     ws_release_matrix(h);
     const int64_t nb = np / NB;
-    GP_TRY(dev_alloc(h, &h->A, B * np * ld));
-    GP_TRY(dev_alloc(h, &h->B, B * np * ld));
-    GP_TRY(dev_alloc(h, &h->Tm, B * np * ld));
-    h->ld = ld;
-    GP_TRY(dev_alloc(h, &h->dinv, B * nb * NB * NB));
-    GP_TRY(dev_alloc(h, &h->ypad, B * np));
-    GP_TRY(dev_alloc(h, &h->z, B * np));
-    GP_TRY(dev_alloc(h, &h->alpha, B * np));
-    GP_TRY(dev_alloc(h, &h->logdet_part, B * nb));
-    GP_TRY(dev_alloc(h, &h->grad_part, B * nb * (nb + 1) / 2 * 8));
-    GP_TRY(dev_alloc(h, &h->theta, (int64_t)B));
-    GP_TRY(dev_alloc(h, &h->adam_m, (int64_t)B * MAXP));
-    GP_TRY(dev_alloc(h, &h->adam_v, (int64_t)B * MAXP));
-    GP_TRY(dev_alloc(h, &h->iter, (int64_t)B));
+    // sizes first: if an allocation in the middle fails, ws_release_matrix() frees what exists (it
+    // frees by pointer, with these sizes for the byte accounting)
     h->np = np;
     h->ws_batch = B;
+    h->ld = ld;
+    int rc = GPIMHIP_OK;
+    if ((rc = dev_alloc(h, &h->A, B * np * ld)) || (rc = dev_alloc(h, &h->B, B * np * ld)) ||
+        (rc = dev_alloc(h, &h->Tm, B * np * ld)) || (rc = dev_alloc(h, &h->dinv, B * nb * NB * NB)) ||
+        (rc = dev_alloc(h, &h->ypad, B * np)) || (rc = dev_alloc(h, &h->z, B * np)) ||
+        (rc = dev_alloc(h, &h->alpha, B * np)) || (rc = dev_alloc(h, &h->logdet_part, B * nb)) ||
+        (rc = dev_alloc(h, &h->grad_part, B * nb * (nb + 1) / 2 * 8)) || (rc = dev_alloc(h, &h->theta, (int64_t)B)) ||
+        (rc = dev_alloc(h, &h->adam_m, (int64_t)B * MAXP)) || (rc = dev_alloc(h, &h->adam_v, (int64_t)B * MAXP)) ||
+        (rc = dev_alloc(h, &h->iter, (int64_t)B))) {
+        ws_release_matrix(h);
+        return rc;
+    }
     return plan_ensure(h, (int)nb);
 }
 int ws_ensure(gpimhip_ctx* h, int64_t N) { return ws_ensure_b(h, N, h->nbatch, 0); }
@@ -494,7 +494,7 @@ struct StageTimer {
 // N <= 128: the fused single-workgroup trainer (smalln.hip) replaces the blocked path
 static bool use_small_path(int64_t N) { return N <= NB && !getenv("GPIMHIP_NO_SMALLN"); }
 
-static int check_model(const gpimhip_model_t* m) {
+int check_model(const gpimhip_model_t* m) {
     if (!m || m->dim < 1 || m->dim > GPIMHIP_MAX_DIM || (m->n_ls != 1 && m->n_ls != m->dim) ||
         m->kernel < 0 || m->kernel > GPIMHIP_KERNEL_RQ) {
         gpim_set_error("invalid gpimhip_model_t");
@@ -581,17 +581,54 @@ static int upload_bc_table(gpimhip_ctx* h, double lr, int T) {
     return GPIMHIP_OK;
 }
 
+// info[0]: 0 or 1 + first failing column; info[1]: the number of Adam iterations that had completed
+// when a training loop first met a non-PD matrix (min over the problems of a batch; only meaningful
+// when info[0] != 0 -- fit_impl presets it to a large value).
 static int finish_and_check(gpimhip_ctx* h) {
-    int32_t info = 0;
-    HIP_TRY(hipMemcpyAsync(&info, h->info, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    int32_t info[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(info, h->info, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    if (info != 0) {
+    if (info[0] != 0) {
+        h->fit_completed = std::max(0, std::min(h->fit_completed, info[1]));
         gpim_set_error("cholesky: the input is not positive-definite (leading minor of order " +
-                       std::to_string(info) + ")");
+                       std::to_string(info[0]) + ")");
         return GPIMHIP_E_NOT_PD;
     }
     return GPIMHIP_OK;
 }
+
+// Bounded run-ahead for training loops: every `period` iterations the status word is copied to pinned
+// host memory behind an event; before enqueueing more work the host looks at the copy made two periods
+// ago (already complete unless the queue is that short), so a failed factorisation stops the loop
+// within 2 * period iterations while the device queue never drains.  The device side freezes u, the
+// Adam state and the history at the failing iteration on its own (finalize_kernel), so where exactly
+// the host stops enqueueing does not change any result.
+struct RunAhead {
+    gpimhip_ctx* h;
+    int period;
+    bool armed[2] = {false, false};
+    RunAhead(gpimhip_ctx* h_, int64_t np) : h(h_), period(np >= 4096 ? 4 : 32) {
+        if (!h->pinned_info) {
+            void* q = nullptr;
+            if (hipHostMalloc(&q, 2 * sizeof(int32_t), hipHostMallocDefault) == hipSuccess) h->pinned_info = (int32_t*)q;
+            for (auto& e : h->ra_ev)
+                if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr;
+        }
+    }
+    // call before enqueueing iteration t; returns true when the loop should stop
+    bool stop(int t) {
+        if (!h->pinned_info || !h->ra_ev[0] || !h->ra_ev[1] || t == 0 || t % period) return false;
+        const int slot = (t / period) & 1;
+        if (armed[slot]) {
+            (void)hipEventSynchronize(h->ra_ev[slot]);
+            if (h->pinned_info[slot] != 0) return true;
+        }
+        (void)hipMemcpyAsync(h->pinned_info + slot, h->info, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream);
+        (void)hipEventRecord(h->ra_ev[slot], h->stream);
+        armed[slot] = true;
+        return false;
+    }
+};
 
 int vfe_finish_and_check(gpimhip_ctx* h) { return finish_and_check(h); }
 void vfe_release(gpimhip_ctx* h);
@@ -636,6 +673,9 @@ int gpimhip_destroy(gpimhip_handle h) {
     dev_free(h, &h->info, 4);
     if (h->plan.d_tiles) (void)hipFree(h->plan.d_tiles);
     for (auto e : h->ev_pool) (void)hipEventDestroy(e);
+    for (auto e : h->ra_ev)
+        if (e) (void)hipEventDestroy(e);
+    if (h->pinned_info) (void)hipHostFree(h->pinned_info);
     if (h->panel_stream) (void)hipStreamDestroy(h->panel_stream);
     if (h->bulk_stream) (void)hipStreamDestroy(h->bulk_stream);
     if (h->capture_stream) (void)hipStreamDestroy(h->capture_stream);
@@ -667,6 +707,8 @@ int gpimhip_timing_read(gpimhip_handle h, int stage, double* total_ms, int64_t* 
     h->ev[stage].clear();
     return GPIMHIP_OK;
 }
+
+int gpimhip_fit_completed(gpimhip_handle h) { return h ? h->fit_completed : 0; }
 
 int gpimhip_sync(gpimhip_handle h) {
     if (!h) return GPIMHIP_E_BADARG;
@@ -712,6 +754,8 @@ static int fit_impl(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X, i
     HIP_TRY(hipSetDevice(h->device));
     h->nbatch = B;
     HIP_TRY(hipMemsetAsync(h->info, 0, sizeof(int32_t), h->stream));
+    HIP_TRY(hipMemsetAsync(h->info + 1, 0x7f, sizeof(int32_t), h->stream));   // "completed" = huge until a failure
+    h->fit_completed = T;
     if (T == 0) return GPIMHIP_OK;
     GP_TRY(upload_bc_table(h, lr, T));
     if (use_small_path(N)) {
@@ -748,16 +792,20 @@ static int fit_impl(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X, i
         h->stream = main_s;
         if (rc != GPIMHIP_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
         if (e == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
-            for (int t = 0; t < T; ++t) HIP_TRY(hipGraphLaunch(exec, main_s));
+            RunAhead ra(h, h->np);
+            hipError_t le = hipSuccess;
+            for (int t = 0; t < T && le == hipSuccess && !ra.stop(t); ++t) le = hipGraphLaunch(exec, main_s);
             rc = finish_and_check(h);
             (void)hipGraphExecDestroy(exec);
             (void)hipGraphDestroy(graph);
+            HIP_TRY(le);
             return rc;
         }
         if (graph) (void)hipGraphDestroy(graph);
         (void)hipGetLastError();                        // capture unavailable: plain launches below
     }
-    for (int t = 0; t < T; ++t)
+    RunAhead ra(h, h->np);
+    for (int t = 0; t < T && !ra.stop(t); ++t)
         GP_TRY(loss_grad_at_u(h, m, X, x_bs, N, u, 1, st, nullptr, nullptr, nullptr, &tab));
     return finish_and_check(h);
 }

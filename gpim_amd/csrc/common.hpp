@@ -120,6 +120,13 @@ struct gpimhip_ctx {
     // top-k scratch
     unsigned long long* keys = nullptr;
     int64_t keys_cap = 0;
+    // training-loop bookkeeping: iterations completed by the last fit call, pinned copy of the status
+    // word + events of the bounded run-ahead check (api.hip: RunAhead)
+    int fit_completed = 0;
+    int32_t* pinned_info = nullptr;
+    hipEvent_t ra_ev[2] = {nullptr, nullptr};
+    // sparse (VFE) workspace, owned by vfe.hip (VfeWs*); released by vfe_release()
+    void* vfe = nullptr;
 };
 
 static inline int64_t pad_to(int64_t n, int64_t m) { return (n + m - 1) / m * m; }

@@ -458,7 +458,8 @@ __global__ __launch_bounds__(256) void finalize_kernel(gpimhip_model_t m, int64_
                                                        double* __restrict__ adam_m, double* __restrict__ adam_v,
                                                        int do_adam, AdamStep st, double* __restrict__ loss_out,
                                                        double* __restrict__ grad_out,
-                                                       double* __restrict__ hist_row, FinalizeIter fi) {
+                                                       double* __restrict__ hist_row, FinalizeIter fi,
+                                                       int32_t* __restrict__ info) {
     __shared__ double red[256];
     __shared__ double S[8];
     const int tid = threadIdx.x;
@@ -494,6 +495,13 @@ __global__ __launch_bounds__(256) void finalize_kernel(gpimhip_model_t m, int64_
 
     if (fi.iter) {
         const int it = *fi.iter;
+        // A factorisation of this training loop has failed (this iteration's, or an earlier one of any
+        // problem of the batch): the reference raises here (gpr.py:192), with u, the Adam state and the
+        // history as the previous iteration left them.  Freeze them; record how far the loop got.
+        if (*info != 0) {
+            atomicMin(info + 1, it);
+            return;
+        }
         const int P = 2 + m.n_ls + (m.kernel == GPIMHIP_KERNEL_RQ ? 1 : 0);
         st.lr_over_bc1 = fi.bc[it];
         st.bc2_sqrt = fi.bc[fi.T + it];
@@ -512,7 +520,7 @@ int launch_finalize(gpimhip_ctx* h, const gpimhip_model_t* m, int64_t N, int64_t
     FinalizeIter fi{iter, bc, T, hist_base, loss_base};
     hipLaunchKernelGGL(finalize_kernel, dim3(1, h->nbatch), dim3(256), 0, h->stream, *m, N, np, nb, nb * (nb + 1) / 2,
                        h->grad_part, h->z, h->logdet_part, h->theta, u, h->adam_m, h->adam_v, do_adam, st,
-                       loss_out, grad_out, hist_row, fi);
+                       loss_out, grad_out, hist_row, fi, h->info);
     HIP_TRY(hipGetLastError());
     return GPIMHIP_OK;
 }

@@ -139,6 +139,13 @@ __global__ __launch_bounds__(NTH, 1) void fit_small_kernel(SmallFitArgs a) {
         // Cholesky and triangular inverse in one sweep (the inverse is built block row by block row
         // behind the factorisation); D holds L^-1 afterwards
         lds_factor_inv(D, invd, Xs, npan, &s_bad, tid, [](int, int) {});
+        // not positive-definite: the reference raises at this iteration (gpr.py:192) with u, the Adam
+        // state and the history as the previous one left them -- stop here, record how far we got
+        __syncthreads();
+        if (s_bad != 0) {
+            if (tid == 0 && a.T > 0) atomicMin(a.info + 1, it);
+            break;
+        }
         SSTAMP(4);
         SSTAMP(5);
         SSTAMP(6);

@@ -20,7 +20,6 @@
 #include <stdlib.h>
 #include <algorithm>
 #include <map>
-#include <mutex>
 #include "kfun.hpp"
 #include "theta.hpp"
 
@@ -66,8 +65,7 @@ struct VfeWs {
     int n_ptiles = 0;
 };
 
-static std::map<gpimhip_ctx*, VfeWs> g_vfe;      // per-handle sparse workspace
-static std::mutex g_vfe_mu;
+// the sparse workspace hangs off the handle (gpimhip_ctx::vfe); the library keeps no global state
 
 template <typename T>
 static int valloc(T** p, int64_t n) {
@@ -88,21 +86,17 @@ static void vfe_free(VfeWs& w) {
     w = VfeWs();
 }
 void vfe_release(gpimhip_ctx* h) {
-    std::lock_guard<std::mutex> lk(g_vfe_mu);
-    auto it = g_vfe.find(h);
-    if (it != g_vfe.end()) {
-        vfe_free(it->second);
-        g_vfe.erase(it);
+    VfeWs* w = static_cast<VfeWs*>(h->vfe);
+    if (w) {
+        vfe_free(*w);
+        delete w;
+        h->vfe = nullptr;
     }
 }
 
 static int vfe_ensure(gpimhip_ctx* h, int64_t Mu, int64_t N, int d, int P, VfeWs** out) {
-    VfeWs* wp;
-    {
-        std::lock_guard<std::mutex> lk(g_vfe_mu);
-        wp = &g_vfe[h];                       // std::map nodes are address-stable
-    }
-    VfeWs& w = *wp;
+    if (!h->vfe) h->vfe = new VfeWs();
+    VfeWs& w = *static_cast<VfeWs*>(h->vfe);
     const int64_t mp = pad_to(Mu, NB), nq = pad_to(N, NB);
     *out = &w;
     if (w.mp == mp && w.nq == nq) return GPIMHIP_OK;
@@ -340,6 +334,7 @@ struct VfeFinalArgs {
     int do_adam;
     int32_t* iter; const double* bc; int32_t T;
     double *hist_theta, *hist_xu, *loss_out, *grad_out;
+    int32_t* info;                  // [0] factorisation status, [1] iterations completed at the first failure
 };
 
 __device__ double vfe_block_sum(double v, double* red) {
@@ -363,6 +358,12 @@ __global__ __launch_bounds__(256) void vfe_finalize_kernel(VfeFinalArgs a) {
     const int tid = threadIdx.x;
     const int d = a.m.dim;
     const int P = 2 + a.m.n_ls + (a.m.kernel == GPIMHIP_KERNEL_RQ ? 1 : 0);
+    // a factorisation of this training loop failed: freeze u, Xu, the Adam state and the histories at
+    // the failing iteration (the reference raises there, gpr.py:192) and record how far the loop got
+    if (a.iter && *a.info != 0) {
+        if (tid == 0) atomicMin(a.info + 1, *a.iter);
+        return;
+    }
     for (int k = 0; k < 7; ++k) {
         double v = 0.0;
         for (int q = tid; q < a.mb * a.nbq; q += 256) v += a.part_rect[(int64_t)q * 8 + k];
@@ -582,6 +583,7 @@ static int vfe_loss_grad(gpimhip_ctx* h, VfeWs& w, const gpimhip_model_t* m, con
     a.yq = w.yq; a.wtb = w.wtb; a.v = w.v; a.c1 = w.c1; a.beta = w.beta; a.Cs = w.Cs; a.Vc = w.Vc;
     a.logdet_part = h->logdet_part; a.th = h->theta; a.u = u; a.adam_m = w.adam_m; a.adam_v = w.adam_v;
     a.do_adam = do_adam;
+    a.info = h->info;
     if (it) { a.iter = it->iter; a.bc = it->bc; a.T = it->T; a.hist_theta = it->hist_theta; a.hist_xu = it->hist_xu; a.loss_out = it->loss; }
     else { a.loss_out = loss_out; a.grad_out = grad_out; }
     hipLaunchKernelGGL(vfe_finalize_kernel, dim3(1), dim3(256), 0, h->stream, a);
@@ -589,8 +591,15 @@ static int vfe_loss_grad(gpimhip_ctx* h, VfeWs& w, const gpimhip_model_t* m, con
     return GPIMHIP_OK;
 }
 
+int check_model(const gpimhip_model_t* m);
+
 static int vfe_prepare(gpimhip_ctx* h, const gpimhip_model_t* m, const double* y, int64_t N, int64_t Mu, int P,
                        VfeWs** w) {
+    GP_TRY(check_model(m));
+    if (Mu > N) {
+        gpim_set_error("sparse GP: more inducing inputs than observations");
+        return GPIMHIP_E_BADARG;
+    }
     HIP_TRY(hipSetDevice(h->device));
     h->nbatch = 1;
     GP_TRY(ws_ensure(h, Mu));                                  // mp x mp blocked-algorithm workspace
@@ -619,6 +628,8 @@ int gpimhip_fit_vfe(gpimhip_handle h, const gpimhip_model_t* m, const double* X,
     const int P = 2 + m->n_ls + (m->kernel == GPIMHIP_KERNEL_RQ ? 1 : 0);
     VfeWs* w;
     GP_TRY(vfe_prepare(h, m, y, N, Mu, P, &w));
+    HIP_TRY(hipMemsetAsync(h->info + 1, 0x7f, sizeof(int32_t), h->stream));
+    h->fit_completed = T;
     if (T == 0) return GPIMHIP_OK;
     const int64_t na = P + w->mp * GPIMHIP_MAX_DIM;
     HIP_TRY(hipMemsetAsync(w->adam_m, 0, na * sizeof(double), h->stream));

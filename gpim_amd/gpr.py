@@ -14,14 +14,18 @@ Deliberate differences from the reference, all on the outside of the numerics:
   * the initial hyper-parameters are always drawn with torch's CPU generator (the reference does
     that on its CPU path; its CUDA path uses the CUDA generator and is not reproducible).
   * no process-global side effects: torch's default tensor type is left alone.
-  * a non-positive-definite covariance is reported at the end of ``train``/``predict`` (the
-    device loop runs without host synchronisation) instead of at the failing iteration.
+  * a non-positive-definite covariance during training freezes the hyper-parameters, the optimiser
+    and the history on the device at the failing iteration (what the reference's state is when
+    torch.linalg.cholesky raises, gpr.py:192); the host stops enqueueing a bounded number of
+    iterations later and ``train`` raises the same exception class with the history up to that
+    iteration appended, so the reconstructor stays usable.
   * ``precision='single'``: inputs are taken, the initial hyper-parameters drawn and the results
     returned in float32 like the reference does, but the arithmetic in between stays fp64 (the
     engine has no fp32 path; results are at least as accurate as a float32 run, not bit-comparable
     to one).
 """
 import ctypes
+import random
 import time
 import warnings
 
@@ -123,7 +127,11 @@ class reconstructor:
         self._handle = _lib.Handle()          # raises if there is no GPU / no library
         self._dev = self._handle.device
         self.verbose = verbose
+        # pyro.set_rng_seed(seed) at gpr.py:101 seeds torch, numpy and Python's random: the boptimizer
+        # paths that draw from np.random (checkvalues' exit strategy, update_points' padding) depend on it
         torch.manual_seed(seed)
+        np.random.seed(seed)
+        random.seed(seed)
         input_dim = np.ndim(y)
         self.X, self.y = gprutils.prepare_training_data(X, y, precision=self.precision)
         self.do_sparse = bool(sparse)
@@ -217,7 +225,13 @@ class reconstructor:
                 self._handle.h, ctypes.byref(self._mstruct), _lib.ptr(self._Xd), _lib.ptr(self._yd),
                 self._Xd.shape[0], self._n_ind, _lib.ptr(self._u), float(self.learning_rate), T,
                 _lib.ptr(hist), _lib.ptr(hist_xu), _lib.ptr(loss))
-        _lib.check(rc)
+        failed = rc == _lib.E_NOT_PD
+        if failed:
+            # the device loop froze the parameters at the failing iteration: keep the history up to it
+            # and raise what torch.linalg.cholesky raises there in the reference (gpr.py:192)
+            T = int(self._handle.lib.gpimhip_fit_completed(self._handle.h))
+        else:
+            _lib.check(rc)
         if self.do_sparse and T > 0:
             self.indpoints_all.extend(list(hist_xu[:T].cpu().numpy()))
         hist_h = hist[:T].cpu().numpy()
@@ -235,6 +249,8 @@ class reconstructor:
                       'amp: {} ...'.format(np.around(self.amp_all[-1], 4)),
                       'length: {} ...'.format(np.around(self.lscales[-1], 4)),
                       'noise: {} ...'.format(np.around(self.noise_all[-1], 7)))
+        if failed:
+            _lib.check(rc)
         if self.verbose:
             dt = time.time() - start_time
             if T > 0:

@@ -18,7 +18,9 @@
  *     gpimhip_last_error().  Non-positive-definite detection is asynchronous: the
  *     factorisation records the first failing column in a device word that
  *     gpimhip_fit_exact / gpimhip_predict_exact read back at their final sync and
- *     report as GPIMHIP_E_NOT_PD (torch.linalg.cholesky raises at gpr.py:192,248).
+ *     report as GPIMHIP_E_NOT_PD (torch.linalg.cholesky raises at gpr.py:192,248).  Training loops stop
+ *     updating on the device at the failing iteration and stop being enqueued a bounded number of
+ *     iterations later (see gpimhip_fit_completed).
  *   - parameter vector u (unconstrained, the thing Adam updates), length
  *     P = 2 + n_ls (+1 for RationalQuadratic):
  *         u[0]            variance      sigma^2 = amp_lo + (amp_hi-amp_lo)*sigmoid(u)
@@ -201,6 +203,13 @@ int gpimhip_topk(gpimhip_handle h, const double* acq, int64_t M, int32_t k, int3
  * intervals since the last read, and clears them. */
 int gpimhip_timing_enable(gpimhip_handle h, int enable);
 int gpimhip_timing_read(gpimhip_handle h, int stage, double* total_ms, int64_t* count);
+
+/* Number of Adam iterations the last gpimhip_fit_exact[_batched] / gpimhip_fit_vfe call completed: T,
+ * or -- when that call returned GPIMHIP_E_NOT_PD -- the index of the iteration whose covariance was not
+ * positive-definite.  The device loop freezes u, the optimiser state and the history rows at that
+ * iteration (the reference raises there, gpr.py:192, with the parameters of the previous step), so
+ * u_inout and the first gpimhip_fit_completed() rows of hist_out / loss_out are valid after the error. */
+int gpimhip_fit_completed(gpimhip_handle h);
 
 /* Block until everything enqueued on the handle's stream has finished. */
 int gpimhip_sync(gpimhip_handle h);

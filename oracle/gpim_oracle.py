@@ -41,6 +41,7 @@ test/test_gpreg.py:24-36); for those this file follows Pyro's documented formula
 """
 
 import math
+import random
 import types
 import warnings
 
@@ -342,7 +343,10 @@ class reconstructor:
         if kwargs.get("precision", "double") != "double":
             raise NotImplementedError("oracle restates the double-precision path only")
         self.verbose = verbose
+        # pyro.set_rng_seed(seed) (gpr.py:101): torch.manual_seed + random.seed + np.random.seed
         torch.manual_seed(seed)
+        random.seed(seed)
+        np.random.seed(seed)
         input_dim = np.ndim(y)
         self.X, self.y = prepare_training_data(X, y)
         if lengthscale is None and not kwargs.get("isotropic"):

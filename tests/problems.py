@@ -102,3 +102,33 @@ def hyperspectral_cube(size=64, nspec=64, keep=0.30, seed=3):
     mask = rng.random((size, size)) < keep
     R = np.where(mask[..., None], cube, np.nan)
     return R, cube
+
+
+def ckpfm_cube(nx=10, ny=10, nv=64, ns=5, seed=5):
+    """Synthetic twin of config C5: a 10 x 10 x Nv x Ns cKPFM response -- a smooth,
+    nearly separable 4-D function (hysteresis-like tanh in the voltage axis whose offset drifts over
+    the (x, y) grid and with the read step) + noise; fully observed, like the reference's
+    Nd_mat_amp * cos(Nd_mat_phase) cube (examples/notebooks/GP_TD_cKPFM.ipynb:332-339)."""
+    rng = np.random.default_rng(seed)
+    i, j, v, s = np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nv), np.arange(ns), indexing="ij")
+    v0 = nv / 2 + 0.12 * nv * np.sin(i / 3.0) * np.cos(j / 4.0) + 1.5 * (s - ns / 2)
+    cube = (1.0 + 0.2 * np.cos((i + j) / 5.0)) * np.tanh((v - v0) / (0.12 * nv)) * (1.0 - 0.08 * s)
+    return cube + 0.02 * rng.standard_normal(cube.shape)
+
+
+class oracle_threads:
+    """Lets the CPU oracle use the host's cores for one large comparison (the suite otherwise runs
+    torch single-threaded, which is fastest for the many tiny-N oracle loops)."""
+
+    def __init__(self, n=32):
+        self.n = n
+
+    def __enter__(self):
+        import os
+        import torch
+        self.prev = torch.get_num_threads()
+        torch.set_num_threads(max(1, min(self.n, os.cpu_count() or 1)))
+
+    def __exit__(self, *a):
+        import torch
+        torch.set_num_threads(self.prev)

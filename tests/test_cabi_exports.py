@@ -44,3 +44,25 @@ def test_product_fails_loudly_without_gpu(ensure_built):
     R[::2, ::2] = np.nan
     with pytest.raises(RuntimeError):
         gpim_amd.reconstructor(gpim_amd.utils.get_sparse_grid(R), R, gpim_amd.utils.get_full_grid(R))
+
+
+def test_gpim_alias_package():
+    """``import gpim`` resolves to the engine under the reference's own names (gpim/__init__.py:1-5
+    and the sub-module paths user code imports from)."""
+    import gpim
+    import gpim_amd
+    assert gpim.reconstructor is gpim_amd.reconstructor
+    assert gpim.boptimizer is gpim_amd.boptimizer
+    assert gpim.utils.get_sparse_grid is gpim_amd.utils.get_sparse_grid
+    from gpim.gpreg.gpr import reconstructor
+    from gpim.gpbayes.boptim import boptimizer
+    from gpim.gpbayes import acqfunc
+    from gpim.kernels.pyro_kernels import get_kernel
+    from gpim import gprutils
+    assert reconstructor is gpim_amd.reconstructor and boptimizer is gpim_amd.boptimizer
+    assert acqfunc.expected_improvement is gpim_amd.acqfunc.expected_improvement
+    assert get_kernel("RBF", 2, [[0., 0.], [5., 5.]]).n_params == 4
+    assert gprutils.get_full_grid is gpim_amd.utils.get_full_grid
+    import pytest
+    with pytest.raises(NotImplementedError):
+        gpim.skreconstructor()
