@@ -6,9 +6,10 @@ A script written for ziatdinovmax/GPim (``import gpim; gpim.reconstructor(...).r
 directory on ``sys.path``: the names of the reference's package root that are on the hot path
 (gpim/__init__.py:1-5: ``utils``, ``reconstructor``, ``boptimizer``) and the sub-module paths that
 user code imports from (``gpim.gpreg.gpr``, ``gpim.gpbayes.boptim``, ``gpim.gpbayes.acqfunc``,
-``gpim.kernels.pyro_kernels``, ``gpim.gprutils``) resolve to ``gpim_amd``.  The GPyTorch-based
-``skreconstructor`` / ``vreconstructor`` are outside the scope of this engine and
-raise NotImplementedError when called.
+``gpim.kernels.pyro_kernels``, ``gpim.gprutils``) resolve to ``gpim_amd``.  ``skreconstructor``
+resolves to the engine's exact Kronecker-structured reconstructor (gpim_amd/skgpr.py); the GPyTorch-based
+vector-valued ``vreconstructor`` is outside the scope of this engine and raises
+NotImplementedError when called.
 """
 from gpim_amd import gprutils as utils            # noqa: F401
 from gpim_amd import gprutils                     # noqa: F401  (``from gpim import gprutils``)
@@ -26,7 +27,8 @@ def _out_of_scope(name):
     return ctor
 
 
-skreconstructor = _out_of_scope("skreconstructor")
+from gpim_amd.skgpr import skreconstructor        # noqa: F401,E402  (exact Kronecker solver in the SKI class's role)
+
 vreconstructor = _out_of_scope("vreconstructor")
 
 __all__ = ["utils", "reconstructor", "boptimizer", "skreconstructor", "vreconstructor"]

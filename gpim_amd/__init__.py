@@ -5,8 +5,9 @@ part that is in scope: ``reconstructor``, ``boptimizer``, ``utils``.
 """
 from . import gprutils as utils
 from .gpr import reconstructor
+from .skgpr import skreconstructor
 from .boptim import boptimizer
 from . import acqfunc
 
-__all__ = ["reconstructor", "boptimizer", "utils", "acqfunc"]
+__all__ = ["reconstructor", "skreconstructor", "boptimizer", "utils", "acqfunc"]
 __version__ = "0.1.0"

@@ -62,6 +62,14 @@ _PROTOS = {
                                        ctypes.c_int64, c_dp, ctypes.c_double, ctypes.c_int32, c_dp, c_dp, c_dp]),
     "gpimhip_predict_vfe": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ModelStruct), c_dp, c_dp, ctypes.c_int64,
                                            ctypes.c_int64, c_dp, c_dp, ctypes.c_int64, c_dp, c_dp]),
+    "gpimhip_kron_nll_grad": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ModelStruct), ctypes.c_int32,
+                                             ctypes.POINTER(ctypes.c_int32), c_dp, c_dp, c_dp, c_dp, c_dp]),
+    "gpimhip_fit_kron": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ModelStruct), ctypes.c_int32,
+                                        ctypes.POINTER(ctypes.c_int32), c_dp, c_dp, c_dp, ctypes.c_double,
+                                        ctypes.c_int32, c_dp, c_dp]),
+    "gpimhip_predict_kron": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ModelStruct), ctypes.c_int32,
+                                            ctypes.POINTER(ctypes.c_int32), c_dp, c_dp, c_dp,
+                                            ctypes.POINTER(ctypes.c_int32), c_dp, c_dp, c_dp]),
     "gpimhip_acq": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, c_dp, c_dp, ctypes.c_int64, ctypes.c_double,
                                    ctypes.c_double, c_dp, c_dp]),
     "gpimhip_nanmax": (ctypes.c_int, [ctypes.c_void_p, c_dp, ctypes.c_int64, c_dp]),

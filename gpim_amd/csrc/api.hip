@@ -563,7 +563,7 @@ static int loss_grad_at_u(gpimhip_ctx* h, const gpimhip_model_t* m, const double
 }
 
 // Fill the device table of Adam bias corrections (same libm pow() values for every path).
-static int upload_bc_table(gpimhip_ctx* h, double lr, int T) {
+int upload_bc_table(gpimhip_ctx* h, double lr, int T) {
     if (h->bc_cap < 2 * (int64_t)T) {
         HIP_TRY(hipStreamSynchronize(h->stream));
         dev_free(h, &h->bc, h->bc_cap);
@@ -584,7 +584,7 @@ static int upload_bc_table(gpimhip_ctx* h, double lr, int T) {
 // info[0]: 0 or 1 + first failing column; info[1]: the number of Adam iterations that had completed
 // when a training loop first met a non-PD matrix (min over the problems of a batch; only meaningful
 // when info[0] != 0 -- fit_impl presets it to a large value).
-static int finish_and_check(gpimhip_ctx* h) {
+int finish_and_check(gpimhip_ctx* h) {
     int32_t info[2] = {0, 0};
     HIP_TRY(hipMemcpyAsync(info, h->info, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -632,6 +632,7 @@ struct RunAhead {
 
 int vfe_finish_and_check(gpimhip_ctx* h) { return finish_and_check(h); }
 void vfe_release(gpimhip_ctx* h);
+void kron_release(gpimhip_ctx* h);
 
 // ------------------------------------------------------------------------------------------
 // C ABI
@@ -662,6 +663,7 @@ int gpimhip_destroy(gpimhip_handle h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     vfe_release(h);
+    kron_release(h);
     ws_release_matrix(h);
     dev_free(h, &h->Ks, h->ks_batch * h->ks_rows * (h->ks_cols + 16));
     dev_free(h, &h->colpart, h->ks_batch * (h->ks_rows / NB) * h->ks_cols);

@@ -127,6 +127,8 @@ struct gpimhip_ctx {
     hipEvent_t ra_ev[2] = {nullptr, nullptr};
     // sparse (VFE) workspace, owned by vfe.hip (VfeWs*); released by vfe_release()
     void* vfe = nullptr;
+    // structured (Kronecker) workspace, owned by kron.hip (KronWs*); released by kron_release()
+    void* kron = nullptr;
 };
 
 static inline int64_t pad_to(int64_t n, int64_t m) { return (n + m - 1) / m * m; }

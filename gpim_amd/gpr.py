@@ -117,6 +117,12 @@ class reconstructor:
         verbose (int): 0, 1 or 2
         seed (int): seeds the CPU generator used for the initial hyper-parameter draw
         **amplitude, **precision, **jitter, **isotropic: as in the reference
+        **structured (bool): gpim_amd extension -- exact GP through the Kronecker structure of the
+            covariance (csrc/kron.hip).  Requires fully observed data on a product grid (X as returned
+            by ``utils.get_full_grid``) and the RBF kernel; same model, parameterisation and results as
+            the dense path, O(sum n_i^3 + N sum n_i) instead of O(N^3) work.  Takes the role of the
+            reference's structured-kernel ``skreconstructor`` (gpim/gpreg/skgpr.py), exact rather than
+            interpolated.
     """
 
     def __init__(self, X, y, Xtest=None, kernel='RBF', lengthscale=None, sparse=False,
@@ -135,6 +141,15 @@ class reconstructor:
         input_dim = np.ndim(y)
         self.X, self.y = gprutils.prepare_training_data(X, y, precision=self.precision)
         self.do_sparse = bool(sparse)
+        self.do_structured = bool(kwargs.get("structured", False))
+        if self.do_structured:
+            if self.do_sparse:
+                raise NotImplementedError("structured=True and sparse=True are mutually exclusive")
+            if kernel != "RBF":
+                raise NotImplementedError("structured=True needs a kernel that factorises over the grid axes: 'RBF'")
+            if np.isnan(np.asarray(y)).any():
+                raise NotImplementedError("structured=True needs a fully observed grid (no NaN in y)")
+            self._axes, self._axes_n = self._grid_axes(X)
         if lengthscale is None and not kwargs.get("isotropic"):
             lmean = float(np.mean(y.shape) / 2)
             lengthscale = [[0. for _ in range(input_dim)], [lmean for _ in range(input_dim)]]
@@ -168,6 +183,9 @@ class reconstructor:
         self._Xd = self._to_device(self.X)
         self._yd = self._to_device(self.y)
         self._Xtest_d = self._to_device(self.Xtest) if self.Xtest is not None else None
+        if self.do_structured:
+            self._axes_d = self._to_device(np.concatenate(self._axes))
+            self._taxes = self._grid_axes(Xtest) if Xtest is not None else (self._axes, self._axes_n)
         self.model = _ModelView(self)
         self.learning_rate = learning_rate
         self.iterations = iterations
@@ -183,6 +201,24 @@ class reconstructor:
         self._last_pred = None       # (mean, sd) device tensors of the latest predict()
 
     # ------------------------------------------------------------------ helpers
+    @staticmethod
+    def _grid_axes(X):
+        """Coordinate vectors of a product grid X (d, n_1, ..., n_d): X[i] must vary along axis i only
+        (what utils.get_full_grid returns, with or without ``extent`` / ``dense_x``)."""
+        X = np.asarray(X, dtype=np.float64)
+        d = X.shape[0]
+        if X.ndim != d + 1:
+            raise NotImplementedError("structured=True needs grid coordinates of shape (d, n_1, ..., n_d)")
+        axes = []
+        for i in range(d):
+            c = np.moveaxis(X[i], i, 0).reshape(X.shape[1 + i], -1)[:, 0].copy()
+            shape = [1] * d
+            shape[i] = -1
+            if not np.array_equal(X[i], np.broadcast_to(c.reshape(shape), X.shape[1:])):
+                raise NotImplementedError("structured=True needs a product grid (coordinate i varying along axis i only)")
+            axes.append(c)
+        return axes, (ctypes.c_int32 * d)(*[len(c) for c in axes])
+
     def _to_device(self, t):
         if isinstance(t, np.ndarray):
             t = torch.from_numpy(t)
@@ -213,7 +249,11 @@ class reconstructor:
             print('Model training...')
         hist = torch.empty((max(T, 1), P), dtype=_F64, device=self._dev)
         loss = torch.empty((max(T, 1),), dtype=_F64, device=self._dev)
-        if not self.do_sparse:
+        if self.do_structured:
+            rc = self._handle.lib.gpimhip_fit_kron(
+                self._handle.h, ctypes.byref(self._mstruct), self._spec.dim, self._axes_n, _lib.ptr(self._axes_d),
+                _lib.ptr(self._yd), _lib.ptr(self._u), float(self.learning_rate), T, _lib.ptr(hist), _lib.ptr(loss))
+        elif not self.do_sparse:
             rc = self._handle.lib.gpimhip_fit_exact(
                 self._handle.h, ctypes.byref(self._mstruct), _lib.ptr(self._Xd), _lib.ptr(self._yd),
                 self._Xd.shape[0], _lib.ptr(self._u), float(self.learning_rate), T,
@@ -274,6 +314,8 @@ class reconstructor:
             self.Xtest = gprutils.prepare_test_data(Xtest, precision=self.precision)
             self._Xtest_d = self._to_device(self.Xtest)
             self.fulldims = Xtest.shape[1:]
+            if self.do_structured:
+                self._taxes = self._grid_axes(Xtest)
         if kwargs.get("verbose") is not None:
             self.verbose = kwargs.get("verbose")
         if self.verbose:
@@ -282,7 +324,15 @@ class reconstructor:
         M = self._Xtest_d.shape[0]
         mean = torch.empty((M,), dtype=_F64, device=self._dev)
         var = torch.empty((M,), dtype=_F64, device=self._dev)
-        if not self.do_sparse:
+        if self.do_structured:
+            taxes, tn = self._taxes
+            if int(np.prod([len(c) for c in taxes])) != M:
+                raise NotImplementedError("structured=True predicts on product grids only")
+            rc = self._handle.lib.gpimhip_predict_kron(
+                self._handle.h, ctypes.byref(self._mstruct), self._spec.dim, self._axes_n, _lib.ptr(self._axes_d),
+                _lib.ptr(self._yd), _lib.ptr(self._u), tn, _lib.ptr(self._to_device(np.concatenate(taxes))),
+                _lib.ptr(mean), _lib.ptr(var))
+        elif not self.do_sparse:
             rc = self._handle.lib.gpimhip_predict_exact(
                 self._handle.h, ctypes.byref(self._mstruct), _lib.ptr(self._Xd), _lib.ptr(self._yd),
                 self._Xd.shape[0], _lib.ptr(self._u), _lib.ptr(self._Xtest_d), M, _lib.ptr(mean), _lib.ptr(var))
@@ -322,7 +372,12 @@ class reconstructor:
         self._check_data()
         P = self._u.numel()
         out = torch.empty((1 + P,), dtype=_F64, device=self._dev)
-        if self.do_sparse:
+        if self.do_structured:
+            rc = self._handle.lib.gpimhip_kron_nll_grad(
+                self._handle.h, ctypes.byref(self._mstruct), self._spec.dim, self._axes_n, _lib.ptr(self._axes_d),
+                _lib.ptr(self._yd), _lib.ptr(self._u), ctypes.c_void_p(out.data_ptr()),
+                ctypes.c_void_p(out.data_ptr() + 8))
+        elif self.do_sparse:
             rc = self._handle.lib.gpimhip_vfe_nll_grad(
                 self._handle.h, ctypes.byref(self._mstruct), _lib.ptr(self._Xd), _lib.ptr(self._yd),
                 self._Xd.shape[0], self._n_ind, _lib.ptr(self._u), ctypes.c_void_p(out.data_ptr()),

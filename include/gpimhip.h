@@ -175,6 +175,29 @@ int gpimhip_predict_vfe(gpimhip_handle h, const gpimhip_model_t* m,
                         const double* u, const double* Xs, int64_t M,
                         double* mean_out, double* var_out);
 
+/* ---- exact GP on a fully observed regular grid (Kronecker-structured covariance) ---------------
+ * Takes the role of the reference's structured-kernel reconstructor (gpim/gpreg/skgpr.py:399-448, there
+ * GPyTorch's interpolated SKI approximation): the SAME model and parameterisation as
+ * gpimhip_fit_exact / gpimhip_predict_exact (RBF kernel, ARD or isotropic), but for observations on a
+ * complete product grid c_1 x ... x c_d the covariance is s2 K_1 (x) ... (x) K_d and loss, gradient,
+ * Adam loop and posterior follow from the n_i x n_i eigen-decompositions: O(sum n_i^3 + N sum n_i) work,
+ * O(N + sum n_i^2) memory, results equal to the dense path's up to rounding.
+ *   d, n[d]      grid shape (HOST array; N = prod n_i observations in C order, last axis fastest)
+ *   axes         device, sum n_i doubles: the coordinate vectors c_1, ..., c_d, concatenated
+ *   y            device, N doubles (no NaN: the grid must be fully observed)
+ *   n_test / axes_test   the prediction grid, the same way (M = prod n_test_i outputs, C order)
+ * Only GPIMHIP_KERNEL_RBF factorises over the axes; other kernels return GPIMHIP_E_BADARG. */
+int gpimhip_kron_nll_grad(gpimhip_handle h, const gpimhip_model_t* m, int32_t d, const int32_t* n,
+                          const double* axes, const double* y, const double* u,
+                          double* loss_out, double* grad_out);
+int gpimhip_fit_kron(gpimhip_handle h, const gpimhip_model_t* m, int32_t d, const int32_t* n,
+                     const double* axes, const double* y, double* u_inout, double lr, int32_t T,
+                     double* hist_out, double* loss_out);
+int gpimhip_predict_kron(gpimhip_handle h, const gpimhip_model_t* m, int32_t d, const int32_t* n,
+                         const double* axes, const double* y, const double* u,
+                         const int32_t* n_test, const double* axes_test,
+                         double* mean_out, double* var_out);
+
 /* Acquisition sweep over the dense grid (gpim/gpbayes/acqfunc.py:11-92):
  *   CB : p0*mean + p1*sd                                  (alpha, beta)
  *   EI : imp*Phi(imp/sd) + sd*phi(imp/sd), imp = mean - p0 - p1     (best, xi)

@@ -64,5 +64,6 @@ def test_gpim_alias_package():
     assert get_kernel("RBF", 2, [[0., 0.], [5., 5.]]).n_params == 4
     assert gprutils.get_full_grid is gpim_amd.utils.get_full_grid
     import pytest
+    assert gpim.skreconstructor is gpim_amd.skreconstructor
     with pytest.raises(NotImplementedError):
-        gpim.skreconstructor()
+        gpim.vreconstructor()
