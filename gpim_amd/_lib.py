@@ -75,6 +75,8 @@ _PROTOS = {
     "gpimhip_nanmax": (ctypes.c_int, [ctypes.c_void_p, c_dp, ctypes.c_int64, c_dp]),
     "gpimhip_topk": (ctypes.c_int, [ctypes.c_void_p, c_dp, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
                                     c_dp, c_dp, c_dp]),
+    "gpimhip_thin_batch": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_dp, ctypes.c_int32, ctypes.c_int32, c_dp,
+                                          ctypes.c_double, ctypes.c_int32, c_dp, c_dp]),
 }
 EXPORTS = tuple(_PROTOS)
 

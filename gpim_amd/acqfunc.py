@@ -60,6 +60,36 @@ def _nanmax(handle, *tensors):
     return out.item()
 
 
+# ------------------------------------------------------------------ device-resident path (boptimizer)
+def acquisition_on_device(gpmodel, kind, X_full, X_sparse, p0=0.0, p1=1.0, xi=0.01, Xf_d=None):
+    """The three built-in acquisition functions for a ``gpim_amd.reconstructor`` surrogate WITHOUT leaving
+    the GPU: returns device tensors (acq, mean, sd) over the flattened grid.  Same arithmetic as the public
+    functions below.  The incumbent of EI / POI -- nanmax of the posterior at the observed points, which the
+    reference obtains from a second predict over the whole NaN-masked grid (acqfunc.py:58-59,86-88) -- is
+    predicted at the observed rows only: every column of a prediction is independent of the others, so the
+    values (and their nanmax) are the same and the N^2 M triangular product shrinks to N^2 N_obs."""
+    handle = gpmodel._handle
+    Xf = Xf_d if Xf_d is not None else gpmodel._to_device(_rows(X_full, gpmodel.precision))
+    mean_d, sd_d = gpmodel._predict_device(Xf)
+    if kind == "cb":
+        a, b = p0, p1
+    else:
+        Xs = _rows(X_sparse, gpmodel.precision)
+        obs = ~torch.isnan(Xs).any(dim=1)
+        mo, so = gpmodel._predict_device(gpmodel._to_device(Xs[obs].contiguous()))
+        a = _nanmax(handle, mo) if kind == "ei" else _nanmax(handle, mo, so)
+        b = xi
+    out = torch.empty_like(mean_d)
+    _lib.check(handle.lib.gpimhip_acq(handle.h, _lib.ACQ_IDS[kind], _lib.ptr(mean_d), _lib.ptr(sd_d), mean_d.numel(),
+                                      float(a), float(b), None, _lib.ptr(out)))
+    return out, mean_d, sd_d
+
+
+def _rows(X, precision):
+    from . import gprutils
+    return gprutils.prepare_test_data(np.asarray(X), precision=precision)
+
+
 def confidence_bound(gpmodel, X_full, **kwargs):
     """alpha * mean + beta * sd (defaults 0, 1)."""
     alpha, beta = kwargs.get("alpha", 0), kwargs.get("beta", 1)

@@ -14,12 +14,43 @@ import types
 
 import numpy as np
 import torch
-from scipy import spatial
 
 from . import _lib, acqfunc, gprutils
 from .gpr import reconstructor
 
 _F64 = torch.float64
+
+
+class _LazyMaps(list):
+    """``boptimizer.gp_predictions``: one (mean, sd) pair of numpy maps per exploration step, like the
+    reference's list -- but the maps of the built-in acquisition path stay on the GPU until somebody looks
+    at them (indexing, iteration, saving), so an exploration step makes no device-to-host copy of a map."""
+
+    class _Pending:
+        def __init__(self, mean_d, sd_d, shape, np_dtype):
+            self.mean_d, self.sd_d, self.shape, self.np_dtype = mean_d, sd_d, shape, np_dtype
+
+        def get(self):
+            both = torch.stack([self.mean_d, self.sd_d]).cpu().numpy().astype(self.np_dtype, copy=False)
+            return both[0].reshape(self.shape), both[1].reshape(self.shape)
+
+    def _mat(self, i):
+        v = list.__getitem__(self, i)
+        if isinstance(v, _LazyMaps._Pending):
+            v = v.get()
+            list.__setitem__(self, i, v)
+        return v
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self._mat(j) for j in range(*i.indices(len(self)))]
+        return self._mat(i if i >= 0 else len(self) + i)
+
+    def __iter__(self):
+        return (self._mat(i) for i in range(len(self)))
+
+    def __reduce__(self):                   # pickles (np.save of the results dict) as a plain list of arrays
+        return (list, (list(iter(self)),))
 
 
 class boptimizer:
@@ -79,7 +110,9 @@ class boptimizer:
         self.filename = kwargs.get("filename", "./boptim_results")
         self.shard_candidates = kwargs.get("shard_candidates", False)
         self.indices_all, self.vals_all = [], []
-        self.target_func_vals, self.gp_predictions = [y_seed.copy()], []
+        self.target_func_vals, self.gp_predictions = [y_seed.copy()], _LazyMaps()
+        self._mask_d = None
+        self._Xfull_d = None
 
     # ------------------------------------------------------------------ posterior update
     def update_posterior(self):
@@ -115,12 +148,18 @@ class boptimizer:
         acq_d = getattr(sm, "_last_acq", None)
         if acq_d is None or acq_d.numel() != acq.size:
             acq_d = torch.as_tensor(np.ascontiguousarray(acq), dtype=_F64).reshape(-1).to(handle.device)
+        sm._last_acq = None
+        return self._rank_device(acq_d, acq.shape)
+
+    def _rank_device(self, acq_d, grid_shape):
+        """Top-``batch_size`` of a device-resident acquisition map (flattened); returns host lists."""
+        handle = self.surrogate_model._handle
         keep_nan = 1
         if self.mask is not None:
-            mask_d = torch.as_tensor(np.ascontiguousarray(self.mask), dtype=_F64).reshape(-1).to(handle.device)
-            acq_d = mask_d * acq_d
+            if self._mask_d is None or self._mask_d.numel() != acq_d.numel():
+                self._mask_d = torch.as_tensor(np.ascontiguousarray(self.mask), dtype=_F64).reshape(-1).to(handle.device)
+            acq_d = self._mask_d * acq_d
             keep_nan = 0
-        sm._last_acq = None
         k = int(min(self.batch_size, acq_d.numel()))
         vals = torch.empty((k,), dtype=_F64, device=handle.device)
         idx = torch.empty((k,), dtype=torch.int64, device=handle.device)
@@ -130,7 +169,7 @@ class boptimizer:
         n = int(cnt.item())
         flat = idx[:n].cpu().numpy()
         vals_list = vals[:n].cpu().numpy().tolist()
-        indices_list = np.stack(np.unravel_index(flat, acq.shape), axis=-1).tolist()
+        indices_list = np.stack(np.unravel_index(flat, tuple(grid_shape)), axis=-1).tolist()
         return vals_list, indices_list
 
     def next_point(self):
@@ -148,20 +187,25 @@ class boptimizer:
             if radius is None:
                 radius = sm.model.kernel.lengthscale.mean().item()
             return self.update_points(vals_list, indices_list, radius)
-        if af == 'cb':
-            acq, pred = acqfunc.confidence_bound(sm, self.X_full, alpha=self.alpha, beta=self.beta)
-        elif af == 'ei':
-            acq, pred = acqfunc.expected_improvement(sm, self.X_full, self.X_sparse, xi=self.xi)
-        elif af == 'poi':
-            acq, pred = acqfunc.probability_of_improvement(sm, self.X_full, self.X_sparse, xi=self.xi)
+        if af in ('cb', 'ei', 'poi'):
+            # built-in acquisition: prediction, incumbent, sweep, mask and ranking all stay on the GPU;
+            # only the batch_size ranked (value, index) pairs come back
+            p0, p1 = (self.alpha, self.beta) if af == 'cb' else (0.0, 0.0)
+            if self._Xfull_d is None:
+                self._Xfull_d = sm._to_device(gprutils.prepare_test_data(np.asarray(self.X_full), precision=self.precision))
+            acq_d, mean_d, sd_d = acqfunc.acquisition_on_device(sm, af, self.X_full, self.X_sparse, p0, p1, self.xi,
+                                                                Xf_d=self._Xfull_d)
+            grid_shape = tuple(np.shape(self.X_full)[1:])
+            self.gp_predictions.append(_LazyMaps._Pending(mean_d, sd_d, grid_shape, sm._np_out))
+            vals_list, indices_list = self._rank_device(acq_d, grid_shape)
         elif isinstance(af, types.FunctionType):
             acq, pred = af(sm, self.X_full, self.X_sparse)
             sm._last_acq = None
+            self.gp_predictions.append(pred)
+            vals_list, indices_list = self._rank(np.asarray(acq))
         else:
             raise NotImplementedError(
                 "Choose between 'cb', 'ei', and 'poi' acquisition functions or define your own")
-        self.gp_predictions.append(pred)
-        vals_list, indices_list = self._rank(np.asarray(acq))
         if not self.batch_update:
             return vals_list, indices_list
         radius = self.batch_dscale
@@ -219,30 +263,36 @@ class boptimizer:
         return gv.cpu().numpy().tolist(), np.stack(np.unravel_index(flat, grid_shape), axis=-1).tolist()
 
     def update_points(self, acqfunc_values, indices, dscale):
-        """Thin a ranked batch so that kept points are farther than ``dscale`` apart
-        (cKDTree ball queries), pad with random members of the batch -- boptim.py:326-376."""
+        """Thin a ranked batch so that kept points are farther than ``dscale`` apart, pad with random
+        members of the batch -- boptim.py:326-376.  The greedy maximum-and-suppress loop (the reference's
+        cKDTree ball queries) runs on the GPU (gpimhip_thin_batch); the random padding draws from
+        ``np.random`` on the host like the reference."""
         _, val = self.checkvalues(indices, acqfunc_values)
         first = np.where(np.array(acqfunc_values) == val)[0][0]
-        vals = np.array(acqfunc_values)[first:]
+        vals = np.array(acqfunc_values, dtype=np.float64)[first:]
         pts = np.vstack(indices)[first:]
-        vals_orig = vals.copy()
-        floor = vals.min()
-        tree = spatial.cKDTree(pts)
-        kept_vals, kept_ids = [], []
-        cur = int(np.argmax(vals))
-        while vals[cur] > floor - 1:
-            kept_vals.append(vals[cur])
-            kept_ids.append(cur)
-            vals[tree.query_ball_point(pts[cur], dscale)] = floor - 1
-            cur = int(np.argmax(vals))
-        kept_vals = kept_vals[:self.batch_out_max]
-        out = pts[kept_ids].tolist()[:self.batch_out_max]
+        n, d = pts.shape
+        handle = self.surrogate_model._handle
+        dev = handle.device
+        shape = pts.max(axis=0).astype(np.int64) + 1                  # any box containing the candidates
+        flat = np.ravel_multi_index(tuple(pts.T.astype(np.int64)), tuple(shape))
+        vals_d = torch.from_numpy(vals).to(dev)
+        flat_d = torch.from_numpy(flat.astype(np.int64)).to(dev)
+        shape_d = torch.from_numpy(shape).to(dev)
+        keep_d = torch.empty((self.batch_out_max,), dtype=torch.int32, device=dev)
+        nkeep_d = torch.zeros((1,), dtype=torch.int32, device=dev)
+        _lib.check(handle.lib.gpimhip_thin_batch(handle.h, _lib.ptr(vals_d), _lib.ptr(flat_d), int(n), int(d),
+                                                 _lib.ptr(shape_d), float(dscale), int(self.batch_out_max),
+                                                 _lib.ptr(keep_d), _lib.ptr(nkeep_d)))
+        kept_ids = keep_d[:int(nkeep_d.item())].cpu().numpy().astype(np.int64)
+        kept_vals = vals[kept_ids].tolist()
+        out = pts[kept_ids].tolist()
         if len(out) < self.batch_out_max:
             if self.verbose == 2:
                 print("Adding {} random indices".format(self.batch_out_max - len(out)))
             rnd = np.random.randint(0, len(vals), self.batch_out_max - len(out))
             out.extend(pts[rnd].tolist())
-            kept_vals.extend(vals_orig[rnd].tolist())
+            kept_vals.extend(vals[rnd].tolist())
         return kept_vals, out
 
     def checkvalues(self, idx_list, val_list):
@@ -306,6 +356,6 @@ class boptimizer:
     def save_results(self, *args):
         """np.save of {'gp_pred','func_val','inds_all','vals_all'} (boptim.py:472-485)."""
         filename = args[0] if args else self.filename
-        results = {'gp_pred': self.gp_predictions, 'func_val': self.target_func_vals,
+        results = {'gp_pred': list(self.gp_predictions), 'func_val': self.target_func_vals,
                    'inds_all': np.array(self.indices_all), 'vals_all': np.array(self.vals_all)}
         np.save(filename + ".npy", results)

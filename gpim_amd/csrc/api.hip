@@ -32,6 +32,12 @@ int launch_acq(gpimhip_ctx* h, int kind, const double* mean, const double* sd, i
 int launch_nanmax(gpimhip_ctx* h, const double* x, int64_t n, double* out);
 int launch_topk(gpimhip_ctx* h, const double* x, int64_t M, int k, int keep_nan, double* vals, int64_t* idx,
                 int64_t* count);
+int launch_topk_radix(gpimhip_ctx* h, const double* x, int64_t M, int k, int keep_nan, double* vals, int64_t* idx,
+                      int64_t* count);
+int launch_nanmax_two_stage(gpimhip_ctx* h, const double* x, int64_t n, double* out);
+int launch_thin_batch(gpimhip_ctx* h, const double* vals, const int64_t* flat, int n, int d, const int64_t* shape,
+                      double dscale, int max_out, int32_t* keep_out, int32_t* nkeep_out);
+size_t sel_scratch_bytes();
 int launch_fit_small(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X, int64_t x_bs, const double* y,
                      int N, double* u, const double* lr_over_bc1, const double* bc2_sqrt, int T, double* hist,
                      double* loss, double* grad);
@@ -670,6 +676,7 @@ int gpimhip_destroy(gpimhip_handle h) {
     dev_free(h, &h->pred_tiles, h->pred_ntiles);
     dev_free(h, &h->mean_tmp, h->ks_batch * h->ks_cols);
     dev_free(h, &h->keys, h->keys_cap);
+    if (h->sel_scratch) dev_free(h, &h->sel_scratch, (int64_t)sel_scratch_bytes());
     dev_free(h, &h->bc, h->bc_cap);
     dev_free(h, &h->theta1, 1);
     dev_free(h, &h->info, 4);
@@ -911,10 +918,17 @@ int gpimhip_acq(gpimhip_handle h, int32_t kind, const double* mean, const double
     return launch_acq(h, kind, mean, sd, M, p0, p1, mask, acq_out);
 }
 
+static int sel_scratch_ensure(gpimhip_ctx* h) {
+    if (h->sel_scratch) return GPIMHIP_OK;
+    return dev_alloc(h, &h->sel_scratch, (int64_t)sel_scratch_bytes());
+}
+
 int gpimhip_nanmax(gpimhip_handle h, const double* x, int64_t n, double* out) {
     if (!h || !x || !out || n < 1) return GPIMHIP_E_BADARG;
     HIP_TRY(hipSetDevice(h->device));
-    return launch_nanmax(h, x, n, out);
+    if (n <= 4096) return launch_nanmax(h, x, n, out);
+    GP_TRY(sel_scratch_ensure(h));
+    return launch_nanmax_two_stage(h, x, n, out);
 }
 
 int gpimhip_topk(gpimhip_handle h, const double* acq, int64_t M, int32_t k, int32_t keep_nan, double* vals_out,
@@ -928,7 +942,22 @@ int gpimhip_topk(gpimhip_handle h, const double* acq, int64_t M, int32_t k, int3
         GP_TRY(dev_alloc(h, &h->keys, M));
         h->keys_cap = M;
     }
+    // large grids: multi-block radix selection (15 launches, O(M) each); small ones: k arg-max passes of one
+    // workgroup (2 launches)
+    if (M > 2048 && k <= 1024 && M < ((int64_t)1 << 32) && !getenv("GPIMHIP_NO_RADIX_TOPK")) {
+        GP_TRY(sel_scratch_ensure(h));
+        return launch_topk_radix(h, acq, M, k, keep_nan, vals_out, idx_out, count_out);
+    }
     return launch_topk(h, acq, M, k, keep_nan, vals_out, idx_out, count_out);
+}
+
+int gpimhip_thin_batch(gpimhip_handle h, const double* vals, const int64_t* flat_idx, int32_t n, int32_t d,
+                       const int64_t* shape, double dscale, int32_t max_out, int32_t* keep_out, int32_t* nkeep_out) {
+    if (!h || !vals || !flat_idx || !shape || !keep_out || !nkeep_out || n < 1 || n > 1024 || d < 1 ||
+        d > GPIMHIP_MAX_DIM || max_out < 1)
+        return GPIMHIP_E_BADARG;
+    HIP_TRY(hipSetDevice(h->device));
+    return launch_thin_batch(h, vals, flat_idx, n, d, shape, dscale, max_out, keep_out, nkeep_out);
 }
 
 }  // extern "C"

@@ -120,6 +120,7 @@ struct gpimhip_ctx {
     // top-k scratch
     unsigned long long* keys = nullptr;
     int64_t keys_cap = 0;
+    char* sel_scratch = nullptr;    // radix-select state, candidates, nanmax partials (select.hip)
     // training-loop bookkeeping: iterations completed by the last fit call, pinned copy of the status
     // word + events of the bounded run-ahead check (api.hip: RunAhead)
     int fit_completed = 0;

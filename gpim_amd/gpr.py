@@ -350,6 +350,27 @@ class reconstructor:
             print("Done")
         return mean_h, sd_h
 
+    def _predict_device(self, Xrows_d):
+        """Posterior (mean, sd) device tensors at the (M, d) device rows `Xrows_d`; no host copies and no
+        change of the stored test grid.  Internal: the device-resident acquisition path of boptimizer."""
+        self._check_data()
+        M = Xrows_d.shape[0]
+        mean = torch.empty((M,), dtype=_F64, device=self._dev)
+        var = torch.empty((M,), dtype=_F64, device=self._dev)
+        if self.do_structured:
+            raise NotImplementedError("structured models predict on product grids (use predict())")
+        if not self.do_sparse:
+            rc = self._handle.lib.gpimhip_predict_exact(
+                self._handle.h, ctypes.byref(self._mstruct), _lib.ptr(self._Xd), _lib.ptr(self._yd),
+                self._Xd.shape[0], _lib.ptr(self._u), _lib.ptr(Xrows_d), M, _lib.ptr(mean), _lib.ptr(var))
+        else:
+            rc = self._handle.lib.gpimhip_predict_vfe(
+                self._handle.h, ctypes.byref(self._mstruct), _lib.ptr(self._Xd), _lib.ptr(self._yd),
+                self._Xd.shape[0], self._n_ind, _lib.ptr(self._u), _lib.ptr(Xrows_d), M, _lib.ptr(mean),
+                _lib.ptr(var))
+        _lib.check(rc)
+        return mean, var.sqrt()
+
     def run(self, **kwargs):
         """train + predict; returns (mean, sd, hyperparams) (gpr.py:257-283)."""
         if kwargs.get("learning_rate") is not None:

@@ -214,9 +214,21 @@ int gpimhip_nanmax(gpimhip_handle h, const double* x, int64_t n, double* out);
 /* Descending top-k of acq (NaNs ranked first when keep_nan != 0, exactly like
  * np.argsort(...)[::-1] at boptim.py:303-306; dropped otherwise, boptim.py:310-315).
  * vals_out: k doubles, idx_out: k int64 flat indices (device).  count_out (device
- * int64): number of valid entries written (< k when fewer non-NaN values exist). */
+ * int64): number of valid entries written (< k when fewer non-NaN values exist).
+ * Ties rank the larger flat index first.  Grids of more than 2048 points use a multi-block radix
+ * selection (O(M) per pass, no host round trip), smaller ones k arg-max passes of one workgroup. */
 int gpimhip_topk(gpimhip_handle h, const double* acq, int64_t M, int32_t k, int32_t keep_nan,
                  double* vals_out, int64_t* idx_out, int64_t* count_out);
+
+/* Batch thinning of boptimizer.update_points (gpim/gpbayes/boptim.py:326-376): among n <= 1024 ranked
+ * candidates (vals, flat grid indices into a d-dimensional grid of the given shape) repeatedly keep the
+ * largest remaining value and drop every candidate within Euclidean index distance <= dscale of it
+ * (scipy.spatial.cKDTree.query_ball_point semantics), until none is left or max_out are kept.
+ *   shape      d int64 (device);  keep_out  max_out int32 (device): kept positions 0..n-1, in order;
+ *   nkeep_out  1 int32 (device).  The random padding of short batches stays with the caller (np.random). */
+int gpimhip_thin_batch(gpimhip_handle h, const double* vals, const int64_t* flat_idx, int32_t n, int32_t d,
+                       const int64_t* shape, double dscale, int32_t max_out, int32_t* keep_out,
+                       int32_t* nkeep_out);
 
 /* Stage timing for bench.py (HIP events on the handle's stream, recorded only while enabled).
  * stage: 0 = Cholesky (all launches of one factorisation), 1 = triangular inverse,
