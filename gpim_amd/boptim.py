@@ -113,6 +113,7 @@ class boptimizer:
         self.target_func_vals, self.gp_predictions = [y_seed.copy()], _LazyMaps()
         self._mask_d = None
         self._Xfull_d = None
+        self._map_slabs, self._maps_used = [], 0
 
     # ------------------------------------------------------------------ posterior update
     def update_posterior(self):
@@ -150,6 +151,22 @@ class boptimizer:
             acq_d = torch.as_tensor(np.ascontiguousarray(acq), dtype=_F64).reshape(-1).to(handle.device)
         sm._last_acq = None
         return self._rank_device(acq_d, acq.shape)
+
+    def _retain_maps(self, mean_d, sd_d):
+        """Copies the step's posterior maps into a slab allocated 16 steps at a time and returns views of it:
+        the per-step tensors then go back to torch's caching allocator and are reused by the next step
+        (holding on to them made every step pay fresh hipMallocs, ~10x the cost of the step itself)."""
+        slot = self._maps_used % 16
+        if slot == 0:
+            self._map_slabs.append(torch.empty((16, 2, mean_d.numel()), dtype=mean_d.dtype, device=mean_d.device))
+        slab = self._map_slabs[-1]
+        if slab.shape[2] != mean_d.numel():                      # grid changed size: start a new slab
+            self._map_slabs.append(torch.empty((16, 2, mean_d.numel()), dtype=mean_d.dtype, device=mean_d.device))
+            slab, slot, self._maps_used = self._map_slabs[-1], 0, 16 * (len(self._map_slabs) - 1)
+        slab[slot, 0].copy_(mean_d)
+        slab[slot, 1].copy_(sd_d)
+        self._maps_used += 1
+        return slab[slot, 0], slab[slot, 1]
 
     def _rank_device(self, acq_d, grid_shape):
         """Top-``batch_size`` of a device-resident acquisition map (flattened); returns host lists."""
@@ -196,6 +213,7 @@ class boptimizer:
             acq_d, mean_d, sd_d = acqfunc.acquisition_on_device(sm, af, self.X_full, self.X_sparse, p0, p1, self.xi,
                                                                 Xf_d=self._Xfull_d)
             grid_shape = tuple(np.shape(self.X_full)[1:])
+            mean_d, sd_d = self._retain_maps(mean_d, sd_d)
             self.gp_predictions.append(_LazyMaps._Pending(mean_d, sd_d, grid_shape, sm._np_out))
             vals_list, indices_list = self._rank_device(acq_d, grid_shape)
         elif isinstance(af, types.FunctionType):

@@ -135,36 +135,62 @@ static int ws_ensure_b(gpimhip_ctx* h, int64_t N, int B, int padded) {
 int ws_ensure(gpimhip_ctx* h, int64_t N) { return ws_ensure_b(h, N, h->nbatch, 0); }
 static int ws_ensure_padded(gpimhip_ctx* h, int64_t N) { return ws_ensure_b(h, N, h->nbatch, 1); }
 
-int ws_ensure_predict(gpimhip_ctx* h, int64_t np, int64_t mc) {
-    const int B = h->nbatch;
-    if (h->ks_rows == np && h->ks_cols == mc && h->ks_batch == B) return GPIMHIP_OK;
-    HIP_TRY(hipStreamSynchronize(h->stream));
+static void ws_release_predict(gpimhip_ctx* h) {
     dev_free(h, &h->Ks, h->ks_batch * h->ks_rows * (h->ks_cols + 16));
     dev_free(h, &h->colpart, h->ks_batch * (h->ks_rows / NB) * h->ks_cols);
-    dev_free(h, &h->pred_tiles, h->pred_ntiles);
     dev_free(h, &h->mean_tmp, h->ks_batch * h->ks_cols);
+    for (auto& pl : h->pred_lists) dev_free(h, &pl.tiles, pl.n);
+    h->pred_lists.clear();
+    h->pred_tiles = nullptr;
+    h->pred_ntiles = 0;
     h->ks_rows = h->ks_cols = 0;
     h->ks_batch = 0;
-    GP_TRY(dev_alloc(h, &h->Ks, B * np * (mc + 16)));      // rows mc + 16 apart (no power-of-two row stride)
-    GP_TRY(dev_alloc(h, &h->colpart, B * (np / NB) * mc));
-    GP_TRY(dev_alloc(h, &h->mean_tmp, B * mc));
-    h->ks_batch = B;
-    // tile list of the variance product W = L^-1 K*: 8x8 patches, longest k-ranges first
+}
+
+// Prediction workspace for slabs of up to mc test points.  Grow-only in mc: a Bayesian-optimisation step
+// alternates between the full grid and the handful of observed points, and re-allocating the slab on every
+// switch costs more than the prediction itself.  Buffers are laid out for the capacity h->ks_cols (row
+// stride of the slab: capacity + 16 doubles -- no power-of-two stride); the tile list of the variance
+// product depends on the number of column blocks actually used and is cached per size.
+int ws_ensure_predict(gpimhip_ctx* h, int64_t np, int64_t mc) {
+    const int B = h->nbatch;
+    if (!(h->ks_rows == np && h->ks_batch == B && mc <= h->ks_cols)) {
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        const int64_t cap = (h->ks_rows == np && h->ks_batch == B) ? std::max(mc, h->ks_cols) : mc;
+        ws_release_predict(h);
+        h->ks_rows = np;                 // sizes first: a failed allocation is cleaned up by pointer
+        h->ks_cols = cap;
+        h->ks_batch = B;
+        int rc = GPIMHIP_OK;
+        if ((rc = dev_alloc(h, &h->Ks, B * np * (cap + 16))) || (rc = dev_alloc(h, &h->colpart, B * (np / NB) * cap)) ||
+            (rc = dev_alloc(h, &h->mean_tmp, B * cap))) {
+            ws_release_predict(h);
+            return rc;
+        }
+    }
     const int nb = (int)(np / NB), nc = (int)(mc / NB);
+    for (auto& pl : h->pred_lists)
+        if (pl.nc == nc) {
+            h->pred_tiles = pl.tiles;
+            h->pred_ntiles = pl.n;
+            return GPIMHIP_OK;
+        }
+    // tile list of the variance product W = L^-1 K*: 8x8 patches, longest k-ranges first
     std::vector<TileDesc> tl;
     tl.reserve((size_t)nb * nc);
     for (int ig = (nb - 1) / 8; ig >= 0; --ig)
         for (int jg = 0; jg <= (nc - 1) / 8; ++jg)
             for (int ci = std::min(nb - 1, ig * 8 + 7); ci >= ig * 8; --ci)
                 for (int cj = jg * 8; cj < std::min(nc, jg * 8 + 8); ++cj) tl.push_back({ci, cj, 0, ci + 1});
-    h->pred_ntiles = (int64_t)tl.size();
-    GP_TRY(dev_alloc(h, &h->pred_tiles, h->pred_ntiles));
+    gpimhip_ctx::PredList pl{nc, nullptr, (int64_t)tl.size()};
+    GP_TRY(dev_alloc(h, &pl.tiles, pl.n));
     // (async + stream sync rather than hipMemcpy: the latter serialises against the legacy stream and is
     // illegal while another thread captures a graph)
-    HIP_TRY(hipMemcpyAsync(h->pred_tiles, tl.data(), tl.size() * sizeof(TileDesc), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(pl.tiles, tl.data(), tl.size() * sizeof(TileDesc), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    h->ks_rows = np;
-    h->ks_cols = mc;
+    h->pred_lists.push_back(pl);
+    h->pred_tiles = pl.tiles;
+    h->pred_ntiles = pl.n;
     return GPIMHIP_OK;
 }
 
@@ -671,10 +697,7 @@ int gpimhip_destroy(gpimhip_handle h) {
     vfe_release(h);
     kron_release(h);
     ws_release_matrix(h);
-    dev_free(h, &h->Ks, h->ks_batch * h->ks_rows * (h->ks_cols + 16));
-    dev_free(h, &h->colpart, h->ks_batch * (h->ks_rows / NB) * h->ks_cols);
-    dev_free(h, &h->pred_tiles, h->pred_ntiles);
-    dev_free(h, &h->mean_tmp, h->ks_batch * h->ks_cols);
+    ws_release_predict(h);
     dev_free(h, &h->keys, h->keys_cap);
     if (h->sel_scratch) dev_free(h, &h->sel_scratch, (int64_t)sel_scratch_bytes());
     dev_free(h, &h->bc, h->bc_cap);
@@ -738,9 +761,10 @@ int gpimhip_kmat(gpimhip_handle h, const gpimhip_model_t* m, const double* X, in
     // tiles are 128x128: build into a padded scratch and copy out the valid part
     const int64_t rp = pad_to(N, NB), cp = pad_to(Mv, NB);
     GP_TRY(ws_ensure_predict(h, rp, cp));
-    GP_TRY(launch_kmat(h, m, X, N, sym ? nullptr : Z, Mv, h->theta1, diag_add, 0, h->Ks, cp, rp, cp, sym ? 1 : 0, 0, 0,
+    const int64_t kld = h->ks_cols + 16;
+    GP_TRY(launch_kmat(h, m, X, N, sym ? nullptr : Z, Mv, h->theta1, diag_add, 0, h->Ks, kld, rp, cp, sym ? 1 : 0, 0, 0,
                        0, 0));
-    HIP_TRY(hipMemcpy2DAsync(out, (size_t)ld * sizeof(double), h->Ks, (size_t)cp * sizeof(double),
+    HIP_TRY(hipMemcpy2DAsync(out, (size_t)ld * sizeof(double), h->Ks, (size_t)kld * sizeof(double),
                              (size_t)Mv * sizeof(double), (size_t)N, hipMemcpyDeviceToDevice, h->stream));
     return GPIMHIP_OK;
 }
@@ -835,25 +859,25 @@ static int predict_impl(gpimhip_ctx* h, const gpimhip_model_t* m, const double* 
     const int64_t cap = std::max<int64_t>(NB, ((int64_t)1 << 27) / np / B / NB * NB);
     mc = std::min(mc, cap);
     GP_TRY(ws_ensure_predict(h, np, mc));
+    const int64_t mcap = h->ks_cols, kld = mcap + 16;       // buffer strides follow the capacity
     for (int64_t m0 = 0; m0 < M; m0 += mc) {
         const int64_t cnt = std::min(mc, M - m0);
         const int64_t cpad = pad_to(cnt, NB);
         // the test grid Xs is shared by all problems of the batch (z stride 0)
-        const int64_t kld = mc + 16;
         GP_TRY(launch_kmat(h, m, X, N, Xs + m0 * m->dim, cnt, h->theta, 0.0, 0, h->Ks, kld, np, cpad, 0, 0, x_bs, 0,
                            np * kld));
-        GP_TRY(launch_gemv_t(h, h->Ks, kld, np, cpad, h->alpha, h->mean_tmp, 0, np * kld, np, mc));
-        GP_TRY(launch_copy_slice(h, h->mean_tmp, mean_out + m0, cnt, mc, M));
+        GP_TRY(launch_gemv_t(h, h->Ks, kld, np, cpad, h->alpha, h->mean_tmp, 0, np * kld, np, mcap));
+        GP_TRY(launch_copy_slice(h, h->mean_tmp, mean_out + m0, cnt, mcap, M));
         GemmArgs g = gemm_args(h->A, h->ld, h->Ks, kld, nullptr, 0, 1.0, 0.0, h->pred_tiles, 0, h->np);
         g.sB = np * kld;
         g.chunk = deal_chunk();
         g.colpart = h->colpart;
-        g.ld_colpart = mc;
-        g.sColpart = (int64_t)nb * mc;
+        g.ld_colpart = mcap;
+        g.sColpart = (int64_t)nb * mcap;
         // a ragged last chunk still sweeps all column tiles of the slab (stale columns are ignored)
         g.ntiles = (int)h->pred_ntiles;
         { StageTimer t(h, 3); GP_TRY(launch_gemm(h, false, true, EPI_COLSUMSQ, g)); }
-        GP_TRY(launch_predict_var(h, mc, nb, m0, cnt, var_out, M));
+        GP_TRY(launch_predict_var(h, mcap, nb, m0, cnt, var_out, M));
     }
     return finish_and_check(h);
 }

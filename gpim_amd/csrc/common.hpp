@@ -102,7 +102,9 @@ struct gpimhip_ctx {
     double* adam_v = nullptr;       // MAXP
     int32_t* info = nullptr;        // potrf status word
     // prediction workspace
-    int64_t ks_rows = 0, ks_cols = 0, ks_batch = 0;
+    int64_t ks_rows = 0, ks_cols = 0, ks_batch = 0;   // ks_cols = CAPACITY in test-point columns (grow-only)
+    struct PredList { int nc; TileDesc* tiles; int64_t n; };
+    std::vector<PredList> pred_lists;                // variance-product tile lists by number of column blocks
     double* Ks = nullptr;           // np x mc chunk of K(X, X*)
     double* colpart = nullptr;      // nb x mc partial column sums of squares
     double* mean_tmp = nullptr;     // mc
