@@ -75,6 +75,11 @@ _PROTOS = {
     "gpimhip_nanmax": (ctypes.c_int, [ctypes.c_void_p, c_dp, ctypes.c_int64, c_dp]),
     "gpimhip_topk": (ctypes.c_int, [ctypes.c_void_p, c_dp, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
                                     c_dp, c_dp, c_dp]),
+    "gpimhip_dist_begin": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64]),
+    "gpimhip_dist_panel_factor": (ctypes.c_int, [ctypes.c_void_p, c_dp, ctypes.c_int64, ctypes.c_int32,
+                                                 ctypes.c_int32, c_dp, c_dp]),
+    "gpimhip_dist_trailing_update": (ctypes.c_int, [ctypes.c_void_p, c_dp, ctypes.c_int64, ctypes.c_int32, c_dp,
+                                                    ctypes.c_int64, ctypes.c_int32, ctypes.c_int32]),
     "gpimhip_thin_batch": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_dp, ctypes.c_int32, ctypes.c_int32, c_dp,
                                           ctypes.c_double, ctypes.c_int32, c_dp, c_dp]),
 }

@@ -107,10 +107,13 @@ static void ws_release_matrix(gpimhip_ctx* h) {
 // padded != 0: rows of the np x np matrices are np + 16 doubles apart.  With ld = np = 2^k every row
 // of a 128-column panel maps to the same L2 sets (row stride 2^(k+3) bytes) and tiles that share a
 // panel evict each other's lines; one extra cache line per row spreads the rows over the sets.
-static int ws_ensure_b(gpimhip_ctx* h, int64_t N, int B, int padded) {
+// matrices == false: only what the diagonal-block kernels and the launch plan need (dinv, log-det partials,
+// theta, Adam state) -- the distributed factorisation keeps its share of the matrix in caller-owned storage
+// and never needs the three np x np buffers (3 x 32 GiB at N = 65536).
+static int ws_ensure_b(gpimhip_ctx* h, int64_t N, int B, int padded, bool matrices = true) {
     const int64_t np = pad_to(std::max<int64_t>(N, 1), NB);
     const int64_t ld = np + ((padded && np >= 1024) ? 16 : 0);
-    if (np == h->np && B == h->ws_batch && ld == h->ld) return GPIMHIP_OK;
+    if (np == h->np && B == h->ws_batch && ld == h->ld && (h->A != nullptr || !matrices)) return GPIMHIP_OK;
     HIP_TRY(hipStreamSynchronize(h->stream));
     ws_release_matrix(h);
     const int64_t nb = np / NB;
@@ -120,8 +123,9 @@ static int ws_ensure_b(gpimhip_ctx* h, int64_t N, int B, int padded) {
     h->ws_batch = B;
     h->ld = ld;
     int rc = GPIMHIP_OK;
-    if ((rc = dev_alloc(h, &h->A, B * np * ld)) || (rc = dev_alloc(h, &h->B, B * np * ld)) ||
-        (rc = dev_alloc(h, &h->Tm, B * np * ld)) || (rc = dev_alloc(h, &h->dinv, B * nb * NB * NB)) ||
+    if ((matrices && ((rc = dev_alloc(h, &h->A, B * np * ld)) || (rc = dev_alloc(h, &h->B, B * np * ld)) ||
+                      (rc = dev_alloc(h, &h->Tm, B * np * ld)))) ||
+        (rc = dev_alloc(h, &h->dinv, B * nb * NB * NB)) ||
         (rc = dev_alloc(h, &h->ypad, B * np)) || (rc = dev_alloc(h, &h->z, B * np)) ||
         (rc = dev_alloc(h, &h->alpha, B * np)) || (rc = dev_alloc(h, &h->logdet_part, B * nb)) ||
         (rc = dev_alloc(h, &h->grad_part, B * nb * (nb + 1) / 2 * 8)) || (rc = dev_alloc(h, &h->theta, (int64_t)B)) ||
@@ -704,6 +708,7 @@ int gpimhip_destroy(gpimhip_handle h) {
     dev_free(h, &h->theta1, 1);
     dev_free(h, &h->info, 4);
     if (h->plan.d_tiles) (void)hipFree(h->plan.d_tiles);
+    for (auto& d : h->dist_lists) dev_free(h, &d.tiles, d.n);
     for (auto e : h->ev_pool) (void)hipEventDestroy(e);
     for (auto e : h->ra_ev)
         if (e) (void)hipEventDestroy(e);
@@ -973,6 +978,67 @@ int gpimhip_topk(gpimhip_handle h, const double* acq, int64_t M, int32_t k, int3
         return launch_topk_radix(h, acq, M, k, keep_nan, vals_out, idx_out, count_out);
     }
     return launch_topk(h, acq, M, k, keep_nan, vals_out, idx_out, count_out);
+}
+
+// ---- distributed (block-column-cyclic) factorisation: building blocks (see include/gpimhip.h) ----
+int gpimhip_dist_begin(gpimhip_handle h, int64_t n) {
+    if (!h || n < 1) return GPIMHIP_E_BADARG;
+    HIP_TRY(hipSetDevice(h->device));
+    h->nbatch = 1;
+    GP_TRY(ws_ensure_b(h, n, 1, 0, false));
+    HIP_TRY(hipMemsetAsync(h->info, 0, sizeof(int32_t), h->stream));
+    return GPIMHIP_OK;
+}
+
+int gpimhip_dist_panel_factor(gpimhip_handle h, double* Aloc, int64_t ldloc, int32_t loc_blk0, int32_t glob_blk0,
+                              double* logdet_out, int32_t* info) {
+    if (!h || !Aloc || !info || loc_blk0 < 0 || glob_blk0 < 0 || !h->np) return GPIMHIP_E_BADARG;
+    HIP_TRY(hipSetDevice(h->device));
+    const int nb = (int)(h->np / NB);
+    if (glob_blk0 >= nb || ldloc < (int64_t)(loc_blk0 + std::min(OUTER_W, nb - glob_blk0)) * NB) return GPIMHIP_E_BADARG;
+    h->nbatch = 1;
+    GP_TRY(plan_ensure(h, nb));
+    // the panel's columns live at local block offset loc_blk0: shift the base so that GLOBAL column indices
+    // address them (the panel steps only touch columns of this panel)
+    double* As = Aloc - (int64_t)(glob_blk0 - loc_blk0) * NB;
+    const int p1 = std::min(glob_blk0 + OUTER_W, nb);
+    GP_TRY(panel_steps(h, As, ldloc, info, glob_blk0, p1));
+    if (logdet_out)
+        HIP_TRY(hipMemcpyAsync(logdet_out, h->logdet_part + glob_blk0, (size_t)(p1 - glob_blk0) * sizeof(double),
+                               hipMemcpyDeviceToDevice, h->stream));
+    return GPIMHIP_OK;
+}
+
+int gpimhip_dist_trailing_update(gpimhip_handle h, const double* panel, int64_t ldp, int32_t panel_glob_blk0,
+                                 double* Aloc, int64_t ldloc, int32_t loc_blk0, int32_t glob_blk0) {
+    if (!h || !panel || !Aloc || !h->np || panel_glob_blk0 < 0 || glob_blk0 <= panel_glob_blk0) return GPIMHIP_E_BADARG;
+    HIP_TRY(hipSetDevice(h->device));
+    const int nb = (int)(h->np / NB);
+    if (glob_blk0 >= nb) return GPIMHIP_E_BADARG;
+    h->nbatch = 1;
+    const int ncol = std::min(OUTER_W, nb - glob_blk0), kblk = std::min(OUTER_W, nb - panel_glob_blk0);
+    gpimhip_ctx::DistList* dl = nullptr;
+    for (auto& d : h->dist_lists)
+        if (d.gblk0 == glob_blk0 && d.ncol == ncol) dl = &d;
+    if (!dl) {
+        std::vector<TileDesc> tl;
+        for (int i = glob_blk0; i < nb; ++i)
+            for (int j = glob_blk0; j < std::min(glob_blk0 + ncol, i + 1); ++j) tl.push_back({i, j, 0, 0});
+        gpimhip_ctx::DistList d{glob_blk0, ncol, nullptr, (int64_t)tl.size()};
+        GP_TRY(dev_alloc(h, &d.tiles, d.n));
+        HIP_TRY(hipMemcpyAsync(d.tiles, tl.data(), tl.size() * sizeof(TileDesc), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        h->dist_lists.push_back(d);
+        dl = &h->dist_lists.back();
+    }
+    // operands: the broadcast panel holds columns [panel_glob_blk0, +kblk) of L for ALL rows; shifted bases
+    // again let the tile engine use global block indices
+    const double* Ps = panel - (int64_t)panel_glob_blk0 * NB;
+    double* Cs = Aloc - (int64_t)(glob_blk0 - loc_blk0) * NB;
+    GemmArgs g = gemm_args(Ps, ldp, Ps, ldp, Cs, ldloc, -1.0, 1.0, dl->tiles, (int)dl->n, h->np);
+    g.kfix0 = panel_glob_blk0;
+    g.kfix1 = panel_glob_blk0 + kblk;
+    return launch_gemm(h, false, false, EPI_STORE, g);
 }
 
 int gpimhip_thin_batch(gpimhip_handle h, const double* vals, const int64_t* flat_idx, int32_t n, int32_t d,

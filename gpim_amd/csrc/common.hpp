@@ -128,6 +128,9 @@ struct gpimhip_ctx {
     int fit_completed = 0;
     int32_t* pinned_info = nullptr;
     hipEvent_t ra_ev[2] = {nullptr, nullptr};
+    // distributed factorisation: per global column panel the tile list of its trailing update
+    struct DistList { int gblk0; int ncol; TileDesc* tiles; int64_t n; };
+    std::vector<DistList> dist_lists;
     // sparse (VFE) workspace, owned by vfe.hip (VfeWs*); released by vfe_release()
     void* vfe = nullptr;
     // structured (Kronecker) workspace, owned by kron.hip (KronWs*); released by kron_release()
@@ -152,6 +155,7 @@ struct GemmArgs {
     int chunk;                             // XCD dealing: 0 = contiguous slices, >0 = round-robin chunks
     int inplace;                           // C aliases an operand tile (panel solve): one workgroup must own the whole tile
     int krev;                              // walk each tile's k-range from its end (ranges sharing their upper end)
+    int kfix0, kfix1;                      // when kfix1 > kfix0: every tile uses this k-block range (its own is ignored)
     double* colpart; int64_t ld_colpart;   // EPI_COLSUMSQ: colpart[ci*ld + cj*128 + col]
     int64_t sA, sB, sC, sColpart;          // per-problem (blockIdx.y) strides in elements
 };

@@ -172,7 +172,8 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_tiles_kernel(GemmArgs g) {
             p = b;
         }
     }
-    const TileDesc t = g.tiles[p];
+    TileDesc t = g.tiles[p];
+    if (g.kfix1 > g.kfix0) { t.kb0 = g.kfix0; t.kb1 = g.kfix1; }
     const int nsteps = (t.kb1 - t.kb0) * (NB / GEMM_BK);
     const int qi = (quad / QN) * TSM, qj = (quad % QN) * TSN;
     // batch: blockIdx.y selects the problem; operands advance by their per-problem strides

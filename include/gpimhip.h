@@ -220,6 +220,32 @@ int gpimhip_nanmax(gpimhip_handle h, const double* x, int64_t n, double* out);
 int gpimhip_topk(gpimhip_handle h, const double* acq, int64_t M, int32_t k, int32_t keep_nan,
                  double* vals_out, int64_t* idx_out, int64_t* count_out);
 
+/* ---- one exact GP across several GPUs: building blocks of a block-column-cyclic Cholesky ----------
+ * (SURVEY 8(f) rank 1.  The reference treats a cube as ONE d-dimensional GP, gpim/gpreg/gpr.py:30-43,
+ * 115-126; its covariance does not fit one device beyond N ~ 10^5.)  The matrix is dealt to the P ranks
+ * of a process group by 512-column panels (panel p -> rank p mod P, the 1 x P case of a 2-D block-cyclic
+ * layout); each rank keeps its panels, all rows, side by side in ONE caller-owned row-major array
+ *     Aloc : np x (512 * owned panels), leading dimension ldloc,   np = N padded to 128.
+ * The host driver (gpim_amd/dist_chol.py, torch.distributed / RCCL) runs, for p = 0, 1, ...:
+ *     owner(p):  gpimhip_dist_panel_factor   -> L(:, panel p) in place
+ *     all     :  broadcast of the factored panel (np x 512 doubles, src = owner)
+ *     each    :  gpimhip_dist_trailing_update for every owned panel right of p
+ * With P = 1 the sequence of tile operations is the one gpimhip_potrf performs (same bits).
+ *   gpimhip_dist_begin            per-handle set-up for order n (diagonal-block workspace and launch plans
+ *                                 only -- none of the n x n buffers of the single-GPU path)
+ *   gpimhip_dist_panel_factor     loc_blk0: block column (128-wide) where the panel starts inside Aloc;
+ *                                 glob_blk0: its global block index; logdet_out: up to 4 doubles (device), the
+ *                                 sums of log L_ii of the panel's 128-blocks, or NULL; info as gpimhip_potrf
+ *   gpimhip_dist_trailing_update  panel: the broadcast copy (np rows x 512, leading dimension ldp) of the
+ *                                 factored panel with global block index panel_glob_blk0; updates the owned
+ *                                 panel (loc_blk0 / glob_blk0) in Aloc:  C -= P_rows P_cols^T on tiles i >= j */
+int gpimhip_dist_begin(gpimhip_handle h, int64_t n);
+int gpimhip_dist_panel_factor(gpimhip_handle h, double* Aloc, int64_t ldloc, int32_t loc_blk0,
+                              int32_t glob_blk0, double* logdet_out, int32_t* info);
+int gpimhip_dist_trailing_update(gpimhip_handle h, const double* panel, int64_t ldp,
+                                 int32_t panel_glob_blk0, double* Aloc, int64_t ldloc,
+                                 int32_t loc_blk0, int32_t glob_blk0);
+
 /* Batch thinning of boptimizer.update_points (gpim/gpbayes/boptim.py:326-376): among n <= 1024 ranked
  * candidates (vals, flat grid indices into a d-dimensional grid of the given shape) repeatedly keep the
  * largest remaining value and drop every candidate within Euclidean index distance <= dscale of it

@@ -93,3 +93,98 @@ def test_single_process_paths():
     units = [np.full((2, 2), float(i)) for i in range(3)]
     mean, sd = gd.run_units(units, lambda R: (R + 1, R + 2), (2, 2), device=torch.device("cpu"))
     assert mean.shape == (3, 2, 2) and sd[2, 0, 0].item() == 4.0
+
+
+# ------------------------------------------------------------------------------------------------
+# block-column-cyclic Cholesky: ownership / broadcast schedule with a stubbed tile engine
+# ------------------------------------------------------------------------------------------------
+class NumpyTileEngine:
+    """Test stub of gpim_amd.dist_chol.HipTileEngine (the product engine needs the GPU): the same two tile
+    operations in plain torch-CPU arithmetic, so that world-size-2 gloo ranks can run the real schedule."""
+
+    def __init__(self, layout):
+        self.layout = layout
+        self.bad = 0
+
+    def empty(self, rows, cols):
+        return torch.zeros((rows, cols), dtype=torch.float64)
+
+    def panel_factor(self, Aloc, p):
+        from gpim_amd.dist_chol import PW
+        L = self.layout
+        w, r0, l0 = L.width(p), p * PW, L.local_col0(p)
+        A = Aloc[r0:r0 + w, l0:l0 + w]
+        sym = torch.tril(A) + torch.tril(A, -1).T
+        Lpp, info = torch.linalg.cholesky_ex(sym)
+        if int(info) != 0 and self.bad == 0:
+            self.bad = r0 + int(info)
+        Aloc[r0:r0 + w, l0:l0 + w] = Lpp
+        if r0 + w < L.np:
+            Aloc[r0 + w:, l0:l0 + w] = torch.linalg.solve_triangular(Lpp, Aloc[r0 + w:, l0:l0 + w].T, upper=False).T
+
+    def trailing_update(self, panel, p, Aloc, c):
+        from gpim_amd.dist_chol import PW
+        L = self.layout
+        wp, wc, c0, l0 = L.width(p), L.width(c), c * PW, L.local_col0(c)
+        Aloc[c0:, l0:l0 + wc] -= panel[c0:, :wp] @ panel[c0:c0 + wc, :wp].T
+
+    def failed_column(self):
+        return self.bad
+
+
+def _chol_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from gpim_amd import dist as gd
+    from gpim_amd.dist_chol import DistributedCholesky, Layout
+    gd.init_from_env(backend="gloo")
+    for n in (1500, 512, 700):                       # 3 panels (ragged last), 1 panel, 2 panels
+        rng = np.random.default_rng(n)
+        B = rng.standard_normal((n, n // 2))
+        A = torch.from_numpy(B @ B.T + n * np.eye(n))
+        y = torch.from_numpy(rng.standard_normal(n))
+        ch = DistributedCholesky(n, engine_factory=NumpyTileEngine)
+        lay = ch.layout
+        assert lay.owned == [p for p in range(lay.npanel) if p % world == rank]
+        assert ch.local.shape == (lay.np, max(1, len(lay.owned)) * 512)
+        ch.set_from_function(lambda c0, c1: A[:, c0:c1]).factor()
+        Lref = torch.linalg.cholesky(A)
+        Lfull = ch.gather_lower()
+        assert torch.allclose(Lfull, Lref, rtol=1e-11, atol=1e-11)
+        assert abs(ch.logdet() - torch.logdet(A).item()) < 1e-9 * abs(torch.logdet(A).item())
+        alpha = ch.solve(y)
+        assert torch.allclose(alpha, torch.cholesky_solve(y[:, None], Lref)[:, 0], rtol=1e-9, atol=1e-12)
+        ref_nll = 0.5 * float(y @ torch.cholesky_solve(y[:, None], Lref)[:, 0]) + 0.5 * torch.logdet(A).item() \
+            + 0.5 * n * np.log(2 * np.pi)
+        assert abs(ch.nll(y) - ref_nll) < 1e-9 * abs(ref_nll)
+    # a matrix that is not positive-definite is reported on every rank
+    A = torch.eye(700, dtype=torch.float64)
+    A[600, 600] = -1.0
+    ch = DistributedCholesky(700, engine_factory=NumpyTileEngine)
+    try:
+        ch.set_from_function(lambda c0, c1: A[:, c0:c1]).factor()
+        raised = False
+    except torch.linalg.LinAlgError:
+        raised = True
+    assert raised
+    ret[rank] = True
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_block_cyclic_cholesky_schedule_gloo(world):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_chol_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert all(ret.get(r) for r in range(world))
+
+
+def test_block_cyclic_layout():
+    from gpim_amd.dist_chol import Layout
+    lay = Layout(65536, 3, 8)
+    assert lay.nb == 512 and lay.npanel == 128 and lay.owned == list(range(3, 128, 8))
+    assert lay.owner(19) == 3 and lay.local_col0(19) == 2 * 512 and lay.local_cols == 16 * 512
+    lay = Layout(700, 0, 1)
+    assert lay.np == 768 and lay.npanel == 2 and lay.width(1) == 256 and lay.owned == [0, 1]

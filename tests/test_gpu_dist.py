@@ -1,0 +1,71 @@
+"""
+One exact GP across GPUs -- gpim_amd/dist_chol.py on the HIP tile engine, single process (P = 1): the
+block-column-cyclic driver performs the tile operations of gpimhip_potrf in the same order, so the factor
+is bit-identical; log det / solve / NLL / posterior mean against torch and the dense oracle.  The multi-rank
+schedule itself (ownership, broadcasts, small collectives of the solves) is covered on CPU ranks in
+tests/test_dist_gloo.py with a stub engine; a multi-GPU run needs the driver's 8-GPU node.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+from numpy.testing import assert_allclose
+
+pytestmark = pytest.mark.gpu
+
+from oracle import gpim_oracle as O
+
+
+@pytest.mark.parametrize("n", [700, 1500, 4096])
+def test_p1_bit_identical_to_potrf(ensure_built, n):
+    from gpim_amd import _lib
+    from gpim_amd.dist_chol import DistributedCholesky
+    rng = np.random.default_rng(n)
+    B = rng.standard_normal((n, n // 3))
+    A = torch.from_numpy(B @ B.T + n * np.eye(n)).cuda()
+    ch = DistributedCholesky(n)
+    ch.set_from_function(lambda c0, c1: A[:, c0:c1]).factor()
+    Ld = ch.gather_lower()
+    H = _lib.Handle()
+    Lp = A.clone()
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    _lib.check(H.lib.gpimhip_potrf(H.h, _lib.ptr(Lp), n, n, _lib.ptr(info)))
+    torch.cuda.synchronize()
+    assert info.item() == 0
+    assert torch.equal(Ld, torch.tril(Lp))
+    ref = torch.linalg.cholesky(A)
+    assert_allclose(ch.logdet(), 2 * torch.log(torch.diagonal(ref)).sum().item(), rtol=1e-12)
+    y = torch.from_numpy(rng.standard_normal(n)).cuda()
+    alpha = ch.solve(y)
+    assert_allclose(alpha.cpu().numpy(), torch.cholesky_solve(y[:, None], ref)[:, 0].cpu().numpy(), rtol=1e-8, atol=1e-12)
+    H.close()
+
+
+def test_not_pd_raises(ensure_built):
+    from gpim_amd.dist_chol import DistributedCholesky
+    A = torch.eye(900, dtype=torch.float64, device="cuda")
+    A[650, 650] = -2.0
+    with pytest.raises(torch.linalg.LinAlgError):
+        DistributedCholesky(900).set_from_function(lambda c0, c1: A[:, c0:c1]).factor()
+
+
+def test_exact_gp_posterior_mean_vs_oracle(ensure_built):
+    """Posterior mean and NLL of one exact GP through the distributed driver (P = 1) against the dense oracle."""
+    from gpim_amd.dist_chol import exact_gp_posterior_mean
+    rng = np.random.default_rng(2)
+    pts = np.unique(rng.integers(0, 60, size=(4000, 2)), axis=0)
+    pts = pts[rng.permutation(len(pts))[:1300]].astype(np.float64)
+    y = np.sin(pts[:, 0] / 7.0) * np.cos(pts[:, 1] / 9.0) + 0.05 * rng.standard_normal(len(pts))
+    Xs = rng.uniform(0, 59, size=(777, 2))
+    ls, var, noise = [6.0, 8.0], 1.3, 0.02
+    mean, nll = exact_gp_posterior_mean(pts, y, Xs, kernel="Matern52", lengthscale=ls, variance=var, noise=noise)
+    kp = O.KernelParams("Matern52", 2, [[0., 0.], [12., 16.]])
+    with torch.no_grad():
+        kp.u_var.copy_(torch.logit(torch.tensor((var - 1e-4) / (10 - 1e-4), dtype=torch.float64)))
+        kp.u_ls.copy_(torch.zeros(2, dtype=torch.float64))          # sigmoid(0) = 1/2 -> ls = hi / 2
+        kp.u_noise.copy_(torch.log(torch.tensor(noise, dtype=torch.float64)))
+    gp = O.ExactGP(torch.from_numpy(pts), torch.from_numpy(y), kp, 1e-5)
+    mref, _ = gp.predict(torch.from_numpy(Xs))
+    assert_allclose(mean, mref.numpy(), atol=1e-9)
+    assert_allclose(nll, (gp.loss() - kp.neg_log_prior()).item(), rtol=1e-11)
