@@ -215,12 +215,21 @@ def main():
                     help="Adam iterations per step (the named workloads use 100 (c2) / 250 (c3))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip rmse_vs_oracle and the C1/C3/C4 extras")
+    ap.add_argument("--extras-only", action="store_true",
+                    help="internal: print {rmse_vs_oracle, extra} as one JSON line and exit (run by the default "
+                         "command in a child process, so that a kernel trace of the parent holds the timed "
+                         "workload's launches only)")
     args = ap.parse_args()
 
     import torch.distributed as dist
     import gpim_amd
     from gpim_amd import _lib, dist as gdist
     from problems import hyperspectral_cube, lattice_image
+
+    if args.extras_only:
+        torch.cuda.set_device(0)
+        print(json.dumps({"rmse_vs_oracle": rmse_vs_oracle(gpim_amd), "extra": extra_configs(gpim_amd)}))
+        return
 
     rank, world, local_rank = gdist.init_from_env()
     if world != args.gpus:
@@ -397,8 +406,15 @@ def main():
         if world == 1:
             out["cpu_baseline"] = cpu_baseline(N, M, T) if (args.workload == "c2" and not args.no_cpu_baseline) else None
             if not args.no_extra and args.workload == "c2":
-                out["rmse_vs_oracle"] = rmse_vs_oracle(gpim_amd)
-                out["extra"] = extra_configs(gpim_amd)
+                # in a child process: the other configs launch the same kernel instantiations at other sizes,
+                # and would blur the per-kernel averages of a `rocprofv3 --stats` run of this command
+                import subprocess
+                child = subprocess.run([sys.executable, os.path.abspath(__file__), "--extras-only"],
+                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+                try:
+                    out.update(json.loads(child.stdout.strip().splitlines()[-1]))
+                except Exception:
+                    out["extra"] = {"error": (child.stderr or child.stdout)[-400:]}
         print(json.dumps(out))
     if world > 1:
         dist.barrier(device_ids=[local_rank])

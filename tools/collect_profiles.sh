@@ -1,11 +1,12 @@
 #!/bin/bash
 # Collects the rocprofv3 summaries committed under profiles/ (run on the MI355X box through gpurun;
-# outputs land in gpurun_out/prof_final -- delete that directory on the dev box first, gpurun merges into it and
+# outputs land in gpurun_out/prof_<round tag> -- delete that directory on the dev box first, gpurun merges into it and
 # rocprofv3 names its files by process id -- and are copied into profiles/ by hand, then
 # tools/summarize_profiles.py regenerates the derived tables).
 cd /tmp; export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out/prof_final
+TAG=${1:-r02}
+O=$R/gpurun_out/prof_$TAG
 rm -rf $O; mkdir -p $O
 # 1. kernel stats of the bench command itself (+ the JSON lines with and without the profiler)
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_stats -- python $R/bench.py > $O/bench_line_profiled.json 2> $O/bench_profiled.err
@@ -15,4 +16,6 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES
   tag=$(echo $set | cut -d' ' -f1)
   rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/pmc_$tag -- python $R/tests/tools/prof_fit.py 16384 2 0 Matern52 > /dev/null 2>&1
 done
+# the profiled bench also traces its child process (the extras): keep the PARENT's stats (lowest pid)
+ls $O/bench_stats/*/*_kernel_stats.csv | sort -t/ -k1 -V | head -3
 find $O -name "*.csv" | head -30

@@ -1,6 +1,7 @@
 """Derives profiles/pmc_lauum.json and the tables of profiles/README.md from the rocprofv3 CSVs that
 tools/collect_profiles.sh produced (run on the dev box after copying them into profiles/)."""
-import csv, collections, json, os, re
+import csv, collections, json, os, re, sys
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 P = os.path.join(ROOT, "profiles")
 N = 16384
@@ -15,11 +16,11 @@ def avg(d, key, pred):
     v = [c[key] for (_, k), c in d.items() if pred(k)]
     return sum(v) / len(v), len(v)
 
-f = per_kernel(os.path.join(P, "r01_pmc_FETCH_SIZE_fit_n16384.csv"))
-w = per_kernel(os.path.join(P, "r01_pmc_WRITE_SIZE_fit_n16384.csv"))
-m = per_kernel(os.path.join(P, "r01_pmc_MFMA_fit_n16384.csv"))
-stats = {r["Name"]: r for r in csv.DictReader(open(os.path.join(P, "r01_bench_kernel_stats.csv")))}
-line = json.load(open(os.path.join(P, "r01_bench_line.json")))
+f = per_kernel(os.path.join(P, TAG + "_pmc_FETCH_SIZE_fit_n16384.csv"))
+w = per_kernel(os.path.join(P, TAG + "_pmc_WRITE_SIZE_fit_n16384.csv"))
+m = per_kernel(os.path.join(P, TAG + "_pmc_MFMA_fit_n16384.csv"))
+stats = {r["Name"]: r for r in csv.DictReader(open(os.path.join(P, TAG + "_bench_kernel_stats.csv")))}
+line = json.load(open(os.path.join(P, TAG + "_bench_line.json")))
 
 lau = lambda k: "true, true" in k
 fl, n = avg(f, "FETCH_SIZE", lau)
@@ -72,6 +73,6 @@ readme = open(os.path.join(P, "README.md")).read()
 readme = re.sub(r"<!-- MFMA_TABLE -->.*?<!-- /MFMA_TABLE -->", "<!-- MFMA_TABLE -->\n" + mfma_table + "\n<!-- /MFMA_TABLE -->", readme, flags=re.S)
 readme = re.sub(r"<!-- HBM_TABLE -->.*?<!-- /HBM_TABLE -->", "<!-- HBM_TABLE -->\n" + "\n".join(hbm) + "\n<!-- /HBM_TABLE -->", readme, flags=re.S)
 readme = re.sub(r"<!-- LAUUM -->.*?<!-- /LAUUM -->", "<!-- LAUUM -->`AverageNs` in the stats CSV: %.2f ms; `roofline.avg_launch_ms` of the committed bench line: %.2f ms (%.1f TFLOP/s, frac %.3f); L2-miss traffic %.1f GB per launch<!-- /LAUUM -->" % (
-    lau_ms, line["roofline"]["avg_launch_ms"], line["roofline"]["achieved"], line["roofline"]["frac"], out["hbm_bytes_per_launch"] / 1e9), readme, flags=re.S)
+    lau_ms, line["roofline"]["dominant_launch"]["avg_launch_ms"], line["roofline"]["dominant_launch"]["achieved"], line["roofline"]["dominant_launch"]["achieved"] / 78.6, out["hbm_bytes_per_launch"] / 1e9), readme, flags=re.S)
 open(os.path.join(P, "README.md"), "w").write(readme)
 print(mfma_table); print("\n".join(hbm)); print(json.dumps({k: out[k] for k in ("hbm_bytes_per_launch", "avg_launch_ms_rocprof_stats")}))
