@@ -7,7 +7,7 @@ Pins the oracle (oracle/gpim_oracle.py) to the reference's own known answers.
 * test_notebook_trace: the hyper-parameters printed after every 1000-iteration training in
   examples/notebooks/GP_based_exploration_exploitation.ipynb (four runs: plain EI, EI + mask,
   EI + dscale/memory, custom acquisition).  The CPU suite replays the first rows of each run;
-  tests/tools/pin_oracle_full.py replays all 51 rows (result recorded in DESIGN.md).
+  tests/tools/pin_oracle_full.py replays all 51 rows (result: tests/golden/oracle_full_replay.json).
 """
 import json
 import os
