@@ -62,10 +62,9 @@ def gather_to_root(local, n_units, unit_shape, device=None, dtype=torch.float64)
     if ws == 1:
         parts = [slab]
     else:
-        # all_gather (the most basic RCCL collective) rather than gather: the slabs are small and every
-        # backend implements it; only rank 0 assembles the result
-        parts = [torch.empty_like(slab) for _ in range(ws)]
-        dist.all_gather(parts, slab)
+        # one gather to rank 0 (RCCL ncclGather = grouped send/recv): only the root receives the slabs
+        parts = [torch.empty_like(slab) for _ in range(ws)] if rank == 0 else None
+        dist.gather(slab, gather_list=parts, dst=0)
         if rank != 0:
             return None
     full = torch.empty((n_units,) + tuple(unit_shape), dtype=dtype, device=device)
@@ -184,13 +183,13 @@ def global_topk(local_vals, local_idx, k, nan_first=False):
     if not nan_first:
         keep = keep & ~torch.isnan(vals)
     vals, idx = vals[keep], idx[keep]
-    vl, il = vals.tolist(), idx.tolist()
-
-    def key(i):
-        v = vl[i]
-        return (float("inf") if v != v else v, 1 if v != v else 0, il[i])
-    order = sorted(range(len(vl)), key=key, reverse=True)[:k]
-    order = torch.as_tensor(order, dtype=torch.int64, device=vals.device)
+    # descending by (NaN first, value, flat index): three stable sorts from the least significant key up,
+    # on the device the pairs live on
+    isnan = torch.isnan(vals)
+    order = torch.sort(idx, descending=True, stable=True).indices
+    order = order[torch.sort(torch.where(isnan, torch.full_like(vals, float("inf")), vals)[order], descending=True,
+                             stable=True).indices]
+    order = order[torch.sort(isnan[order].to(torch.int8), descending=True, stable=True).indices][:k]
     return vals[order], idx[order]
 
 
