@@ -31,7 +31,7 @@ roofline: fp64 MFMA.  Top level = algorithmic flop of one step (T*N^3 for the fi
 cpu_baseline: the CPU oracle (torch fp64 + autograd restatement of the reference, kind "port")
           timed on rank 0's host cores at three sizes; iteration and prediction times are fitted to
           a*N^2 + b*N^3 (resp. c*N*M + e*N^2*M) and evaluated at the full size.
-extra   : driver-run throughputs of the other BASELINE.json configs that fit one GPU (C1, C3, C4).
+extra   : driver-run throughputs of the other BASELINE.json configs (C1, C3, C4, C5) on one GPU.
 """
 import argparse
 import ctypes
@@ -166,7 +166,7 @@ def rmse_vs_oracle(gpim, iterations=5):
 # ------------------------------------------------------------------------------------------------
 def extra_configs(gpim):
     from gpim_amd import dist as gdist
-    from problems import hyperspectral_cube, notebook_problem, spiral_image
+    from problems import ckpfm_cube, hyperspectral_cube, notebook_problem, spiral_image
     out = {}
     sync = torch.cuda.synchronize
     # C1: 128x128 spiral twin, RBF, T = 300
@@ -202,6 +202,29 @@ def extra_configs(gpim):
     out["C4"] = {"workload": "BO 25x25, EI, 30 steps x (1000 Adam its + acquisition sweep), boptimizer.run()",
                  "seconds": dt, "grid_points_per_s": 625 * 30 / dt, "steps_per_s": 30 / dt,
                  "us_per_adam_iteration": dt / (31 * 1000) * 1e6}
+    # C5: 4D cKPFM twin 10x10x64x5, one GP per Ns slice (N = 6400 points in 3-D, fully observed), T = 200:
+    # (i) the reference's model for it -- sparse VFE with indpoints=512 (534 inducing inputs);
+    # (ii) the same slices as EXACT GPs through the Kronecker solver (possible because the slices are complete grids)
+    cube4 = ckpfm_cube()
+    kw5 = dict(kernel="RBF", learning_rate=0.05, iterations=200)
+    gdist.reconstruct_slices(cube4[..., :1], axis=-1, sparse=True, indpoints=512, **dict(kw5, iterations=3))
+    sync(); t0 = time.perf_counter()
+    gdist.reconstruct_slices(cube4, axis=-1, sparse=True, indpoints=512, **kw5)
+    sync(); dt = time.perf_counter() - t0
+    out["C5"] = {"workload": "10x10x64x5 cKPFM twin, 5 per-Ns slices (N=6400 each), sparse VFE with 534 inducing inputs, "
+                             "RBF, T=200, dist.reconstruct_slices on one GPU",
+                 "seconds": dt, "grid_points_per_s": cube4.size / dt, "ms_per_adam_iteration": dt / (5 * 200) * 1e3}
+    R5 = cube4[..., 0]
+    Xf5 = gpim.utils.get_full_grid(R5)
+    gpim.reconstructor(Xf5, R5, Xf5, structured=True, verbose=0, **dict(kw5, iterations=3)).run()
+    sync(); t0 = time.perf_counter()
+    for k in range(cube4.shape[-1]):
+        gpim.reconstructor(Xf5, cube4[..., k], Xf5, structured=True, verbose=0, **kw5).run()
+    sync(); dt = time.perf_counter() - t0
+    out["C5_structured_exact"] = {"workload": "the same 5 slices as exact GPs through the Kronecker solver "
+                                              "(reconstructor(structured=True)), RBF, T=200",
+                                  "seconds": dt, "grid_points_per_s": cube4.size / dt,
+                                  "ms_per_adam_iteration": dt / (5 * 200) * 1e3}
     return out
 
 
