@@ -150,6 +150,58 @@ __global__ __launch_bounds__(NW * 64, 1) void loop256(const double* __restrict__
     if (t == 1.2345) out[0] = t;
 }
 
+// ---------------------------------------------------------------- V4: register-direct operands (no LDS, no barriers)
+// Every wave loads its own 64x64 tile's operand fragments straight from global memory / L2 into registers in
+// MFMA operand layout: lane group q = lane >> 4 takes k = 2q, 2q+1 of an 8-deep half-step (16 contiguous bytes of a
+// k-contiguous row) -- any assignment of k to lane groups is fine as long as A and B use the same one.  One
+// global_load_dwordx4 per 16x16 row block per half-step: 8 loads feed 32 MFMAs; the next half-step's loads are
+// in flight while the current one computes.  2 workgroups x 4 waves per CU as in the shipped kernel.
+template <int PRIO>
+__global__ __launch_bounds__(256, 2) void loop_regdirect(const double* __restrict__ G, double* out, int steps) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    constexpr int LD = 4112;
+    d4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (d4){0, 0, 0, 0};
+    const int r = lane & 15, q = lane >> 4;
+    const int rowA = (blockIdx.x * 128 + wm * 64 + r) % 3840, rowB = ((blockIdx.x * 37 + 5) * 128 + wn * 64 + r) % 3840;
+    const double* pa = G + (size_t)rowA * LD + 2 * q;
+    const double* pb = G + (size_t)rowB * LD + 2 * q;
+    d2 ca[4], cb[4], na[4], nb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        ca[i] = *reinterpret_cast<const d2*>(pa + (size_t)i * 16 * LD);
+        cb[i] = *reinterpret_cast<const d2*>(pb + (size_t)i * 16 * LD);
+    }
+    for (int s = 0; s < 2 * steps; ++s) {               // half-steps of 8 k
+        const int koff = ((s + 1) * 8) & 4095;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            na[i] = *reinterpret_cast<const d2*>(pa + (size_t)i * 16 * LD + koff);
+            nb[i] = *reinterpret_cast<const d2*>(pb + (size_t)i * 16 * LD + koff);
+        }
+        if (PRIO) __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ca[i][e], cb[j][e], acc[i][j], 0, 0, 0);
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { ca[i] = na[i]; cb[i] = nb[i]; }
+    }
+    double t = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (t == 1.2345) out[0] = t;
+}
+
 template <typename F>
 static void timeit(const char* tag, double flop, F launch) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -167,13 +219,15 @@ static void timeit(const char* tag, double flop, F launch) {
 
 int main() {
     double *G, *out;
-    hipMalloc(&G, (size_t)4096 * 4096 * 8); hipMemset(G, 0, (size_t)4096 * 4096 * 8); hipMalloc(&out, 16);
+    hipMalloc(&G, (size_t)4096 * 4112 * 8); hipMemset(G, 0, (size_t)4096 * 4112 * 8); hipMalloc(&out, 16);
     const int steps = 2048;
     {
         const int wgs = 2048;
         const double flop = (double)wgs * 4 * steps * 64 * 2048.0;
         timeit("V0 128x128, 4 waves x 64x64, 2 WG/CU, ds_read_b64", flop, [&] { hipLaunchKernelGGL((loop128<0>), dim3(wgs), dim3(256), 0, 0, G, out, steps); });
         timeit("V1 128x128, 4 waves x 64x64, 2 WG/CU, ds_read_b128", flop, [&] { hipLaunchKernelGGL((loop128<1>), dim3(wgs), dim3(256), 0, 0, G, out, steps); });
+        timeit("V4 128x128, 4 waves x 64x64, 2 WG/CU, register-direct operands (no LDS)", flop, [&] { hipLaunchKernelGGL((loop_regdirect<0>), dim3(wgs), dim3(256), 0, 0, G, out, steps); });
+        timeit("V4 same + s_setprio around the MFMA block", flop, [&] { hipLaunchKernelGGL((loop_regdirect<1>), dim3(wgs), dim3(256), 0, 0, G, out, steps); });
     }
     {
         const int wgs = 1024;
