@@ -155,19 +155,41 @@ __device__ __forceinline__ double kwave_sum(double v) {
 // loads, several pairs in flight), then applies them.
 // Stopping rule per pair (i, j) with a = |w_i|^2, b = |w_j|^2, c = w_i . w_j:
 //   |c| <= 1e-15 sqrt(a b)                          rows orthogonal to working precision, or
-//   |c| <= 2e-15 lmax (sqrt(a) + sqrt(b))           the coupling (V K V^T)_ij ~ c / (lam_i + lam_j) is below
+//   |c| <= 2e-15 lmax sqrt(a + b)                   the coupling (V K V^T)_ij ~ c / (lam_i + lam_j) is below
 //                                                   ~10 eps * lmax: RBF Gram matrices have most of their
 //                                                   spectrum below eps * lmax, and rows that are pure
 //                                                   rounding noise never get orthogonal in the relative sense
 // Eigenvalue j = (row j of W) . (row j of V) -- keeps the sign of numerically negative ones.
 #define EIGH_WAVES 16
 
+// 1/x and 1/sqrt(x) from the hardware seeds (v_rcp_f64 / v_rsq_f64) + two Newton steps: a tenth of the
+// instructions of an IEEE divide / square root.  tools/jacobi_prof.hip: with 16 waves on 4 SIMDs the
+// rotation arithmetic -- 3 divides and 4 square roots per pair, ~1500 issue cycles -- was what a step waited
+// for, not the row loads.
+__device__ __forceinline__ double fast_rcp(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    y = fma(y, fma(-x, y, 1.0), y);
+    return fma(y, fma(-x, y, 1.0), y);
+}
+__device__ __forceinline__ double fast_rsqrt(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    y = y * fma(-0.5 * x * y, y, 1.5);
+    return y * fma(-0.5 * x * y, y, 1.5);
+}
+
+// rotation that makes rows i, j orthogonal (a = |w_i|^2, b = |w_j|^2, c = w_i . w_j), or false when the pair
+// passes the stopping rule above.  With d = b - a, e = 2c:  tan = sign(d e) |e| / (|d| + sqrt(d^2 + e^2)).
+// The tests are on squares ((sqrt a + sqrt b)^2 <= 2 (a + b)), so nothing here divides or takes a root the
+// slow way; cos = 1/sqrt(1 + tan^2) is accurate to rounding, which is what keeps V orthogonal.
 __device__ __forceinline__ bool jacobi_rotation(double a, double b, double c, double lmax, double& cs, double& sn) {
-    const double ac = fabs(c);
-    if (!(ac > 1e-15 * sqrt(a * b) && ac > 2e-15 * lmax * (sqrt(a) + sqrt(b)))) return false;
-    const double zeta = (b - a) / (2.0 * c);
-    const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-    cs = 1.0 / sqrt(1.0 + t * t);
+    const double c2 = c * c;
+    if (!(c2 > 1e-30 * (a * b) && c2 > (4e-30 * lmax * lmax) * (a + b))) return false;
+    const double d = b - a, e = 2.0 * c;
+    const double h2 = fma(d, d, e * e);
+    const double h = h2 * fast_rsqrt(h2);
+    double t = fabs(e) * fast_rcp(fabs(d) + h);
+    t = ((d >= 0.0) == (e >= 0.0)) ? t : -t;
+    cs = fast_rsqrt(fma(t, t, 1.0));
     sn = cs * t;
     return true;
 }

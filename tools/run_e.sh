@@ -1,6 +1,6 @@
 cd /tmp; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-for v in off 96 80 64 48 32; do
-  if [ $v = off ]; then unset GPIMHIP_RELAX_ROWS; else export GPIMHIP_RELAX_ROWS=$v; fi
-  echo "== relax rows > $v"; PROF_STAGES=1 python $R/tests/tools/prof_fit.py 16384 3 0 Matern52 2>&1 | grep -E "stage potrf"
-done
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/kt_c3 -- python $R/tests/tools/bench_c3.py > /tmp/c3.log 2>&1
+tail -2 /tmp/c3.log
+f=$(ls -t $R/gpurun_out/kt_c3/*/*kernel_stats.csv | head -1)
+head -16 $f | cut -c1-150
