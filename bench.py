@@ -20,8 +20,8 @@ N > 1   : one process per GPU (torchrun contract).
               and fitted in lock-step batches per GPU; total work fixed.  Strong scaling.
           --workload c2full: the COMPLETE 256x256 image of config C2 as ONE exact GP (N = 65536, a 32 GiB
               covariance) across the GPUs: block-column-cyclic Cholesky with one panel broadcast per 512
-              columns (gpim_amd/dist_chol.py), distributed solves, posterior mean on the grid, at fixed
-              hyper-parameters.  Strong scaling.
+              columns (gpim_amd/dist_chol.py), distributed solves, posterior mean and sd on the grid, at
+              fixed hyper-parameters.  Strong scaling.
 roofline: fp64 MFMA.  Top level = algorithmic flop of one step (T*N^3 for the fits: potrf N^3/3 +
           L^-1 N^3/3 + K^-1 N^3/3 per Adam iteration; 2N^3/3 + N^2*M for the prediction) / step time
           / 78.6 TFLOP/s.  ``stages`` breaks it down by the blocked-algorithm stage, each timed live
@@ -293,7 +293,7 @@ def main():
                 return gdist.gather_to_root({rank: torch.stack([mean_d, sd_d])}, world, (2, M), device=dev)
             return torch.stack([mean_d, sd_d]).unsqueeze(0)
     elif args.workload == "c2full":
-        from gpim_amd.dist_chol import exact_gp_posterior_mean
+        from gpim_amd.dist_chol import exact_gp_posterior
         T = 0
         R, _ = lattice_image(size=WORKLOAD["size"], frac=1.0, seed=1)
         ii, jj = np.meshgrid(np.arange(R.shape[0], dtype=np.float64), np.arange(R.shape[1], dtype=np.float64), indexing="ij")
@@ -305,7 +305,7 @@ def main():
         hyper = dict(kernel="Matern52", lengthscale=[4.0, 4.0], variance=0.05, noise=4e-4)
 
         def step():
-            return exact_gp_posterior_mean(Xall, yall, Xall, **hyper)
+            return exact_gp_posterior(Xall, yall, Xall, **hyper)
     else:
         T = args.iterations or C3["iterations"]
         cube, _ = hyperspectral_cube()
@@ -398,21 +398,21 @@ def main():
             }
             out["stages_ms_per_call"] = {k: (v[0] / v[1] if v[1] else None) for k, v in stage_ms.items()}
         elif args.workload == "c2full":
-            mean_f, nll_f = res
-            assert mean_f.shape == (M,) and np.isfinite(mean_f).all() and np.isfinite(nll_f)
+            mean_f, sd_f, nll_f = res
+            assert mean_f.shape == (M,) and np.isfinite(mean_f).all() and np.isfinite(sd_f).all() and np.isfinite(nll_f)
             rms = float(np.sqrt(np.mean((mean_f - yall) ** 2)))
             out["config"] = {"workload": ("C2 complete: 256x256 synthetic twisted-lattice image, ALL pixels observed "
                                           "(N=%d), ONE Matern52 exact GP across the GPUs at fixed hyper-parameters: "
-                                          "block-column-cyclic Cholesky + distributed solves + posterior mean on the "
-                                          "grid (M=%d)") % (N, M),
+                                          "block-column-cyclic Cholesky + distributed solves + posterior mean and sd on "
+                                          "the grid (M=%d)") % (N, M),
                              "N": N, "M": M, "kernel": "Matern52", "hyperparameters": hyper,
                              "rms_mean_minus_data": rms, "nll": nll_f}
-            flop_step = float(N) ** 3 / 3.0
+            flop_step = float(N) ** 3 / 3.0 + float(N) ** 2 * M
             achieved = flop_step / (ms_step * 1e-3) / 1e12 / world
             out["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
-                               "scope": "whole step per GPU: N^3/3 flop of the factorisation / ms_per_step / n_gpus (the "
-                                        "step also builds K, solves and predicts: O(N^2) each)"}
+                               "scope": "whole step per GPU: (N^3/3 factorisation + N^2*M variance solves) / ms_per_step / "
+                                        "n_gpus; the variance GEMMs are rocBLAS (plain library GEMMs through torch)"}
         else:
             mean_c, sd_c = res
             assert mean_c.shape == cube.shape and np.isfinite(mean_c).all() and np.isfinite(sd_c).all()

@@ -21,9 +21,10 @@ Per-rank memory: N^2 / P doubles + two panel buffers.  Communication per rank: N
 total, about the time of the 1/P share of the N^3 / 3 flop at N = 65536, P = 8.
 
 What the distributed model offers: the factor, log det K, the negative log marginal likelihood at given
-hyper-parameters and the posterior MEAN (two distributed triangular solves, O(N^2), then a K*^T alpha
-product that shards over test points).  Training gradients (the distributed K^-1) and the posterior
-variance are not built: hyper-parameters come from a single-GPU fit on a sub-sample.
+hyper-parameters and the posterior mean and standard deviation (two distributed triangular solves for
+alpha, O(N^2); K*^T alpha sharded over test points; for the variance the factor is streamed through every
+rank once more while each rank forward-substitutes its own test columns).  Training gradients (the
+distributed K^-1) are not built: hyper-parameters come from a single-GPU fit on a sub-sample.
 
 The tile arithmetic is behind a small engine interface so that the ownership / broadcast schedule can be
 tested on CPU ranks (gloo) with a stub (tests/test_dist_gloo.py); ``HipTileEngine`` is the product engine and
@@ -215,6 +216,31 @@ class DistributedCholesky:
         self._z = z
         return a[:L.n]
 
+    def solve_colsumsq(self, B):
+        """q_j = |L^-1 B[:, j]|^2 for this rank's own right-hand sides B (np x m, rows beyond n zero; destroyed):
+        the quadratic form of the posterior variance.  L is distributed by columns, the right-hand sides by
+        rank, so the factor is streamed once more -- every owner re-broadcasts its panels in order -- and each
+        rank forward-substitutes its columns: a 512-row triangular solve and a plain (np - r) x 512 x m GEMM
+        per panel (rocBLAS through torch: ordinary library GEMMs, N^2 m flop per rank).  Collective: every
+        rank must call it the same number of times."""
+        L = self.layout
+        q = torch.zeros((B.shape[1],), dtype=torch.float64, device=B.device)
+        for p in range(L.npanel):
+            buf = self._panel[p & 1]
+            w, r0 = L.width(p), p * PW
+            if L.owner(p) == L.rank:
+                l0 = L.local_col0(p)
+                buf[r0:, :w] = self.local[r0:, l0:l0 + w]
+            if L.world > 1:
+                dist.broadcast(buf, src=L.owner(p), group=self.group)
+            if B.shape[1] == 0:
+                continue
+            Wp = torch.linalg.solve_triangular(torch.tril(buf[r0:r0 + w, :w]), B[r0:r0 + w], upper=False)
+            q += (Wp * Wp).sum(0)
+            if r0 + w < L.np:
+                B[r0 + w:].addmm_(buf[r0 + w:, :w], Wp, alpha=-1.0)
+        return q
+
     def nll(self, y):
         """1/2 y^T K^-1 y + 1/2 log det K + N/2 log 2 pi (no prior constant)."""
         alpha = self.solve(y)
@@ -236,11 +262,14 @@ class DistributedCholesky:
         return torch.tril(full)[:L.n, :L.n]
 
 
-def exact_gp_posterior_mean(X, y, Xtest, kernel="Matern52", lengthscale=None, variance=1.0, noise=1e-2,
-                            jitter=1e-5, group=None):
-    """Posterior mean of ONE exact GP on all N points across the ranks of the process group, at fixed
-    hyper-parameters (constrained values).  X (N, d), y (N,), Xtest (M, d) numpy / torch; every rank passes
-    the same arrays and gets the same (M,) mean back.  Also returns the negative log marginal likelihood."""
+def exact_gp_posterior(X, y, Xtest, kernel="Matern52", lengthscale=None, variance=1.0, noise=1e-2,
+                       jitter=1e-5, group=None, with_sd=True, chunk_bytes=1 << 32):
+    """Posterior of ONE exact GP on all N points across the ranks of the process group, at fixed
+    hyper-parameters (constrained values): what ``reconstructor.predict`` returns (gpr.py:247-250; mean, and sd
+    with the noise included), for covariances too large for one device.  X (N, d), y (N,), Xtest (M, d) numpy /
+    torch; every rank passes the same arrays and gets the same results back: (mean, sd, nll) -- sd is None
+    when ``with_sd`` is False.  Test points are sharded over the ranks; the variance streams the factor
+    through every rank once per ``chunk_bytes`` of K* columns (DistributedCholesky.solve_colsumsq)."""
     from . import _lib
     from .kernels import KernelSpec
     rank, world = _world()
@@ -256,34 +285,49 @@ def exact_gp_posterior_mean(X, y, Xtest, kernel="Matern52", lengthscale=None, va
     theta = torch.cat([torch.tensor([variance], dtype=torch.float64), ls,
                        torch.ones(1, dtype=torch.float64)]).to(dev)
 
+    def kmat(Z, out):
+        _lib.check(H.lib.gpimhip_kmat(H.h, ctypes.byref(m), _lib.ptr(Xd), N, _lib.ptr(Z), Z.shape[0], _lib.ptr(theta),
+                                      0.0, _lib.ptr(out), out.stride(0)))
+
     def cols(c0, c1):
         out = torch.empty((N, c1 - c0), dtype=torch.float64, device=dev)
-        _lib.check(H.lib.gpimhip_kmat(H.h, ctypes.byref(m), _lib.ptr(Xd), N, _lib.ptr(Xd[c0:c1].contiguous()), c1 - c0,
-                                      _lib.ptr(theta), 0.0, _lib.ptr(out), c1 - c0))
+        kmat(Xd[c0:c1].contiguous(), out)
         idx = torch.arange(c0, c1, device=dev)
         out[idx, idx - c0] += jitter + noise
         return out
     chol.set_from_function(cols).factor()
-    nll = chol.nll(y)
     alpha = chol.solve(y).contiguous()
-    # mean = K(X*, X) alpha, test points sharded over the ranks
+    yv = torch.as_tensor(y, dtype=torch.float64).to(dev)
+    nll = 0.5 * float((yv * alpha).sum().item()) + 0.5 * chol.logdet() + 0.5 * N * math.log(2 * math.pi)
+    # test points sharded over the ranks, processed in chunks of K* columns
     Xt = torch.as_tensor(Xtest, dtype=torch.float64)
     M = Xt.shape[0]
     per = (M + world - 1) // world
     lo, hi = min(rank * per, M), min((rank + 1) * per, M)
-    part = torch.full((per,), float("nan"), dtype=torch.float64, device=dev)
-    step = max(1, (1 << 27) // max(N, 1))
-    for s0 in range(lo, hi, step):
-        s1 = min(hi, s0 + step)
-        Ks = torch.empty((N, s1 - s0), dtype=torch.float64, device=dev)
-        _lib.check(H.lib.gpimhip_kmat(H.h, ctypes.byref(m), _lib.ptr(Xd), N, _lib.ptr(Xt[s0:s1].to(dev).contiguous()),
-                                      s1 - s0, _lib.ptr(theta), 0.0, _lib.ptr(Ks), s1 - s0))
-        part[s0 - lo:s1 - lo] = Ks.T @ alpha
+    npd = chol.layout.np
+    step = max(1, min(per, int(chunk_bytes // (8 * npd))))
+    nchunk = (per + step - 1) // step                     # the same on every rank (collectives inside)
+    part = torch.full((2, per), float("nan"), dtype=torch.float64, device=dev)
+    for ci in range(nchunk):
+        s0, s1 = min(hi, lo + ci * step), min(hi, lo + (ci + 1) * step)
+        Ks = torch.zeros((npd, s1 - s0), dtype=torch.float64, device=dev)
+        if s1 > s0:
+            kmat(Xt[s0:s1].to(dev).contiguous(), Ks)
+            part[0, s0 - lo:s1 - lo] = Ks[:N].T @ alpha
+        if with_sd:
+            q = chol.solve_colsumsq(Ks)
+            part[1, s0 - lo:s1 - lo] = torch.sqrt(torch.clamp(variance - q, min=0.0) + noise)
     if world > 1:
         parts = [torch.empty_like(part) for _ in range(world)]
         dist.all_gather(parts, part, group=group)
-        mean = torch.cat(parts)[:M] if per * world == M else torch.cat(
-            [parts[r][:max(0, min(per, M - r * per))] for r in range(world)])
+        full = torch.cat([parts[r][:, :max(0, min(per, M - r * per))] for r in range(world)], dim=1)
     else:
-        mean = part[:M]
-    return mean.cpu().numpy(), nll
+        full = part[:, :M]
+    res = full.cpu().numpy()
+    return res[0], (res[1] if with_sd else None), nll
+
+
+def exact_gp_posterior_mean(X, y, Xtest, **kw):
+    """(mean, nll) only -- see exact_gp_posterior."""
+    mean, _, nll = exact_gp_posterior(X, y, Xtest, with_sd=False, **kw)
+    return mean, nll

@@ -158,6 +158,13 @@ def _chol_worker(rank, world, port, ret):
         ref_nll = 0.5 * float(y @ torch.cholesky_solve(y[:, None], Lref)[:, 0]) + 0.5 * torch.logdet(A).item() \
             + 0.5 * n * np.log(2 * np.pi)
         assert abs(ch.nll(y) - ref_nll) < 1e-9 * abs(ref_nll)
+        # variance quadratic form for rank-local right-hand sides (different widths per rank, incl. none)
+        m_loc = [7, 0, 3][rank]
+        Bm = torch.zeros((lay.np, m_loc), dtype=torch.float64)
+        Bm[:n] = torch.from_numpy(np.random.default_rng(100 + rank).standard_normal((n, m_loc)))
+        want = (torch.linalg.solve_triangular(Lref, Bm[:n].clone(), upper=False) ** 2).sum(0) if m_loc else torch.zeros(0)
+        got = ch.solve_colsumsq(Bm)
+        assert torch.allclose(got, want.to(torch.float64), rtol=1e-9, atol=1e-12)
     # a matrix that is not positive-definite is reported on every rank
     A = torch.eye(700, dtype=torch.float64)
     A[600, 600] = -1.0

@@ -51,21 +51,23 @@ def test_not_pd_raises(ensure_built):
 
 
 def test_exact_gp_posterior_mean_vs_oracle(ensure_built):
-    """Posterior mean and NLL of one exact GP through the distributed driver (P = 1) against the dense oracle."""
-    from gpim_amd.dist_chol import exact_gp_posterior_mean
+    """Posterior mean, sd and NLL of one exact GP through the distributed driver (P = 1) against the dense oracle."""
+    from gpim_amd.dist_chol import exact_gp_posterior
     rng = np.random.default_rng(2)
     pts = np.unique(rng.integers(0, 60, size=(4000, 2)), axis=0)
     pts = pts[rng.permutation(len(pts))[:1300]].astype(np.float64)
     y = np.sin(pts[:, 0] / 7.0) * np.cos(pts[:, 1] / 9.0) + 0.05 * rng.standard_normal(len(pts))
     Xs = rng.uniform(0, 59, size=(777, 2))
     ls, var, noise = [6.0, 8.0], 1.3, 0.02
-    mean, nll = exact_gp_posterior_mean(pts, y, Xs, kernel="Matern52", lengthscale=ls, variance=var, noise=noise)
+    mean, sd, nll = exact_gp_posterior(pts, y, Xs, kernel="Matern52", lengthscale=ls, variance=var, noise=noise,
+                                       chunk_bytes=300 * 8 * 1408)          # three chunks of test columns
     kp = O.KernelParams("Matern52", 2, [[0., 0.], [12., 16.]])
     with torch.no_grad():
         kp.u_var.copy_(torch.logit(torch.tensor((var - 1e-4) / (10 - 1e-4), dtype=torch.float64)))
         kp.u_ls.copy_(torch.zeros(2, dtype=torch.float64))          # sigmoid(0) = 1/2 -> ls = hi / 2
         kp.u_noise.copy_(torch.log(torch.tensor(noise, dtype=torch.float64)))
     gp = O.ExactGP(torch.from_numpy(pts), torch.from_numpy(y), kp, 1e-5)
-    mref, _ = gp.predict(torch.from_numpy(Xs))
+    mref, vref = gp.predict(torch.from_numpy(Xs))
     assert_allclose(mean, mref.numpy(), atol=1e-9)
+    assert_allclose(sd, vref.sqrt().numpy(), atol=1e-9)
     assert_allclose(nll, (gp.loss() - kp.neg_log_prior()).item(), rtol=1e-11)
