@@ -64,7 +64,11 @@ def gather_to_root(local, n_units, unit_shape, device=None, dtype=torch.float64)
     else:
         # one gather to rank 0 (RCCL ncclGather = grouped send/recv): only the root receives the slabs
         parts = [torch.empty_like(slab) for _ in range(ws)] if rank == 0 else None
-        dist.gather(slab, gather_list=parts, dst=0)
+        try:
+            dist.gather(slab, gather_list=parts, dst=0)
+        except (RuntimeError, NotImplementedError):      # a backend without gather: every rank takes every slab
+            parts = [torch.empty_like(slab) for _ in range(ws)]
+            dist.all_gather(parts, slab)
         if rank != 0:
             return None
     full = torch.empty((n_units,) + tuple(unit_shape), dtype=dtype, device=device)
