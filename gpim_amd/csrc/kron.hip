@@ -16,7 +16,10 @@
 //
 // Kernels (all HBM/latency-bound; the work is tiny next to the dense path's):
 //   kron_axis_kernel     K_i, E_i = K_i o ((c_a - c_b)/l_i)^2 (= l_i dK_i/dl_i), identity for the rotations
-//   kron_eigh_kernel     one-sided (Hestenes) Jacobi, one 16-wave workgroup per axis, round-robin ordering
+//   kron_reduce_kernel   axes with centro-symmetric coordinates (uniform grids): K_i splits into a symmetric and a
+//                        skew-symmetric eigen-problem of half the order
+//   kron_eigh_kernel     one-sided (Hestenes) Jacobi, one 16-wave workgroup per eigen-problem, round-robin ordering
+//   kron_assemble_kernel eigenvectors of K_i from the rotations of its eigen-problems
 //   kron_modeprod_kernel out[p,a,q] = sum_b M[a,b] in[p,b,q]   (tensor-times-matrix along one mode)
 //   kron_dvec_kernel     D, alpha~ = y~ / D, first reduction pass;  kron_quad_kernel second pass
 //   kron_finalize_kernel sums -> finalize_step;  kron_cross_kernel / kron_var_kernel for the posterior
@@ -41,8 +44,15 @@ struct KronDev {
     int64_t moff[KMAXD];     // offset of axis i's n_i x n_i matrices
     int64_t N;
     const double* coords;    // [sum n_i]
-    double *K, *E, *W, *Qt, *Mm, *Tt;   // [sum n_i^2] each
+    double *K, *E, *W, *Qt, *Mm, *Tt, *Vr;   // [sum n_i^2] each
     double *lam, *mdiag;     // [sum n_i]
+    // eigen-problems: one per axis, or two (symmetric / skew-symmetric half) when the axis' coordinates
+    // are centro-symmetric (any uniform grid): K_i then commutes with the exchange matrix and splits into
+    // two problems of half the size -- an eighth of the Jacobi work each, half the round-robin steps
+    int nprob;
+    int pax[2 * KMAXD], ppart[2 * KMAXD], pn[2 * KMAXD];   // axis, part (0 whole, 1 symmetric, 2 skew), order
+    int64_t poff[2 * KMAXD];                                // offset inside the axis' n_i^2 region (W, Vr, Tt)
+    int plam[2 * KMAXD];                                    // offset of its eigenvalues / Qt rows inside the axis
 };
 
 struct KronWs {
@@ -86,7 +96,7 @@ static int kron_ensure(gpimhip_ctx* h, int d, const int32_t* n, KronWs** out) {
     for (int i = 0; i < KMAXD; ++i) w.n[i] = i < d ? n[i] : 1;
     for (int i = 0; i < d; ++i) { w.N *= n[i]; w.sum_n += n[i]; w.sum_n2 += (int64_t)n[i] * n[i]; }
     w.nblk = (int)std::min<int64_t>(1024, (w.N + 255) / 256);
-    const int64_t count = 3 * w.sum_n + 6 * w.sum_n2 + (4 + d) * w.N + (int64_t)w.nblk * 16 + 64;
+    const int64_t count = 3 * w.sum_n + 7 * w.sum_n2 + (4 + d) * w.N + (int64_t)w.nblk * 16 + 64;
     void* q = nullptr;
     if (hipMalloc(&q, (size_t)count * sizeof(double)) != hipSuccess) {
         gpim_set_error("hipMalloc failed (structured-GP workspace)");
@@ -107,7 +117,7 @@ static int kron_ensure(gpimhip_ctx* h, int d, const int32_t* n, KronWs** out) {
     }
     dv.coords = take(w.sum_n); dv.lam = take(w.sum_n); dv.mdiag = take(w.sum_n);
     dv.K = take(w.sum_n2); dv.E = take(w.sum_n2); dv.W = take(w.sum_n2);
-    dv.Qt = take(w.sum_n2); dv.Mm = take(w.sum_n2); dv.Tt = take(w.sum_n2);
+    dv.Qt = take(w.sum_n2); dv.Mm = take(w.sum_n2); dv.Tt = take(w.sum_n2); dv.Vr = take(w.sum_n2);
     w.yt = take(w.N); w.at = take(w.N); w.t1 = take(w.N); w.t2 = take(w.N);
     w.Z = take((int64_t)d * w.N);
     w.part = take((int64_t)w.nblk * 16);
@@ -133,13 +143,51 @@ __global__ void kron_axis_kernel(KronDev dv, const ThetaDev* __restrict__ th) {
     dv.E[o] = k * r2;
 }
 
-// Qt <- I for every axis (cold start of the rotations)
+// Vr <- I for every eigen-problem (cold start of the rotations)
 __global__ void kron_eye_kernel(KronDev dv) {
-    const int ax = blockIdx.y;
-    const int n = dv.n[ax];
+    const int pr = blockIdx.y;
+    const int n = dv.pn[pr];
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (int64_t)n * n) return;
-    dv.Qt[dv.moff[ax] + e] = (e / n == e % n) ? 1.0 : 0.0;
+    dv.Vr[dv.moff[dv.pax[pr]] + dv.poff[pr] + e] = (e / n == e % n) ? 1.0 : 0.0;
+}
+
+// The matrix of each eigen-problem (into Tt): K_i itself, or its restriction to the symmetric / skew-symmetric
+// vectors.  With n = 2m (+1), basis (e_a +- e_{n-1-a}) / sqrt2 (and e_m):
+//   symmetric  S[a][b] = K[a][b] + K[a][n-1-b],  S[a][m] = S[m][a] = sqrt2 K[a][m],  S[m][m] = K[m][m]
+//   skew       D[a][b] = K[a][b] - K[a][n-1-b]
+__global__ void kron_reduce_kernel(KronDev dv) {
+    const int pr = blockIdx.y;
+    const int ax = dv.pax[pr], part = dv.ppart[pr], np_ = dv.pn[pr], n = dv.n[ax], m = n / 2;
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (int64_t)np_ * np_) return;
+    const int a = (int)(e / np_), b = (int)(e % np_);
+    const double* K = dv.K + dv.moff[ax];
+    double v;
+    if (part == 0) v = K[(int64_t)a * n + b];
+    else if (part == 2) v = K[(int64_t)a * n + b] - K[(int64_t)a * n + (n - 1 - b)];
+    else if (a < m && b < m) v = K[(int64_t)a * n + b] + K[(int64_t)a * n + (n - 1 - b)];
+    else if (a == m && b == m) v = K[(int64_t)m * n + m];
+    else v = 1.4142135623730951 * K[(int64_t)(a < m ? a : b) * n + m];
+    dv.Tt[dv.moff[ax] + dv.poff[pr] + e] = v;
+}
+
+// Qt rows (eigenvectors of K_i, length n) from the rotations of the eigen-problems
+__global__ void kron_assemble_kernel(KronDev dv) {
+    const int pr = blockIdx.y;
+    const int ax = dv.pax[pr], part = dv.ppart[pr], np_ = dv.pn[pr], n = dv.n[ax], m = n / 2;
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (int64_t)np_ * n) return;
+    const int j = (int)(e / n), a = (int)(e % n);
+    const double* V = dv.Vr + dv.moff[ax] + dv.poff[pr] + (int64_t)j * np_;
+    double v;
+    if (part == 0) v = V[a];
+    else {
+        const int lo = a < m ? a : n - 1 - a;            // mirrored index; a == m only when n is odd
+        if ((n & 1) && a == m) v = (part == 1) ? V[m] : 0.0;
+        else v = 0.7071067811865476 * V[lo] * ((part == 2 && a >= n - m) ? -1.0 : 1.0);
+    }
+    dv.Qt[dv.moff[ax] + (int64_t)(dv.plam[pr] + j) * n + a] = v;
 }
 
 __device__ __forceinline__ double kwave_sum(double v) {
@@ -293,10 +341,11 @@ __device__ __forceinline__ double jacobi_step_stream(double* W, double* V, int n
 template <int NPL, int G>
 __global__ __launch_bounds__(EIGH_WAVES * 64) void kron_eigh_kernel(KronDev dv) {
     __shared__ double s_max[EIGH_WAVES];
-    const int ax = blockIdx.x;
-    const int n = dv.n[ax];
-    double* W = dv.W + dv.moff[ax];
-    double* V = dv.Qt + dv.moff[ax];
+    const int pr = blockIdx.x;
+    const int ax = dv.pax[pr];
+    const int n = dv.pn[pr];
+    double* W = dv.W + dv.moff[ax] + dv.poff[pr];
+    double* V = dv.Vr + dv.moff[ax] + dv.poff[pr];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n2 = n + (n & 1), half = n2 / 2, ring = n2 - 1;
     // lmax: the largest absolute row sum of K (Gershgorin: an upper bound of the largest eigenvalue, tight
@@ -315,7 +364,7 @@ __global__ __launch_bounds__(EIGH_WAVES * 64) void kron_eigh_kernel(KronDev dv) 
     for (int w = 0; w < EIGH_WAVES; ++w) lmax = fmax(lmax, s_max[w]);
     // Sweeps until the largest rotation of a sweep is below 1e-8: the method converges quadratically, so
     // what is left after such a sweep is at rounding level (no rotation-free sweep needed to confirm).  The
-    // rotations continue from the V the caller left in Qt -- the identity, or the eigenvectors of the
+    // rotations continue from the V the caller left in Vr -- the identity, or the eigenvectors of the
     // previous Adam iteration, whose K differs by a small change of the lengthscale: W = V K then starts
     // almost orthogonal and two or three sweeps are enough instead of 8 ... 18.
     int nsweep = 0;
@@ -339,9 +388,9 @@ __global__ __launch_bounds__(EIGH_WAVES * 64) void kron_eigh_kernel(KronDev dv) 
         if (all < 1e-8) break;
     }
 #ifdef KRON_DEBUG
-    if (tid == 0) printf("eigh axis %d n %d: %d sweeps, lmax %.3f\n", ax, n, nsweep, lmax);
+    if (tid == 0) printf("eigh axis %d part %d n %d: %d sweeps, lmax %.3f\n", ax, dv.ppart[pr], n, nsweep, lmax);
 #endif
-    double* lam = dv.lam + dv.off[ax];
+    double* lam = dv.lam + dv.off[ax] + dv.plam[pr];
     for (int j = wave; j < n; j += EIGH_WAVES) {
         double s = 0.0;
         for (int e = lane; e < n; e += 64) s = fma(W[(int64_t)j * n + e], V[(int64_t)j * n + e], s);
@@ -560,28 +609,68 @@ __global__ void kron_post_kernel(const double* mean_raw, const double* __restric
 // ------------------------------------------------------------------------------------------
 static int kron_cold_start(gpimhip_ctx* h, KronWs& w) {
     int nmax = 1;
-    for (int i = 0; i < w.d; ++i) nmax = std::max(nmax, w.n[i]);
-    hipLaunchKernelGGL(kron_eye_kernel, dim3((unsigned)(((int64_t)nmax * nmax + 255) / 256), w.d), dim3(256), 0, h->stream,
-                       w.dev);
+    for (int pr = 0; pr < w.dev.nprob; ++pr) nmax = std::max(nmax, w.dev.pn[pr]);
+    hipLaunchKernelGGL(kron_eye_kernel, dim3((unsigned)(((int64_t)nmax * nmax + 255) / 256), w.dev.nprob), dim3(256), 0,
+                       h->stream, w.dev);
     HIP_TRY(hipGetLastError());
     return GPIMHIP_OK;
 }
 
-// K_i(u), its eigen-decomposition continued from the rotations in Qt (kron_cold_start() resets them), y~
+// Splits every axis whose coordinates are centro-symmetric (c_a + c_{n-1-a} constant: any uniform grid) into a
+// symmetric and a skew-symmetric eigen-problem.  Needs the coordinates on the host: one small copy + sync per call.
+static int kron_plan_problems(gpimhip_ctx* h, KronWs& w) {
+    std::vector<double> c((size_t)w.sum_n);
+    HIP_TRY(hipMemcpyAsync(c.data(), w.dev.coords, c.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    KronDev& dv = w.dev;
+    dv.nprob = 0;
+    const bool allow = !getenv("GPIMHIP_KRON_NO_SPLIT");
+    for (int i = 0; i < w.d; ++i) {
+        const int n = w.n[i];
+        const double* ci = c.data() + dv.off[i];
+        bool sym = allow && n >= 8;
+        double scale = 1.0;
+        for (int a = 0; a < n; ++a) scale = std::max(scale, fabs(ci[a]));
+        for (int a = 0; a < n && sym; ++a)
+            sym = fabs((ci[a] + ci[n - 1 - a]) - (ci[0] + ci[n - 1])) <= 1e-12 * scale;
+        auto add = [&](int part, int order, int64_t off, int lam0) {
+            const int pr = dv.nprob++;
+            dv.pax[pr] = i; dv.ppart[pr] = part; dv.pn[pr] = order; dv.poff[pr] = off; dv.plam[pr] = lam0;
+        };
+        if (sym) {
+            const int ns = (n + 1) / 2, nd = n / 2;
+            add(1, ns, 0, 0);
+            add(2, nd, (int64_t)ns * ns, ns);
+        } else {
+            add(0, n, 0, 0);
+        }
+    }
+    return GPIMHIP_OK;
+}
+
+// K_i(u), its eigen-decomposition continued from the rotations in Vr (kron_cold_start() resets them), y~
 static int kron_decompose(gpimhip_ctx* h, KronWs& w, const gpimhip_model_t* m, const double* u, const double* y) {
     const KronDev& dv = w.dev;
     GP_TRY(launch_theta(h, m, u));
-    int nmax = 1;
+    int nmax = 1, pmax = 1;
     for (int i = 0; i < w.d; ++i) nmax = std::max(nmax, w.n[i]);
+    for (int pr = 0; pr < dv.nprob; ++pr) pmax = std::max(pmax, dv.pn[pr]);
     hipLaunchKernelGGL(kron_axis_kernel, dim3((unsigned)(((int64_t)nmax * nmax + 255) / 256), w.d), dim3(256), 0, h->stream,
                        dv, h->theta);
-    for (int i = 0; i < w.d; ++i)      // W_i = V_i K_i
-        GP_TRY(modeprod(h, dv.K + dv.moff[i], dv.W + dv.moff[i], dv.Qt + dv.moff[i], w.n[i], w.n[i], w.n[i], 0, 0, 1, w.n[i]));
-    if (nmax <= 64) hipLaunchKernelGGL((kron_eigh_kernel<1, 4>), dim3(w.d), dim3(EIGH_WAVES * 64), 0, h->stream, dv);
-    else if (nmax <= 128) hipLaunchKernelGGL((kron_eigh_kernel<2, 4>), dim3(w.d), dim3(EIGH_WAVES * 64), 0, h->stream, dv);
-    else if (nmax <= 256) hipLaunchKernelGGL((kron_eigh_kernel<4, 2>), dim3(w.d), dim3(EIGH_WAVES * 64), 0, h->stream, dv);
-    else if (nmax <= 512) hipLaunchKernelGGL((kron_eigh_kernel<8, 1>), dim3(w.d), dim3(EIGH_WAVES * 64), 0, h->stream, dv);
-    else hipLaunchKernelGGL((kron_eigh_kernel<0, 1>), dim3(w.d), dim3(EIGH_WAVES * 64), 0, h->stream, dv);
+    hipLaunchKernelGGL(kron_reduce_kernel, dim3((unsigned)(((int64_t)pmax * pmax + 255) / 256), dv.nprob), dim3(256), 0,
+                       h->stream, dv);
+    for (int pr = 0; pr < dv.nprob; ++pr) {      // W = V * (matrix of the problem)
+        const int64_t o = dv.moff[dv.pax[pr]] + dv.poff[pr];
+        const int np_ = dv.pn[pr];
+        GP_TRY(modeprod(h, dv.Tt + o, dv.W + o, dv.Vr + o, np_, np_, np_, 0, 0, 1, np_));
+    }
+    if (pmax <= 64) hipLaunchKernelGGL((kron_eigh_kernel<1, 4>), dim3(dv.nprob), dim3(EIGH_WAVES * 64), 0, h->stream, dv);
+    else if (pmax <= 128) hipLaunchKernelGGL((kron_eigh_kernel<2, 4>), dim3(dv.nprob), dim3(EIGH_WAVES * 64), 0, h->stream, dv);
+    else if (pmax <= 256) hipLaunchKernelGGL((kron_eigh_kernel<4, 2>), dim3(dv.nprob), dim3(EIGH_WAVES * 64), 0, h->stream, dv);
+    else if (pmax <= 512) hipLaunchKernelGGL((kron_eigh_kernel<8, 1>), dim3(dv.nprob), dim3(EIGH_WAVES * 64), 0, h->stream, dv);
+    else hipLaunchKernelGGL((kron_eigh_kernel<0, 1>), dim3(dv.nprob), dim3(EIGH_WAVES * 64), 0, h->stream, dv);
+    hipLaunchKernelGGL(kron_assemble_kernel, dim3((unsigned)(((int64_t)pmax * nmax + 255) / 256), dv.nprob), dim3(256), 0,
+                       h->stream, dv);
     HIP_TRY(hipGetLastError());
     // y~ = (Q_1^T (x) ... (x) Q_d^T) y
     const double* mats[KMAXD]; int ld[KMAXD];
@@ -638,6 +727,7 @@ static int kron_prepare(gpimhip_ctx* h, const gpimhip_model_t* m, int32_t d, con
     HIP_TRY(hipMemcpyAsync(const_cast<double*>((*w)->dev.coords), axes, (size_t)(*w)->sum_n * sizeof(double),
                            hipMemcpyDeviceToDevice, h->stream));
     HIP_TRY(hipMemsetAsync(h->info, 0, sizeof(int32_t), h->stream));
+    GP_TRY(kron_plan_problems(h, **w));
     return kron_cold_start(h, **w);
 }
 
