@@ -28,6 +28,7 @@
 #include <algorithm>
 #include "kfun.hpp"
 #include "theta.hpp"
+#include "blocklds.hpp"      // wave_sum: DPP / readlane reduction (no LDS crossbar round trips)
 
 hipStream_t ensure_capture_stream(gpimhip_ctx* h);
 int ws_ensure(gpimhip_ctx* h, int64_t N);
@@ -190,11 +191,7 @@ __global__ void kron_assemble_kernel(KronDev dv) {
     dv.Qt[dv.moff[ax] + (int64_t)(dv.plam[pr] + j) * n + a] = v;
 }
 
-__device__ __forceinline__ double kwave_sum(double v) {
-    v += __shfl_xor(v, 32); v += __shfl_xor(v, 16); v += __shfl_xor(v, 8);
-    v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
-    return v;
-}
+__device__ __forceinline__ double kwave_sum(double v) { return wave_sum(v); }
 
 // One-sided Jacobi on the rows of the symmetric positive semi-definite W (= its columns): plane rotations
 // make the rows mutually orthogonal, W = V K; for symmetric K the accumulated V holds the eigenvectors
