@@ -310,6 +310,15 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_tiles_kernel(GemmArgs g) {
     }
 }
 
+// Launches of a few tiles per CU with very different k-ranges (mid-size N): the launch lasts as long as its
+// longest tile, which in the 4-wave shape shares its CU -- and the CU's MFMA rate -- with a second workgroup.
+// Up to this many tiles the 8-wave shape is launched with 24 KB of unused dynamic LDS on top of its 74 KB of
+// staging buffers, so that every tile has a CU to itself (K^-1 product at N = 4206: 0.71 -> 0.56 ms).
+static int mid_tiles() {
+    static const int v = getenv("GPIMHIP_MID_TILES") ? atoi(getenv("GPIMHIP_MID_TILES")) : 2048;
+    return v;
+}
+
 template <bool A_KM, bool B_KM, int EPI>
 static int launch_one(gpimhip_ctx* h, const GemmArgs& g) {
     if (g.ntiles <= 0) return GPIMHIP_OK;
@@ -323,6 +332,11 @@ static int launch_one(gpimhip_ctx* h, const GemmArgs& g) {
         // in-place panel solve: row halves (the workgroup owns the rows it overwrites), 8 waves
         hipLaunchKernelGGL((gemm_tiles_kernel<A_KM, B_KM, EPI_STORE, 8, 64, 128>), dim3(g.ntiles * 2, h->nbatch),
                            dim3(512), 0, h->stream, g);
+    else if (EPI == EPI_STORE && total > 256 && total <= mid_tiles())
+        // one tile per CU (see mid_tiles()).  Not for the column-sum epilogue: its cross-wave summation order
+        // follows the wave layout, and batched and stand-alone predictions must stay bit-identical.
+        hipLaunchKernelGGL((gemm_tiles_kernel<A_KM, B_KM, EPI, 8, 128, 128>), dim3(g.ntiles, h->nbatch), dim3(512),
+                           24 * 1024, h->stream, g);
     else if (total <= 256 || (!A_KM && !B_KM && !getenv("GPIMHIP_NT_4WAVE")) || getenv("GPIMHIP_ALL_8WAVE"))
         // (also every SYRK-shaped update of the Cholesky: measured 8 % faster factorisation at N = 16384,
         // the 512-thread workgroups interleave better with the concurrent panel chain)

@@ -1,6 +1,3 @@
-cd /tmp; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/kt_c3 -- python $R/tests/tools/bench_c3.py > /tmp/c3.log 2>&1
-tail -2 /tmp/c3.log
-f=$(ls -t $R/gpurun_out/kt_c3/*/*kernel_stats.csv | head -1)
-head -16 $f | cut -c1-150
+for v in 0 700 1500 3000; do export GPIMHIP_MID_TILES=$v; echo "== mid $v"
+for n in 2048 4206 6000; do PROF_STAGES=1 python $R/tests/tools/prof_fit.py $n 20 0 RBF 2>&1 | grep -E "stage" | tr '\n' ' '; echo; done; done
