@@ -80,6 +80,9 @@ _PROTOS = {
                                                  ctypes.c_int32, c_dp, c_dp]),
     "gpimhip_dist_trailing_update": (ctypes.c_int, [ctypes.c_void_p, c_dp, ctypes.c_int64, ctypes.c_int32, c_dp,
                                                     ctypes.c_int64, ctypes.c_int32, ctypes.c_int32]),
+    "gpimhip_acquire_exact": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ModelStruct), c_dp, c_dp, ctypes.c_int64,
+                                             c_dp, c_dp, ctypes.c_int64, c_dp, ctypes.c_int64, ctypes.c_int32,
+                                             ctypes.c_double, ctypes.c_double, c_dp, c_dp, c_dp, c_dp]),
     "gpimhip_thin_batch": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_dp, ctypes.c_int32, ctypes.c_int32, c_dp,
                                           ctypes.c_double, ctypes.c_int32, c_dp, c_dp]),
 }

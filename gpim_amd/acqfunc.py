@@ -61,27 +61,48 @@ def _nanmax(handle, *tensors):
 
 
 # ------------------------------------------------------------------ device-resident path (boptimizer)
-def acquisition_on_device(gpmodel, kind, X_full, X_sparse, p0=0.0, p1=1.0, xi=0.01, Xf_d=None):
+def acquisition_on_device(gpmodel, kind, X_full, X_sparse, p0=0.0, p1=1.0, xi=0.01, Xf_d=None, mask_d=None,
+                          Xobs_d=None):
     """The three built-in acquisition functions for a ``gpim_amd.reconstructor`` surrogate WITHOUT leaving
-    the GPU: returns device tensors (acq, mean, sd) over the flattened grid.  Same arithmetic as the public
-    functions below.  The incumbent of EI / POI -- nanmax of the posterior at the observed points, which the
-    reference obtains from a second predict over the whole NaN-masked grid (acqfunc.py:58-59,86-88) -- is
-    predicted at the observed rows only: every column of a prediction is independent of the others, so the
-    values (and their nanmax) are the same and the N^2 M triangular product shrinks to N^2 N_obs."""
+    the GPU: returns device tensors (acq, mean, sd) over the flattened grid (acq already multiplied by
+    ``mask_d`` when one is given).  Same arithmetic as the public functions below.  The incumbent of EI / POI --
+    nanmax of the posterior at the observed points, which the reference obtains from a second predict over the
+    whole NaN-masked grid (acqfunc.py:58-59,86-88) -- is predicted at the observed rows only: every column of a
+    prediction is independent of the others, so the values (and their nanmax) are the same and the N^2 M
+    triangular product shrinks to N^2 N_obs.  Exact models go through ONE library call (gpimhip_acquire_exact:
+    one factorisation, incumbent kept on the device, fused posterior + acquisition launch for N <= 384).
+    ``Xobs_d``: the observed rows of ``X_sparse`` when the caller already holds them on the device (boptimizer:
+    they are the surrogate's training inputs)."""
     handle = gpmodel._handle
     Xf = Xf_d if Xf_d is not None else gpmodel._to_device(_rows(X_full, gpmodel.precision))
+    Xobs = Xobs_d
+    if kind != "cb" and Xobs is None:
+        Xs = _rows(X_sparse, gpmodel.precision)
+        obs = ~torch.isnan(Xs).any(dim=1)
+        Xobs = gpmodel._to_device(Xs[obs].contiguous())
+    if not gpmodel.do_sparse and not gpmodel.do_structured:
+        gpmodel._check_data()
+        M = Xf.shape[0]
+        mean_d = torch.empty((M,), dtype=_F64, device=Xf.device)
+        sd_d = torch.empty_like(mean_d)
+        out = torch.empty_like(mean_d)
+        a, b = (p0, p1) if kind == "cb" else (0.0, xi)
+        _lib.check(handle.lib.gpimhip_acquire_exact(
+            handle.h, ctypes.byref(gpmodel._mstruct), _lib.ptr(gpmodel._Xd), _lib.ptr(gpmodel._yd), gpmodel._Xd.shape[0],
+            _lib.ptr(gpmodel._u), _lib.ptr(Xf), M, None if Xobs is None else _lib.ptr(Xobs),
+            0 if Xobs is None else Xobs.shape[0], _lib.ACQ_IDS[kind], float(a), float(b),
+            None if mask_d is None else _lib.ptr(mask_d), _lib.ptr(mean_d), _lib.ptr(sd_d), _lib.ptr(out)))
+        return out, mean_d, sd_d
     mean_d, sd_d = gpmodel._predict_device(Xf)
     if kind == "cb":
         a, b = p0, p1
     else:
-        Xs = _rows(X_sparse, gpmodel.precision)
-        obs = ~torch.isnan(Xs).any(dim=1)
-        mo, so = gpmodel._predict_device(gpmodel._to_device(Xs[obs].contiguous()))
+        mo, so = gpmodel._predict_device(Xobs)
         a = _nanmax(handle, mo) if kind == "ei" else _nanmax(handle, mo, so)
         b = xi
     out = torch.empty_like(mean_d)
     _lib.check(handle.lib.gpimhip_acq(handle.h, _lib.ACQ_IDS[kind], _lib.ptr(mean_d), _lib.ptr(sd_d), mean_d.numel(),
-                                      float(a), float(b), None, _lib.ptr(out)))
+                                      float(a), float(b), None if mask_d is None else _lib.ptr(mask_d), _lib.ptr(out)))
     return out, mean_d, sd_d
 
 

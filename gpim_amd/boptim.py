@@ -10,6 +10,7 @@ revisit / distance-memory filter, batch thinning and bookkeeping are small host 
 reference.  Ties in the ranking are resolved "larger flat index first" (the reference inherits
 numpy's unspecified introsort order).
 """
+import ctypes
 import types
 
 import numpy as np
@@ -84,6 +85,7 @@ class boptimizer:
             learning_rate, gp_iterations, self.use_gpu, self.verbose, seed,
             isotropic=isotropic, precision=self.precision, jitter=jitter)
         self.X_sparse = X_seed.copy()
+        self.surrogate_model._trained_on = self.X_sparse        # same content as X_seed (see _observed_rows_d)
         self.y_sparse = y_seed.copy()
         self.X_full = X_full
         self.target_function = target_function
@@ -123,6 +125,7 @@ class boptimizer:
         self.surrogate_model.model.X = X_new
         self.surrogate_model.model.y = y_new
         self.surrogate_model.train(verbose=self.verbose)
+        self.surrogate_model._trained_on = self.X_sparse
 
     def evaluate_function(self, indices, y_measured=None):
         """Evaluate the target at the new point(s) and refresh the sparse grid (boptim.py:253-276)."""
@@ -168,24 +171,43 @@ class boptimizer:
         self._maps_used += 1
         return slab[slot, 0], slab[slot, 1]
 
-    def _rank_device(self, acq_d, grid_shape):
-        """Top-``batch_size`` of a device-resident acquisition map (flattened); returns host lists."""
+    def _observed_rows_d(self):
+        """Device rows of the observed points of ``X_sparse``: the surrogate's training inputs whenever it was last
+        fitted to this very grid (update_posterior / the constructor do that); None otherwise."""
+        sm = self.surrogate_model
+        Xd = getattr(sm, "_Xd", None)
+        if Xd is None or sm.do_sparse or sm.do_structured or getattr(sm, "_trained_on", None) is not self.X_sparse:
+            return None
+        return Xd
+
+    def _device_mask(self, n):
+        if self.mask is None:
+            return None
+        if self._mask_d is None or self._mask_d.numel() != n:
+            dev = self.surrogate_model._handle.device
+            self._mask_d = torch.as_tensor(np.ascontiguousarray(self.mask), dtype=_F64).reshape(-1).to(dev)
+        return self._mask_d
+
+    def _rank_device(self, acq_d, grid_shape, masked=False):
+        """Top-``batch_size`` of a device-resident acquisition map (flattened); returns host lists.
+        masked: the map has been multiplied by the mask already."""
         handle = self.surrogate_model._handle
         keep_nan = 1
         if self.mask is not None:
-            if self._mask_d is None or self._mask_d.numel() != acq_d.numel():
-                self._mask_d = torch.as_tensor(np.ascontiguousarray(self.mask), dtype=_F64).reshape(-1).to(handle.device)
-            acq_d = self._mask_d * acq_d
+            if not masked:
+                acq_d = self._device_mask(acq_d.numel()) * acq_d
             keep_nan = 0
         k = int(min(self.batch_size, acq_d.numel()))
-        vals = torch.empty((k,), dtype=_F64, device=handle.device)
-        idx = torch.empty((k,), dtype=torch.int64, device=handle.device)
-        cnt = torch.zeros((1,), dtype=torch.int64, device=handle.device)
+        # one buffer, one device-to-host copy: [count | k indices | k values (as bits)]
+        buf = torch.zeros((2 * k + 1,), dtype=torch.int64, device=handle.device)
+        base = buf.data_ptr()
         _lib.check(handle.lib.gpimhip_topk(handle.h, _lib.ptr(acq_d.contiguous()), acq_d.numel(), k, keep_nan,
-                                           _lib.ptr(vals), _lib.ptr(idx), _lib.ptr(cnt)))
-        n = int(cnt.item())
-        flat = idx[:n].cpu().numpy()
-        vals_list = vals[:n].cpu().numpy().tolist()
+                                           ctypes.c_void_p(base + 8 * (k + 1)), ctypes.c_void_p(base + 8),
+                                           ctypes.c_void_p(base)))
+        host = buf.cpu().numpy()
+        n = int(host[0])
+        flat = host[1:1 + n]
+        vals_list = host[k + 1:k + 1 + n].view(np.float64).tolist()
         indices_list = np.stack(np.unravel_index(flat, tuple(grid_shape)), axis=-1).tolist()
         return vals_list, indices_list
 
@@ -211,11 +233,13 @@ class boptimizer:
             if self._Xfull_d is None:
                 self._Xfull_d = sm._to_device(gprutils.prepare_test_data(np.asarray(self.X_full), precision=self.precision))
             acq_d, mean_d, sd_d = acqfunc.acquisition_on_device(sm, af, self.X_full, self.X_sparse, p0, p1, self.xi,
-                                                                Xf_d=self._Xfull_d)
+                                                                Xf_d=self._Xfull_d,
+                                                                mask_d=self._device_mask(self._Xfull_d.shape[0]),
+                                                                Xobs_d=self._observed_rows_d())
             grid_shape = tuple(np.shape(self.X_full)[1:])
             mean_d, sd_d = self._retain_maps(mean_d, sd_d)
             self.gp_predictions.append(_LazyMaps._Pending(mean_d, sd_d, grid_shape, sm._np_out))
-            vals_list, indices_list = self._rank_device(acq_d, grid_shape)
+            vals_list, indices_list = self._rank_device(acq_d, grid_shape, masked=True)
         elif isinstance(af, types.FunctionType):
             acq, pred = af(sm, self.X_full, self.X_sparse)
             sm._last_acq = None

@@ -708,6 +708,7 @@ int gpimhip_destroy(gpimhip_handle h) {
     ws_release_predict(h);
     dev_free(h, &h->keys, h->keys_cap);
     if (h->sel_scratch) dev_free(h, &h->sel_scratch, (int64_t)sel_scratch_bytes());
+    dev_free(h, &h->acq_tmp, h->acq_tmp_cap);
     dev_free(h, &h->bc, h->bc_cap);
     dev_free(h, &h->theta1, 1);
     dev_free(h, &h->info, 4);
@@ -852,17 +853,16 @@ static int fit_impl(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X, i
     return finish_and_check(h);
 }
 
-static int predict_impl(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X, int64_t x_bs, const double* y,
-                        int64_t N, int B, const double* u, const double* Xs, int64_t M, double* mean_out,
-                        double* var_out) {
-    HIP_TRY(hipSetDevice(h->device));
-    h->nbatch = B;
-    GP_TRY(ws_ensure_padded(h, N));
+
+// posterior mean / variance at M test points from the factorised model in the workspace (theta, L^-1, alpha)
+static int predict_cols(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X, int64_t x_bs, int64_t N, int B,
+                        const double* Xs, int64_t M, double* mean_out, double* var_out) {
     const int64_t np = h->np;
     const int nb = (int)(np / NB);
-    HIP_TRY(hipMemsetAsync(h->info, 0, sizeof(int32_t), h->stream));
-    GP_TRY(launch_pad_copy(h, y, N, h->ypad, np));
-    GP_TRY(factor_at_u(h, m, X, x_bs, N, u));
+    // few observations: one fused launch, K* stays in LDS (predict.hip)
+    if (fused_predict_fits(np))
+        return launch_predict_fused(h, m, X, x_bs, N, Xs, M, mean_out, var_out, nullptr, nullptr, -1, 0.0, nullptr, 0.0,
+                                    nullptr);
     // chunk the test points so that the K* slabs of all problems together stay <= ~1 GiB
     int64_t mc = pad_to(M, NB);
     const int64_t cap = std::max<int64_t>(NB, ((int64_t)1 << 27) / np / B / NB * NB);
@@ -888,6 +888,20 @@ static int predict_impl(gpimhip_ctx* h, const gpimhip_model_t* m, const double* 
         { StageTimer t(h, 3); GP_TRY(launch_gemm(h, false, true, EPI_COLSUMSQ, g)); }
         GP_TRY(launch_predict_var(h, mcap, nb, m0, cnt, var_out, M));
     }
+    return GPIMHIP_OK;
+}
+
+static int predict_impl(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X, int64_t x_bs, const double* y,
+                        int64_t N, int B, const double* u, const double* Xs, int64_t M, double* mean_out,
+                        double* var_out) {
+    HIP_TRY(hipSetDevice(h->device));
+    h->nbatch = B;
+    GP_TRY(ws_ensure_padded(h, N));
+    const int64_t np = h->np;
+    HIP_TRY(hipMemsetAsync(h->info, 0, sizeof(int32_t), h->stream));
+    GP_TRY(launch_pad_copy(h, y, N, h->ypad, np));
+    GP_TRY(factor_at_u(h, m, X, x_bs, N, u));
+    GP_TRY(predict_cols(h, m, X, x_bs, N, B, Xs, M, mean_out, var_out));
     return finish_and_check(h);
 }
 
@@ -949,6 +963,59 @@ int gpimhip_acq(gpimhip_handle h, int32_t kind, const double* mean, const double
     if (!h || !mean || !sd || !acq_out || M < 1 || kind < 0 || kind > GPIMHIP_ACQ_POI) return GPIMHIP_E_BADARG;
     HIP_TRY(hipSetDevice(h->device));
     return launch_acq(h, kind, mean, sd, M, p0, p1, mask, acq_out);
+}
+
+static int sel_scratch_ensure(gpimhip_ctx* h);
+
+int gpimhip_acquire_exact(gpimhip_handle h, const gpimhip_model_t* m, const double* X, const double* y, int64_t N,
+                          const double* u, const double* Xs, int64_t M, const double* Xobs, int64_t Mobs, int32_t kind,
+                          double p0, double p1, const double* mask, double* mean_out, double* sd_out, double* acq_out) {
+    if (!h || !X || !y || !u || !Xs || M < 1 || N < 1 || !mean_out || !sd_out || !acq_out || kind < 0 ||
+        kind > GPIMHIP_ACQ_POI || (kind != GPIMHIP_ACQ_CB && (!Xobs || Mobs < 1)))
+        return GPIMHIP_E_BADARG;
+    GP_TRY(check_model(m));
+    HIP_TRY(hipSetDevice(h->device));
+    h->nbatch = 1;
+    GP_TRY(ws_ensure_padded(h, N));
+    const int64_t np = h->np;
+    HIP_TRY(hipMemsetAsync(h->info, 0, sizeof(int32_t), h->stream));
+    GP_TRY(launch_pad_copy(h, y, N, h->ypad, np));
+    GP_TRY(factor_at_u(h, m, X, 0, N, u));
+    const bool fused = fused_predict_fits(np);
+    const double* inc = nullptr;
+    if (kind != GPIMHIP_ACQ_CB) {
+        // incumbent = nanmax of the posterior at the observed rows (EI: means; POI: means and sds), on device
+        if (h->acq_tmp_cap < 2 * Mobs + 2) {
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            dev_free(h, &h->acq_tmp, h->acq_tmp_cap);
+            h->acq_tmp_cap = 0;
+            GP_TRY(dev_alloc(h, &h->acq_tmp, 2 * Mobs + 2));
+            h->acq_tmp_cap = 2 * Mobs + 2;
+        }
+        double *mo = h->acq_tmp, *so = h->acq_tmp + Mobs, *best = h->acq_tmp + 2 * Mobs;
+        if (fused) {
+            GP_TRY(launch_predict_fused(h, m, X, 0, N, Xobs, Mobs, mo, nullptr, so, nullptr, -1, 0.0, nullptr, 0.0, nullptr));
+        } else {
+            GP_TRY(predict_cols(h, m, X, 0, N, 1, Xobs, Mobs, mo, so));
+            GP_TRY(launch_acq_from_var(h, kind, mo, so, Mobs, 0.0, nullptr, 0.0, nullptr, so, nullptr));
+        }
+        const int64_t nmax = (kind == GPIMHIP_ACQ_EI) ? Mobs : 2 * Mobs;
+        if (nmax <= 4096) {
+            GP_TRY(launch_nanmax(h, mo, nmax, best));
+        } else {
+            GP_TRY(sel_scratch_ensure(h));
+            GP_TRY(launch_nanmax_two_stage(h, mo, nmax, best));
+        }
+        inc = best;
+    }
+    if (fused) {
+        GP_TRY(launch_predict_fused(h, m, X, 0, N, Xs, M, mean_out, nullptr, sd_out, acq_out, kind, p0, inc, p1, mask));
+    } else {
+        // sd_out doubles as the variance buffer of the slab path
+        GP_TRY(predict_cols(h, m, X, 0, N, 1, Xs, M, mean_out, sd_out));
+        GP_TRY(launch_acq_from_var(h, kind, mean_out, sd_out, M, p0, inc, p1, mask, sd_out, acq_out));
+    }
+    return finish_and_check(h);
 }
 
 static int sel_scratch_ensure(gpimhip_ctx* h) {

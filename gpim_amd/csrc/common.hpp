@@ -122,6 +122,7 @@ struct gpimhip_ctx {
     // top-k scratch
     unsigned long long* keys = nullptr;
     int64_t keys_cap = 0;
+    double* acq_tmp = nullptr; int64_t acq_tmp_cap = 0;   // observed-rows posterior + incumbent (gpimhip_acquire_exact)
     char* sel_scratch = nullptr;    // radix-select state, candidates, nanmax partials (select.hip)
     // training-loop bookkeeping: iterations completed by the last fit call, pinned copy of the status
     // word + events of the bounded run-ahead check (api.hip: RunAhead)
@@ -144,6 +145,15 @@ int ws_ensure(gpimhip_ctx* h, int64_t N);
 int ws_ensure_predict(gpimhip_ctx* h, int64_t np, int64_t mc);
 int plan_ensure(gpimhip_ctx* h, int nb);
 int launch_theta(gpimhip_ctx* h, const gpimhip_model_t* m, const double* u);
+// predict.hip
+bool fused_predict_fits(int64_t np);
+int launch_predict_fused(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X, int64_t x_bs, int64_t N,
+                         const double* Xs, int64_t M, double* mean_out, double* var_out, double* sd_out,
+                         double* acq_out, int acq_kind, double p0, const double* p0_dev, double p1,
+                         const double* mask);
+int launch_acq_from_var(gpimhip_ctx* h, int kind, const double* mean, const double* var, int64_t M, double p0,
+                        const double* p0_dev, double p1, const double* mask, double* sd_out, double* acq_out);
+
 
 enum GemmEpi { EPI_STORE = 0, EPI_COLSUMSQ = 1 };
 struct GemmArgs {

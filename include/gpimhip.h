@@ -207,6 +207,19 @@ int gpimhip_predict_kron(gpimhip_handle h, const gpimhip_model_t* m, int32_t d, 
 int gpimhip_acq(gpimhip_handle h, int32_t kind, const double* mean, const double* sd,
                 int64_t M, double p0, double p1, const double* mask, double* acq_out);
 
+/* One acquisition evaluation of boptimizer for an exact-GP surrogate, without leaving the device and with
+ * ONE factorisation (replaces the predict / predict / nanmax / sweep sequence of gpim/gpbayes/acqfunc.py:27-29,
+ * 52-62, 80-91 and boptim.py:303-308):
+ *   posterior at the observed rows Xobs (Mobs x dim; EI, POI only) -> incumbent = nanmax of the means (EI) or
+ *   of the means and standard deviations (POI: the reference's tuple quirk, acqfunc.py:86-88), kept on the device;
+ *   posterior at the grid Xs (M x dim) -> mean_out, sd_out; acq_out = CB(p0 = alpha, p1 = beta) or
+ *   EI / POI(incumbent, p1 = xi), times mask (M doubles of 1 / NaN, or NULL).
+ * For N <= 384 every prediction is one fused launch whose K(X, X*) panel never leaves LDS (csrc/predict.hip). */
+int gpimhip_acquire_exact(gpimhip_handle h, const gpimhip_model_t* m, const double* X, const double* y,
+                          int64_t N, const double* u, const double* Xs, int64_t M, const double* Xobs,
+                          int64_t Mobs, int32_t kind, double p0, double p1, const double* mask,
+                          double* mean_out, double* sd_out, double* acq_out);
+
 /* nanmax over n doubles (device) -> out (1 double, device): the incumbent
  * "np.nanmax(mean_sample)" of acqfunc.py:59,88. */
 int gpimhip_nanmax(gpimhip_handle h, const double* x, int64_t n, double* out);
