@@ -21,6 +21,7 @@ for N in [int(a) for a in sys.argv[1:]]:
         torch.cuda.synchronize(); ts.append((time.perf_counter() - t) * 1e3)
     L = torch.tril(A); v = torch.randn(N, 1, dtype=torch.float64, device=dev)
     res = float((L @ (L.T @ v) - K @ v).norm() / (K @ v).norm())
-    print("   residual |L L^T v - K v| / |K v| = %.2e" % res)
+    import hashlib
+    print("   residual |L L^T v - K v| / |K v| = %.2e   sha1(L) %s" % (res, hashlib.sha1(L.cpu().numpy().tobytes()).hexdigest()[:12]))
     print("potrf N=%d: %s ms  -> %.1f TFLOP/s  info %d" % (N, ["%.2f" % v for v in ts], N ** 3 / 3 / min(ts) / 1e9, int(info[0])), flush=True)
     del K, A
