@@ -80,6 +80,7 @@ _PROTOS = {
                                                  ctypes.c_int32, c_dp, c_dp]),
     "gpimhip_dist_trailing_update": (ctypes.c_int, [ctypes.c_void_p, c_dp, ctypes.c_int64, ctypes.c_int32, c_dp,
                                                     ctypes.c_int64, ctypes.c_int32, ctypes.c_int32]),
+    "gpimhip_set_precision": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32]),
     "gpimhip_acquire_exact": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ModelStruct), c_dp, c_dp, ctypes.c_int64,
                                              c_dp, c_dp, ctypes.c_int64, c_dp, ctypes.c_int64, ctypes.c_int32,
                                              ctypes.c_double, ctypes.c_double, c_dp, c_dp, c_dp, c_dp]),
@@ -135,7 +136,7 @@ def check(rc):
 class Handle:
     """Owns one gpimhip_handle bound to torch's current stream on the current device."""
 
-    def __init__(self):
+    def __init__(self, precision="double"):
         self.device = require_gpu()
         lib = load()
         h = ctypes.c_void_p()
@@ -143,6 +144,9 @@ class Handle:
         check(lib.gpimhip_create(ctypes.byref(h), self.device.index, ctypes.c_void_p(stream)))
         self._h = h
         self.lib = lib
+        self.precision = precision
+        if precision == "single":       # N x N matrices and the O(N^3) products in float (gpimhip_set_precision)
+            check(lib.gpimhip_set_precision(h, 32))
 
     @property
     def h(self):

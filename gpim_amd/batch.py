@@ -26,7 +26,7 @@ def fit_predict_batch(Xs_list, ys_list, Xtest, kernel='RBF', lengthscale=None, l
     and predict each on the shared grid Xtest.  All problems must have the same number of
     observations.  Returns (mean, sd, hist): arrays (B, *Xtest.shape[1:]) and the hyper-parameter
     history (B, iterations, P) in the order [variance, lengthscale.., noise(, alpha)]."""
-    H = handle or _lib.Handle()
+    H = handle or _lib.Handle(precision=kwargs.get("precision", "double"))
     dev = H.device
     B = len(ys_list)
     y0 = np.asarray(ys_list[0])

@@ -22,6 +22,9 @@ int launch_gemv_t(gpimhip_ctx* h, const double* A, int64_t ld, int64_t nrows, in
                   double* out, int tri, int64_t a_bs, int64_t x_bs, int64_t o_bs);
 int launch_grad_reduce(gpimhip_ctx* h, const gpimhip_model_t* m, const double* Kinv, int64_t ld,
                        const double* X, int64_t N, int nb, const double* alpha, int64_t x_bs);
+int launch_kres(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X, int64_t x_bs, int64_t N, double* scratch,
+                int S, double* res);
+int launch_axpy(gpimhip_ctx* h, double* x, const double* d, int64_t n);
 int launch_finalize(gpimhip_ctx* h, const gpimhip_model_t* m, int64_t N, int64_t np, double* u, int do_adam,
                     AdamStep st, double* loss_out, double* grad_out, double* hist_row, int32_t* iter,
                     const double* bc, int T, double* hist_base, double* loss_base);
@@ -86,13 +89,16 @@ static void dev_free(gpimhip_ctx* h, T** p, int64_t count) {
     }
 }
 
+// the N x N matrices hold floats on a single-precision handle: same element counts, half the doubles
+static inline int64_t mat_doubles(const gpimhip_ctx* h, int64_t elements) { return h->fp32 ? (elements + 1) / 2 : elements; }
+
 static void ws_release_matrix(gpimhip_ctx* h) {
     const int64_t np = h->np, nb = np / NB, B = h->ws_batch;
     if (!np) return;
-    dev_free(h, &h->A, B * np * h->ld);
-    dev_free(h, &h->B, B * np * h->ld);
-    dev_free(h, &h->Tm, B * np * h->ld);
-    dev_free(h, &h->dinv, B * nb * NB * NB);
+    dev_free(h, &h->A, mat_doubles(h, B * np * h->ld));
+    dev_free(h, &h->B, mat_doubles(h, B * np * h->ld));
+    dev_free(h, &h->Tm, mat_doubles(h, B * np * h->ld));
+    dev_free(h, &h->dinv, mat_doubles(h, B * nb * NB * NB));
     dev_free(h, &h->ypad, B * np);
     dev_free(h, &h->z, B * np);
     dev_free(h, &h->alpha, B * np);
@@ -116,7 +122,7 @@ static void ws_release_matrix(gpimhip_ctx* h) {
 // and never needs the three np x np buffers (3 x 32 GiB at N = 65536).
 static int ws_ensure_b(gpimhip_ctx* h, int64_t N, int B, int padded, bool matrices = true) {
     const int64_t np = pad_to(std::max<int64_t>(N, 1), NB);
-    const int64_t ld = np + ((padded && np >= 1024) ? 16 : 0);
+    const int64_t ld = np + ((padded && np >= 1024) ? (h->fp32 ? 32 : 16) : 0);      // one extra 128-byte line per row
     if (np == h->np && B == h->ws_batch && ld == h->ld && (h->A != nullptr || !matrices)) return GPIMHIP_OK;
     HIP_TRY(hipStreamSynchronize(h->stream));
     ws_release_matrix(h);
@@ -127,9 +133,10 @@ static int ws_ensure_b(gpimhip_ctx* h, int64_t N, int B, int padded, bool matric
     h->ws_batch = B;
     h->ld = ld;
     int rc = GPIMHIP_OK;
-    if ((matrices && ((rc = dev_alloc(h, &h->A, B * np * ld)) || (rc = dev_alloc(h, &h->B, B * np * ld)) ||
-                      (rc = dev_alloc(h, &h->Tm, B * np * ld)))) ||
-        (rc = dev_alloc(h, &h->dinv, B * nb * NB * NB)) ||
+    if ((matrices && ((rc = dev_alloc(h, &h->A, mat_doubles(h, B * np * ld))) ||
+                      (rc = dev_alloc(h, &h->B, mat_doubles(h, B * np * ld))) ||
+                      (rc = dev_alloc(h, &h->Tm, mat_doubles(h, B * np * ld))))) ||
+        (rc = dev_alloc(h, &h->dinv, mat_doubles(h, B * nb * NB * NB))) ||
         (rc = dev_alloc(h, &h->ypad, B * np)) || (rc = dev_alloc(h, &h->z, B * np)) ||
         (rc = dev_alloc(h, &h->alpha, B * np)) || (rc = dev_alloc(h, &h->logdet_part, B * nb)) ||
         (rc = dev_alloc(h, &h->grad_part, B * nb * (nb + 1) / 2 * 8)) || (rc = dev_alloc(h, &h->theta, (int64_t)B)) ||
@@ -138,13 +145,19 @@ static int ws_ensure_b(gpimhip_ctx* h, int64_t N, int B, int padded, bool matric
         ws_release_matrix(h);
         return rc;
     }
+    if (h->fp32 && h->refine_cap < 10 * (int64_t)B * np) {
+        dev_free(h, &h->refine, h->refine_cap);
+        h->refine_cap = 0;
+        GP_TRY(dev_alloc(h, &h->refine, 10 * (int64_t)B * np));
+        h->refine_cap = 10 * (int64_t)B * np;
+    }
     return plan_ensure(h, (int)nb);
 }
 int ws_ensure(gpimhip_ctx* h, int64_t N) { return ws_ensure_b(h, N, h->nbatch, 0); }
 static int ws_ensure_padded(gpimhip_ctx* h, int64_t N) { return ws_ensure_b(h, N, h->nbatch, 1); }
 
 static void ws_release_predict(gpimhip_ctx* h) {
-    dev_free(h, &h->Ks, h->ks_batch * h->ks_rows * (h->ks_cols + 16));
+    dev_free(h, &h->Ks, mat_doubles(h, h->ks_batch * h->ks_rows * (h->ks_cols + 16)));
     dev_free(h, &h->colpart, h->ks_batch * (h->ks_rows / NB) * h->ks_cols);
     dev_free(h, &h->mean_tmp, h->ks_batch * h->ks_cols);
     for (auto& pl : h->pred_lists) dev_free(h, &pl.tiles, pl.n);
@@ -170,7 +183,7 @@ int ws_ensure_predict(gpimhip_ctx* h, int64_t np, int64_t mc) {
         h->ks_cols = cap;
         h->ks_batch = B;
         int rc = GPIMHIP_OK;
-        if ((rc = dev_alloc(h, &h->Ks, B * np * (cap + 16))) || (rc = dev_alloc(h, &h->colpart, B * (np / NB) * cap)) ||
+        if ((rc = dev_alloc(h, &h->Ks, mat_doubles(h, B * np * (cap + 16)))) || (rc = dev_alloc(h, &h->colpart, B * (np / NB) * cap)) ||
             (rc = dev_alloc(h, &h->mean_tmp, B * cap))) {
             ws_release_predict(h);
             return rc;
@@ -546,10 +559,30 @@ int check_model(const gpimhip_model_t* m) {
 // Everything needed at the current u: theta, K, L, L^-1, z, alpha.  (Shared by fit and predict.)
 // x_bs: per-problem stride of X in elements (0 when all problems of a batch share one X).
 // z = L^-1 y, alpha = L^-T z (two HBM-bound passes over L^-1).
-static int solve_vectors(gpimhip_ctx* h) {
+// Single-precision handles refine alpha against the covariance regenerated in double (launch_kres): the fp32
+// factor and its explicit fp32 inverse leave an error of eps32 * cond(K) in alpha, every pass
+// alpha += K32^-1 (y - K alpha) multiplies it by that factor again (one pass by default; measured at cond = 1e5,
+// N = 2300, RBF: posterior-mean error 6e-4 -> 1.2e-4, a float32 LAPACK run: 1.3e-3; loss 0.95 -> 0.06 of 4129;
+// a second pass changes nothing -- what is left comes from log det and K^-1 themselves).  The loss then takes its
+// quadratic term as y^T alpha (launch_finalize).
+static int refine_passes() {
+    static const int v = getenv("GPIMHIP_REFINE") ? atoi(getenv("GPIMHIP_REFINE")) : 1;
+    return v;
+}
+static int solve_vectors(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X, int64_t x_bs, int64_t N) {
     const int64_t np = h->np, ld = h->ld;
     GP_TRY(launch_trmv_lower(h, h->A, ld, np, h->ypad, h->z));
     GP_TRY(launch_gemv_t(h, h->A, ld, np, np, h->z, h->alpha, 1, np * ld, np, np));
+    if (!h->fp32) return GPIMHIP_OK;
+    const int B = h->nbatch, nb = (int)(np / NB);
+    const int S = std::max(1, std::min(8, 512 / std::max(1, nb * B)));        // >= ~512 workgroups per launch
+    double *res = h->refine, *delta = res + (int64_t)B * np, *scratch = delta + (int64_t)B * np;
+    for (int pass = 0; pass < refine_passes(); ++pass) {
+        GP_TRY(launch_kres(h, m, X, x_bs, N, scratch, S, res));
+        GP_TRY(launch_trmv_lower(h, h->A, ld, np, res, h->z));
+        GP_TRY(launch_gemv_t(h, h->A, ld, np, np, h->z, delta, 1, np * ld, np, np));
+        GP_TRY(launch_axpy(h, h->alpha, delta, (int64_t)B * np));
+    }
     return GPIMHIP_OK;
 }
 
@@ -561,7 +594,7 @@ static int factor_at_u(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X
     GP_TRY(launch_kmat(h, m, X, N, nullptr, N, h->theta, 0.0, 1, h->A, ld, np, np, 1, 1, x_bs, x_bs, np * ld));
     { StageTimer t(h, 0); GP_TRY(launch_potrf(h, h->A, np, ld, h->info)); }
     { StageTimer t(h, 1); GP_TRY(launch_trtri(h, h->A, h->Tm, np, ld)); }
-    if (!defer_vectors) GP_TRY(solve_vectors(h));
+    if (!defer_vectors) GP_TRY(solve_vectors(h, m, X, x_bs, N));
     return GPIMHIP_OK;
 }
 
@@ -582,7 +615,7 @@ static int loss_grad_at_u(gpimhip_ctx* h, const gpimhip_model_t* m, const double
         HIP_TRY(hipEventRecord(ev_in, main_s));
         HIP_TRY(hipStreamWaitEvent(h->panel_stream, ev_in, 0));
         h->stream = h->panel_stream;
-        const int rc = solve_vectors(h);
+        const int rc = solve_vectors(h, m, X, x_bs, N);
         h->stream = main_s;
         GP_TRY(rc);
         HIP_TRY(hipEventRecord(ev_out, h->panel_stream));
@@ -698,6 +731,18 @@ int gpimhip_create(gpimhip_handle* out, int device, void* hip_stream) {
     return GPIMHIP_OK;
 }
 
+int gpimhip_set_precision(gpimhip_handle h, int32_t bits) {
+    if (!h || (bits != 32 && bits != 64)) return GPIMHIP_E_BADARG;
+    const int want = bits == 32 ? 1 : 0;
+    if (want == h->fp32) return GPIMHIP_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    ws_release_matrix(h);               // sized by the element type
+    ws_release_predict(h);
+    h->fp32 = want;
+    return GPIMHIP_OK;
+}
+
 int gpimhip_destroy(gpimhip_handle h) {
     if (!h) return GPIMHIP_OK;
     (void)hipSetDevice(h->device);
@@ -709,6 +754,7 @@ int gpimhip_destroy(gpimhip_handle h) {
     dev_free(h, &h->keys, h->keys_cap);
     if (h->sel_scratch) dev_free(h, &h->sel_scratch, (int64_t)sel_scratch_bytes());
     dev_free(h, &h->acq_tmp, h->acq_tmp_cap);
+    dev_free(h, &h->refine, h->refine_cap);
     dev_free(h, &h->bc, h->bc_cap);
     dev_free(h, &h->theta1, 1);
     dev_free(h, &h->info, 4);
@@ -760,6 +806,7 @@ int gpimhip_sync(gpimhip_handle h) {
 
 int gpimhip_kmat(gpimhip_handle h, const gpimhip_model_t* m, const double* X, int64_t N, const double* Z,
                  int64_t M, const double* theta, double diag_add, double* out, int64_t ld) {
+    FP64_ONLY(h);
     if (!h || !X || !theta || !out || N < 1) return GPIMHIP_E_BADARG;
     GP_TRY(check_model(m));
     HIP_TRY(hipSetDevice(h->device));
@@ -780,6 +827,7 @@ int gpimhip_kmat(gpimhip_handle h, const gpimhip_model_t* m, const double* X, in
 }
 
 int gpimhip_potrf(gpimhip_handle h, double* A, int64_t n, int64_t ld, int32_t* info) {
+    FP64_ONLY(h);
     if (!h || !A || n < 1 || ld < n || !info) return GPIMHIP_E_BADARG;
     HIP_TRY(hipSetDevice(h->device));
     h->nbatch = 1;
@@ -860,7 +908,7 @@ static int predict_cols(gpimhip_ctx* h, const gpimhip_model_t* m, const double* 
     const int64_t np = h->np;
     const int nb = (int)(np / NB);
     // few observations: one fused launch, K* stays in LDS (predict.hip)
-    if (fused_predict_fits(np))
+    if (!h->fp32 && fused_predict_fits(np))
         return launch_predict_fused(h, m, X, x_bs, N, Xs, M, mean_out, var_out, nullptr, nullptr, -1, 0.0, nullptr, 0.0,
                                     nullptr);
     // chunk the test points so that the K* slabs of all problems together stay <= ~1 GiB
@@ -981,13 +1029,14 @@ int gpimhip_acquire_exact(gpimhip_handle h, const gpimhip_model_t* m, const doub
     HIP_TRY(hipMemsetAsync(h->info, 0, sizeof(int32_t), h->stream));
     GP_TRY(launch_pad_copy(h, y, N, h->ypad, np));
     GP_TRY(factor_at_u(h, m, X, 0, N, u));
-    const bool fused = fused_predict_fits(np);
+    const bool fused = !h->fp32 && fused_predict_fits(np);
     const double* inc = nullptr;
     if (kind != GPIMHIP_ACQ_CB) {
         // incumbent = nanmax of the posterior at the observed rows (EI: means; POI: means and sds), on device
         if (h->acq_tmp_cap < 2 * Mobs + 2) {
             HIP_TRY(hipStreamSynchronize(h->stream));
             dev_free(h, &h->acq_tmp, h->acq_tmp_cap);
+    dev_free(h, &h->refine, h->refine_cap);
             h->acq_tmp_cap = 0;
             GP_TRY(dev_alloc(h, &h->acq_tmp, 2 * Mobs + 2));
             h->acq_tmp_cap = 2 * Mobs + 2;
@@ -1053,6 +1102,7 @@ int gpimhip_topk(gpimhip_handle h, const double* acq, int64_t M, int32_t k, int3
 
 // ---- distributed (block-column-cyclic) factorisation: building blocks (see include/gpimhip.h) ----
 int gpimhip_dist_begin(gpimhip_handle h, int64_t n) {
+    FP64_ONLY(h);
     if (!h || n < 1) return GPIMHIP_E_BADARG;
     HIP_TRY(hipSetDevice(h->device));
     h->nbatch = 1;
@@ -1063,6 +1113,7 @@ int gpimhip_dist_begin(gpimhip_handle h, int64_t n) {
 
 int gpimhip_dist_panel_factor(gpimhip_handle h, double* Aloc, int64_t ldloc, int32_t loc_blk0, int32_t glob_blk0,
                               double* logdet_out, int32_t* info) {
+    FP64_ONLY(h);
     if (!h || !Aloc || !info || loc_blk0 < 0 || glob_blk0 < 0 || !h->np) return GPIMHIP_E_BADARG;
     HIP_TRY(hipSetDevice(h->device));
     const int nb = (int)(h->np / NB);
@@ -1082,6 +1133,7 @@ int gpimhip_dist_panel_factor(gpimhip_handle h, double* Aloc, int64_t ldloc, int
 
 int gpimhip_dist_trailing_update(gpimhip_handle h, const double* panel, int64_t ldp, int32_t panel_glob_blk0,
                                  double* Aloc, int64_t ldloc, int32_t loc_blk0, int32_t glob_blk0) {
+    FP64_ONLY(h);
     if (!h || !panel || !Aloc || !h->np || panel_glob_blk0 < 0 || glob_blk0 <= panel_glob_blk0) return GPIMHIP_E_BADARG;
     HIP_TRY(hipSetDevice(h->device));
     const int nb = (int)(h->np / NB);

@@ -227,13 +227,18 @@ __device__ __forceinline__ void tile_write(double* C, d4 v, int lane) {
 // flight, the two chunks that make up rows 0..15 are stored as soon as they arrive, and wave 0 runs
 // chol16 on them while the rest of the block is still on its way (it stores its own remaining
 // chunks afterwards).  Pairs with lds_factor_inv<.., true>.
+// R: element type of the matrix in HBM (double, or float for single-precision handles; the block is factored in
+// double either way).
+template <typename R>
 __device__ __forceinline__ void load_block_chol0(double* D, double* invd, int* s_bad,
-                                                 const double* __restrict__ Ablk, int64_t ld, int tid) {
+                                                 const R* __restrict__ Ablk, int64_t ld, int tid) {
+    typedef R RV2 __attribute__((ext_vector_type(2)));
     d2 r[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int e = tid + NTH * i, row = e >> 6, c2 = (e & 63) * 2;
-        r[i] = *reinterpret_cast<const d2*>(Ablk + (int64_t)row * ld + c2);
+        const RV2 v = *reinterpret_cast<const RV2*>(Ablk + (int64_t)row * ld + c2);
+        r[i] = (d2){(double)v[0], (double)v[1]};
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {

@@ -136,7 +136,18 @@ struct gpimhip_ctx {
     void* vfe = nullptr;
     // structured (Kronecker) workspace, owned by kron.hip (KronWs*); released by kron_release()
     void* kron = nullptr;
+    double* refine = nullptr; int64_t refine_cap = 0;    // residual, correction and partial sums of the refinement (fp32 handles)
+    int fp32 = 0;                   // 1: the N x N matrices of the exact-GP path are float (gpimhip_set_precision)
 };
+
+// entry points outside the exact-GP path keep their matrices in double
+#define FP64_ONLY(h)                                                                                      \
+    do {                                                                                                  \
+        if ((h) && (h)->fp32) {                                                                           \
+            gpim_set_error("this entry point needs a double-precision handle (gpimhip_set_precision(h, 64))"); \
+            return GPIMHIP_E_BADARG;                                                                      \
+        }                                                                                                 \
+    } while (0)
 
 static inline int64_t pad_to(int64_t n, int64_t m) { return (n + m - 1) / m * m; }
 

@@ -12,6 +12,12 @@
 #include "theta.hpp"
 
 typedef double d2 __attribute__((ext_vector_type(2)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+// The N x N matrices (covariance, factor, inverse, K* slab) are double or float (gpimhip_set_precision); vectors,
+// reductions and every scalar stay double.  Host-side the pointers are typed double* for both.
+template <typename R> struct Vec2;
+template <> struct Vec2<double> { typedef d2 T; };
+template <> struct Vec2<float> { typedef f2 T; };
 
 // ------------------------------------------------------------------------------------------
 // u -> theta   (torch.distributions transform_to(interval) = Affine o Sigmoid with clipping;
@@ -70,11 +76,11 @@ __device__ __forceinline__ void lower_tile_from_linear(int q, int& i, int& j) {
     j = q - (int)((int64_t)i * (i + 1) / 2);
 }
 
-template <int KIND>
+template <int KIND, typename R>
 __global__ __launch_bounds__(256) void kmat_kernel(const double* __restrict__ X, int64_t N,
                                                    const double* __restrict__ Z, int64_t M, int d,
                                                    const ThetaDev* __restrict__ th, double diag_add,
-                                                   int use_theta_diag, double* __restrict__ out, int64_t ld,
+                                                   int use_theta_diag, R* __restrict__ out, int64_t ld,
                                                    int ntc, int sym, int lower_only, int64_t x_bs, int64_t z_bs,
                                                    int64_t out_bs) {
     __shared__ double xa[128][5];
@@ -114,7 +120,7 @@ __global__ __launch_bounds__(256) void kmat_kernel(const double* __restrict__ X,
         const double a0 = xa[r][0], a1 = xa[r][1], a2 = xa[r][2], a3 = xa[r][3], an = xa[r][4];
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc) {
-            d2 v;
+            typename Vec2<R>::T v;
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const int c = tx * 2 + 32 * cc + e;
@@ -128,9 +134,9 @@ __global__ __launch_bounds__(256) void kmat_kernel(const double* __restrict__ X,
                 double k = t.var * kfun_value<KIND>(r2, t.alpha);
                 if (gi >= N || gj >= M) k = (sym && gi == gj) ? 1.0 : 0.0;
                 else if (sym && gi == gj) k += dadd;
-                v[e] = k;
+                v[e] = (R)k;
             }
-            *reinterpret_cast<d2*>(out + gi * ld + (int64_t)cj * 128 + tx * 2 + 32 * cc) = v;
+            *reinterpret_cast<typename Vec2<R>::T*>(out + gi * ld + (int64_t)cj * 128 + tx * 2 + 32 * cc) = v;
         }
     }
 }
@@ -146,8 +152,14 @@ int launch_kmat(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X, int64
     dim3 grid((unsigned)nblk, h->nbatch), block(256);
     if (!Z) z_bs = x_bs;
 #define KM_LAUNCH(KIND)                                                                              \
-    hipLaunchKernelGGL((kmat_kernel<KIND>), grid, block, 0, h->stream, X, N, Zp, M, m->dim, theta,    \
-                       diag_add, use_theta_diag, out, ld, ntc, sym, lower_only, x_bs, z_bs, out_bs)
+    do {                                                                                             \
+        if (h->fp32)                                                                                 \
+            hipLaunchKernelGGL((kmat_kernel<KIND, float>), grid, block, 0, h->stream, X, N, Zp, M, m->dim, theta, diag_add, \
+                               use_theta_diag, reinterpret_cast<float*>(out), ld, ntc, sym, lower_only, x_bs, z_bs, out_bs); \
+        else                                                                                         \
+            hipLaunchKernelGGL((kmat_kernel<KIND, double>), grid, block, 0, h->stream, X, N, Zp, M, m->dim, theta, diag_add, \
+                               use_theta_diag, out, ld, ntc, sym, lower_only, x_bs, z_bs, out_bs);     \
+    } while (0)
     switch (m->kernel) {
         case GPIMHIP_KERNEL_RBF: KM_LAUNCH(GPIMHIP_KERNEL_RBF); break;
         case GPIMHIP_KERNEL_MATERN52: KM_LAUNCH(GPIMHIP_KERNEL_MATERN52); break;
@@ -176,21 +188,28 @@ int launch_pad_copy(gpimhip_ctx* h, const double* src, int64_t n, double* dst, i
 }
 
 // A[k,k] <- dinv[k] for every diagonal block (leaves of the triangular inversion)
-__global__ __launch_bounds__(256) void diag_inv_copy_kernel(double* __restrict__ A, int64_t ld,
-                                                            const double* __restrict__ dinv, int64_t a_bs,
+template <typename R>
+__global__ __launch_bounds__(256) void diag_inv_copy_kernel(R* __restrict__ A, int64_t ld,
+                                                            const R* __restrict__ dinv, int64_t a_bs,
                                                             int64_t d_bs) {
+    typedef typename Vec2<R>::T R2;
     const int k = blockIdx.x;
     A += blockIdx.y * a_bs;
     dinv += blockIdx.y * d_bs;
-    double* dst = A + ((int64_t)k * NB) * ld + (int64_t)k * NB;
-    const double* src = dinv + (int64_t)k * NB * NB;
+    R* dst = A + ((int64_t)k * NB) * ld + (int64_t)k * NB;
+    const R* src = dinv + (int64_t)k * NB * NB;
     for (int e = threadIdx.x; e < NB * NB / 2; e += 256) {
         const int r = e >> 6, c2 = (e & 63) * 2;
-        *reinterpret_cast<d2*>(dst + (int64_t)r * ld + c2) = *reinterpret_cast<const d2*>(src + r * NB + c2);
+        *reinterpret_cast<R2*>(dst + (int64_t)r * ld + c2) = *reinterpret_cast<const R2*>(src + r * NB + c2);
     }
 }
 int launch_diag_inv_copy(gpimhip_ctx* h, double* A, int64_t ld, int nb) {
-    hipLaunchKernelGGL(diag_inv_copy_kernel, dim3(nb, h->nbatch), dim3(256), 0, h->stream, A, ld, h->dinv,
+    if (h->fp32)
+        hipLaunchKernelGGL(diag_inv_copy_kernel<float>, dim3(nb, h->nbatch), dim3(256), 0, h->stream,
+                           reinterpret_cast<float*>(A), ld, reinterpret_cast<const float*>(h->dinv), (int64_t)nb * NB * ld,
+                           (int64_t)nb * NB * NB);
+    else
+        hipLaunchKernelGGL(diag_inv_copy_kernel<double>, dim3(nb, h->nbatch), dim3(256), 0, h->stream, A, ld, h->dinv,
                        (int64_t)nb * NB * ld, (int64_t)nb * NB * NB);
     HIP_TRY(hipGetLastError());
     return GPIMHIP_OK;
@@ -241,7 +260,8 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 // z[i] = sum_{j < jend(i)} L[i][j] * y[j];  one wave per row, 4 rows per workgroup
-__global__ __launch_bounds__(256) void trmv_lower_kernel(const double* __restrict__ L, int64_t ld, int64_t np,
+template <typename R>
+__global__ __launch_bounds__(256) void trmv_lower_kernel(const R* __restrict__ L, int64_t ld, int64_t np,
                                                          const double* __restrict__ y, double* __restrict__ z) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t i = (int64_t)blockIdx.x * 4 + wave;
@@ -250,13 +270,13 @@ __global__ __launch_bounds__(256) void trmv_lower_kernel(const double* __restric
     z += blockIdx.y * np;
     if (i >= np) return;
     const int64_t jend = (i / NB + 1) * NB;
-    const double* row = L + i * ld;
+    const R* row = L + i * ld;
     double s = 0.0;
     for (int64_t j = lane * 2; j < jend; j += 128) {
-        const d2 l = *reinterpret_cast<const d2*>(row + j);
+        const typename Vec2<R>::T l = *reinterpret_cast<const typename Vec2<R>::T*>(row + j);
         const d2 v = *reinterpret_cast<const d2*>(y + j);
-        s = fma(l[0], v[0], s);
-        s = fma(l[1], v[1], s);
+        s = fma((double)l[0], v[0], s);
+        s = fma((double)l[1], v[1], s);
     }
     s = wave_sum(s);
     if (lane == 0) z[i] = s;
@@ -266,7 +286,8 @@ __global__ __launch_bounds__(256) void trmv_lower_kernel(const double* __restric
 // diagonal block of the column (A lower triangular), else at row 0.  HBM-bound (8 B per entry of
 // A): 16 waves per workgroup, each with four 512-byte row segments in flight; fixed summation order.
 #define GEMVT_WAVES 16
-__global__ __launch_bounds__(GEMVT_WAVES * 64) void gemv_t_kernel(const double* __restrict__ A, int64_t ld,
+template <typename R>
+__global__ __launch_bounds__(GEMVT_WAVES * 64) void gemv_t_kernel(const R* __restrict__ A, int64_t ld,
                                                                  int64_t nrows, const double* __restrict__ x,
                                                                  double* __restrict__ out, int tri, int64_t a_bs,
                                                                  int64_t x_bs, int64_t o_bs) {
@@ -277,18 +298,18 @@ __global__ __launch_bounds__(GEMVT_WAVES * 64) void gemv_t_kernel(const double* 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t j = (int64_t)blockIdx.x * 64 + lane;
     const int64_t i0 = tri ? ((int64_t)blockIdx.x * 64 / NB) * NB : 0;
-    const double* col = A + j;
+    const R* col = A + j;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     int64_t i = i0 + wave;
     for (; i + 3 * GEMVT_WAVES < nrows; i += 4 * GEMVT_WAVES) {
-        const double a0 = col[i * ld], a1 = col[(i + GEMVT_WAVES) * ld];
-        const double a2 = col[(i + 2 * GEMVT_WAVES) * ld], a3 = col[(i + 3 * GEMVT_WAVES) * ld];
+        const double a0 = (double)col[i * ld], a1 = (double)col[(i + GEMVT_WAVES) * ld];
+        const double a2 = (double)col[(i + 2 * GEMVT_WAVES) * ld], a3 = (double)col[(i + 3 * GEMVT_WAVES) * ld];
         s0 = fma(a0, x[i], s0);
         s1 = fma(a1, x[i + GEMVT_WAVES], s1);
         s2 = fma(a2, x[i + 2 * GEMVT_WAVES], s2);
         s3 = fma(a3, x[i + 3 * GEMVT_WAVES], s3);
     }
-    for (; i < nrows; i += GEMVT_WAVES) s0 = fma(col[i * ld], x[i], s0);
+    for (; i < nrows; i += GEMVT_WAVES) s0 = fma((double)col[i * ld], x[i], s0);
     red[wave][lane] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (wave == 0) {
@@ -300,15 +321,120 @@ __global__ __launch_bounds__(GEMVT_WAVES * 64) void gemv_t_kernel(const double* 
 }
 
 int launch_trmv_lower(gpimhip_ctx* h, const double* L, int64_t ld, int64_t np, const double* y, double* z) {
-    hipLaunchKernelGGL(trmv_lower_kernel, dim3((unsigned)((np + 3) / 4), h->nbatch), dim3(256), 0, h->stream, L, ld,
+    if (h->fp32)
+        hipLaunchKernelGGL(trmv_lower_kernel<float>, dim3((unsigned)((np + 3) / 4), h->nbatch), dim3(256), 0, h->stream,
+                           reinterpret_cast<const float*>(L), ld, np, y, z);
+    else
+        hipLaunchKernelGGL(trmv_lower_kernel<double>, dim3((unsigned)((np + 3) / 4), h->nbatch), dim3(256), 0, h->stream, L, ld,
                        np, y, z);
     HIP_TRY(hipGetLastError());
     return GPIMHIP_OK;
 }
 int launch_gemv_t(gpimhip_ctx* h, const double* A, int64_t ld, int64_t nrows, int64_t ncols, const double* x,
                   double* out, int tri, int64_t a_bs, int64_t x_bs, int64_t o_bs) {
-    hipLaunchKernelGGL(gemv_t_kernel, dim3((unsigned)(ncols / 64), h->nbatch), dim3(GEMVT_WAVES * 64), 0, h->stream, A, ld, nrows,
+    if (h->fp32)
+        hipLaunchKernelGGL(gemv_t_kernel<float>, dim3((unsigned)(ncols / 64), h->nbatch), dim3(GEMVT_WAVES * 64), 0, h->stream,
+                           reinterpret_cast<const float*>(A), ld, nrows, x, out, tri, a_bs, x_bs, o_bs);
+    else
+        hipLaunchKernelGGL(gemv_t_kernel<double>, dim3((unsigned)(ncols / 64), h->nbatch), dim3(GEMVT_WAVES * 64), 0, h->stream, A, ld, nrows,
                        x, out, tri, a_bs, x_bs, o_bs);
+    HIP_TRY(hipGetLastError());
+    return GPIMHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// residual r = y - (K + (jitter + noise) I) alpha with K generated on the fly in double (kmat_kernel's
+// arithmetic): the iterative-refinement step of single-precision handles.  alpha = K^-1 y through an fp32 factor
+// and its explicit fp32 inverse is off by eps32 * cond(K); one pass  alpha += K32^-1 (y - K alpha)  squares that
+// factor.  Workgroup = 128 rows x every S-th column block; partial sums in part[s][row], summed in order.
+// ------------------------------------------------------------------------------------------
+template <int KIND>
+__global__ __launch_bounds__(256) void kres_partial_kernel(const double* __restrict__ X, int64_t N, int d,
+                                                           const double* __restrict__ alpha,
+                                                           const ThetaDev* __restrict__ th, double* __restrict__ part,
+                                                           int64_t x_bs, int64_t np, int S) {
+    __shared__ double xz[128][5];
+    __shared__ double al[128];
+    __shared__ double red[128];
+    const int tid = threadIdx.x, r = tid & 127, half = tid >> 7;
+    const int ci = blockIdx.x / S, s0 = blockIdx.x % S, nb = (int)(np / NB);
+    X += blockIdx.y * x_bs;
+    alpha += blockIdx.y * np;
+    th += blockIdx.y;
+    part += (int64_t)blockIdx.y * S * np;
+    const ThetaDev t = *th;
+    const int64_t gi = (int64_t)ci * 128 + r;
+    double a[4], an = 0.0;
+#pragma unroll
+    for (int k = 0; k < GPIMHIP_MAX_DIM; ++k) {
+        a[k] = (k < d && gi < N) ? X[gi * d + k] / t.ls[k] : 0.0;
+        an += a[k] * a[k];
+    }
+    double acc = 0.0;
+    for (int cj = s0; cj < nb; cj += S) {
+        __syncthreads();
+        if (tid < 128) {
+            const int64_t g = (int64_t)cj * 128 + tid;
+            double s2 = 0.0;
+            for (int k = 0; k < GPIMHIP_MAX_DIM; ++k) {
+                const double v = (k < d && g < N) ? X[g * d + k] / t.ls[k] : 0.0;
+                xz[tid][k] = v;
+                s2 += v * v;
+            }
+            xz[tid][4] = s2;
+            al[tid] = (g < N) ? alpha[g] : 0.0;
+        }
+        __syncthreads();
+        for (int c = half * 64; c < half * 64 + 64; ++c) {
+            double dot = a[0] * xz[c][0];
+            dot = fma(a[1], xz[c][1], dot);
+            dot = fma(a[2], xz[c][2], dot);
+            dot = fma(a[3], xz[c][3], dot);
+            const double r2 = clamp0_nan((an - 2.0 * dot) + xz[c][4]);
+            acc = fma(t.var * kfun_value<KIND>(r2, t.alpha), al[c], acc);
+        }
+    }
+    __syncthreads();
+    if (half == 1) red[r] = acc;
+    __syncthreads();
+    if (half == 0) part[(int64_t)s0 * np + gi] = (gi < N) ? acc + red[r] : 0.0;
+}
+__global__ void kres_final_kernel(const double* __restrict__ y, const double* __restrict__ alpha,
+                                  const double* __restrict__ part, const ThetaDev* __restrict__ th, int64_t N,
+                                  int64_t np, int S, double* __restrict__ res) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= np) return;
+    const int64_t o = (int64_t)blockIdx.y * np;
+    double s = 0.0;
+    for (int q = 0; q < S; ++q) s += part[((int64_t)blockIdx.y * S + q) * np + i];
+    res[o + i] = (i < N) ? (y[o + i] - th[blockIdx.y].diag_add * alpha[o + i]) - s : 0.0;
+}
+__global__ void axpy_kernel(double* __restrict__ x, const double* __restrict__ d, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] += d[i];
+}
+// res <- ypad - K(theta) alpha   (scratch: S * np doubles per problem)
+int launch_kres(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X, int64_t x_bs, int64_t N, double* scratch,
+                int S, double* res) {
+    const int64_t np = h->np;
+    const int nb = (int)(np / NB);
+    dim3 grid(nb * S, h->nbatch), block(256);
+#define KR_LAUNCH(KIND) \
+    hipLaunchKernelGGL((kres_partial_kernel<KIND>), grid, block, 0, h->stream, X, N, m->dim, h->alpha, h->theta, scratch, x_bs, np, S)
+    switch (m->kernel) {
+        case GPIMHIP_KERNEL_RBF: KR_LAUNCH(GPIMHIP_KERNEL_RBF); break;
+        case GPIMHIP_KERNEL_MATERN52: KR_LAUNCH(GPIMHIP_KERNEL_MATERN52); break;
+        case GPIMHIP_KERNEL_RQ: KR_LAUNCH(GPIMHIP_KERNEL_RQ); break;
+        default: gpim_set_error("unknown kernel kind"); return GPIMHIP_E_BADARG;
+    }
+#undef KR_LAUNCH
+    hipLaunchKernelGGL(kres_final_kernel, dim3((unsigned)((np + 255) / 256), h->nbatch), dim3(256), 0, h->stream, h->ypad,
+                       h->alpha, scratch, h->theta, N, np, S, res);
+    HIP_TRY(hipGetLastError());
+    return GPIMHIP_OK;
+}
+int launch_axpy(gpimhip_ctx* h, double* x, const double* d, int64_t n) {
+    hipLaunchKernelGGL(axpy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, x, d, n);
     HIP_TRY(hipGetLastError());
     return GPIMHIP_OK;
 }
@@ -321,8 +447,8 @@ int launch_gemv_t(gpimhip_ctx* h, const double* A, int64_t ld, int64_t nrows, in
 //   S[5]      += delta_ij * (Kinv_ii - alpha_i^2) -> d/d noise
 //   S[6]      += w * s2 * dk/dalpha / s2        -> d/d alpha (RQ)
 // ------------------------------------------------------------------------------------------
-template <int KIND>
-__global__ __launch_bounds__(256) void grad_reduce_kernel(const double* __restrict__ Kinv, int64_t ld,
+template <int KIND, typename R>
+__global__ __launch_bounds__(256) void grad_reduce_kernel(const R* __restrict__ Kinv, int64_t ld,
                                                           const double* __restrict__ X, int64_t N, int d,
                                                           const double* __restrict__ alpha,
                                                           const ThetaDev* __restrict__ th,
@@ -365,13 +491,13 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const double* __restri
         const double ali = al_r[r];
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc) {
-            const d2 kv = *reinterpret_cast<const d2*>(Kinv + gi * ld + (int64_t)cj * 128 + tx * 2 + 32 * cc);
+            const typename Vec2<R>::T kv = *reinterpret_cast<const typename Vec2<R>::T*>(Kinv + gi * ld + (int64_t)cj * 128 + tx * 2 + 32 * cc);
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const int c = tx * 2 + 32 * cc + e;
                 const int64_t gj = (int64_t)cj * 128 + c;
                 if (gi >= N || gj > gi) continue;
-                const double g = kv[e] - ali * al_c[c];
+                const double g = (double)kv[e] - ali * al_c[c];
                 const double w = (gi == gj) ? g : 2.0 * g;
                 double dot = a0 * xz[c][0];
                 dot = fma(a1, xz[c][1], dot);
@@ -409,8 +535,14 @@ int launch_grad_reduce(gpimhip_ctx* h, const gpimhip_model_t* m, const double* K
     const int ntile = nb * (nb + 1) / 2;
     dim3 grid(ntile, h->nbatch), block(256);
 #define GR_LAUNCH(KIND)                                                                                   \
-    hipLaunchKernelGGL((grad_reduce_kernel<KIND>), grid, block, 0, h->stream, Kinv, ld, X, N, m->dim, alpha, \
-                       h->theta, h->grad_part, x_bs, (int64_t)nb * NB)
+    do {                                                                                                  \
+        if (h->fp32)                                                                                      \
+            hipLaunchKernelGGL((grad_reduce_kernel<KIND, float>), grid, block, 0, h->stream, reinterpret_cast<const float*>(Kinv), \
+                               ld, X, N, m->dim, alpha, h->theta, h->grad_part, x_bs, (int64_t)nb * NB);  \
+        else                                                                                              \
+            hipLaunchKernelGGL((grad_reduce_kernel<KIND, double>), grid, block, 0, h->stream, Kinv, ld, X, N, m->dim, alpha, \
+                               h->theta, h->grad_part, x_bs, (int64_t)nb * NB);                           \
+    } while (0)
     switch (m->kernel) {
         case GPIMHIP_KERNEL_RBF: GR_LAUNCH(GPIMHIP_KERNEL_RBF); break;
         case GPIMHIP_KERNEL_MATERN52: GR_LAUNCH(GPIMHIP_KERNEL_MATERN52); break;
@@ -452,7 +584,7 @@ struct FinalizeIter {
 
 __global__ __launch_bounds__(256) void finalize_kernel(gpimhip_model_t m, int64_t N, int64_t np, int nb,
                                                        int ntile, const double* __restrict__ grad_part,
-                                                       const double* __restrict__ z,
+                                                       const double* __restrict__ z, const double* __restrict__ zb,
                                                        const double* __restrict__ logdet_part,
                                                        const ThetaDev* __restrict__ th, double* __restrict__ u,
                                                        double* __restrict__ adam_m, double* __restrict__ adam_v,
@@ -468,6 +600,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(gpimhip_model_t m, int64_
         const int P = 2 + m.n_ls + (m.kernel == GPIMHIP_KERNEL_RQ ? 1 : 0);
         grad_part += b * ntile * 8;
         z += b * np;
+        zb += b * np;
         logdet_part += b * nb;
         th += b;
         u += b * P;
@@ -486,7 +619,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(gpimhip_model_t m, int64_
         if (tid == 0) S[k] = v;
     }
     double q2 = 0.0;
-    for (int64_t i = tid; i < np; i += 256) q2 = fma(z[i], z[i], q2);
+    for (int64_t i = tid; i < np; i += 256) q2 = fma(z[i], zb[i], q2);     // |L^-1 y|^2, or y^T alpha (refined, fp32 matrices)
     q2 = block_sum_256(q2, red);
     double lg = 0.0;
     for (int k = tid; k < nb; k += 256) lg += logdet_part[k];
@@ -519,7 +652,8 @@ int launch_finalize(gpimhip_ctx* h, const gpimhip_model_t* m, int64_t N, int64_t
     const int nb = (int)(np / NB);
     FinalizeIter fi{iter, bc, T, hist_base, loss_base};
     hipLaunchKernelGGL(finalize_kernel, dim3(1, h->nbatch), dim3(256), 0, h->stream, *m, N, np, nb, nb * (nb + 1) / 2,
-                       h->grad_part, h->z, h->logdet_part, h->theta, u, h->adam_m, h->adam_v, do_adam, st,
+                       h->grad_part, h->fp32 ? h->ypad : h->z, h->fp32 ? h->alpha : h->z, h->logdet_part, h->theta, u, h->adam_m,
+                       h->adam_v, do_adam, st,
                        loss_out, grad_out, hist_row, fi, h->info);
     HIP_TRY(hipGetLastError());
     return GPIMHIP_OK;

@@ -27,8 +27,9 @@
 // A: matrix (row-major, ld); kblk: which diagonal block; blockIdx.y: problem of a batch.
 // dinv_all[kblk] <- inverse of the factored block (ld 128, zeros above the diagonal).
 // logdet_out[kblk] = sum_i log L_ii.  info: 1 + first failing global column (set once).
-__global__ __launch_bounds__(NTH, 1) void potf2_kernel(double* __restrict__ A, int64_t ld, int kblk,
-                                                       double* __restrict__ dinv_all,
+template <typename R>
+__global__ __launch_bounds__(NTH, 1) void potf2_kernel(R* __restrict__ A, int64_t ld, int kblk,
+                                                       R* __restrict__ dinv_all,
                                                        double* __restrict__ logdet_out,
                                                        int32_t* __restrict__ info, int nb PROF_ARG) {
     __shared__ __attribute__((aligned(16))) double D[NB * LDD];
@@ -40,7 +41,8 @@ __global__ __launch_bounds__(NTH, 1) void potf2_kernel(double* __restrict__ A, i
     dinv_all += (int64_t)blockIdx.y * nb * NB * NB;
     logdet_out += (int64_t)blockIdx.y * nb;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    double* Ablk = A + ((int64_t)kblk * NB) * ld + (int64_t)kblk * NB;
+    typedef R RV2 __attribute__((ext_vector_type(2)));
+    R* Ablk = A + ((int64_t)kblk * NB) * ld + (int64_t)kblk * NB;
     if (tid == 0) s_bad = 0;
     __syncthreads();
     STAMP(0);
@@ -51,10 +53,10 @@ __global__ __launch_bounds__(NTH, 1) void potf2_kernel(double* __restrict__ A, i
     auto export_row = [&](int i, int t) {
         for (int e = t; e < 16 * 64; e += SINK_THREADS) {
             const int r = i * 16 + (e >> 6), c = (e & 63) * 2;
-            d2 v;
-            v[0] = (c <= r) ? D[r * LDD + c] : 0.0;
-            v[1] = (c + 1 <= r) ? D[r * LDD + c + 1] : 0.0;
-            *reinterpret_cast<d2*>(Ablk + (int64_t)r * ld + c) = v;
+            RV2 v;
+            v[0] = (R)((c <= r) ? D[r * LDD + c] : 0.0);
+            v[1] = (R)((c + 1 <= r) ? D[r * LDD + c + 1] : 0.0);
+            *reinterpret_cast<RV2*>(Ablk + (int64_t)r * ld + c) = v;
         }
     };
     lds_factor_inv<decltype(export_row), true>(D, invd, Xs, 8, &s_bad, tid, export_row);
@@ -71,13 +73,13 @@ __global__ __launch_bounds__(NTH, 1) void potf2_kernel(double* __restrict__ A, i
     }
     STAMP(3);
     STAMP(4);
-    double* dinv = dinv_all + (int64_t)kblk * NB * NB;
+    R* dinv = dinv_all + (int64_t)kblk * NB * NB;
     for (int e = tid; e < NB * NB / 2; e += NTH) {
         const int r = e >> 6, c = (e & 63) * 2;
-        d2 v;
-        v[0] = (c <= r) ? D[r * LDD + c] : 0.0;
-        v[1] = (c + 1 <= r) ? D[r * LDD + c + 1] : 0.0;
-        *reinterpret_cast<d2*>(dinv + r * NB + c) = v;
+        RV2 v;
+        v[0] = (R)((c <= r) ? D[r * LDD + c] : 0.0);
+        v[1] = (R)((c + 1 <= r) ? D[r * LDD + c + 1] : 0.0);
+        *reinterpret_cast<RV2*>(dinv + r * NB + c) = v;
     }
     STAMP(5);
 }
@@ -85,8 +87,12 @@ __global__ __launch_bounds__(NTH, 1) void potf2_kernel(double* __restrict__ A, i
 #ifndef POTF2_PROFILE
 int launch_potf2(gpimhip_ctx* h, double* A, int64_t ld, int kblk, int32_t* info) {
     const int nb = (int)(h->np / NB);
-    hipLaunchKernelGGL(potf2_kernel, dim3(1, h->nbatch), dim3(NTH), 0, h->stream, A, ld, kblk, h->dinv,
-                       h->logdet_part, info, nb);
+    if (h->fp32)
+        hipLaunchKernelGGL(potf2_kernel<float>, dim3(1, h->nbatch), dim3(NTH), 0, h->stream, reinterpret_cast<float*>(A), ld,
+                           kblk, reinterpret_cast<float*>(h->dinv), h->logdet_part, info, nb);
+    else
+        hipLaunchKernelGGL(potf2_kernel<double>, dim3(1, h->nbatch), dim3(NTH), 0, h->stream, A, ld, kblk, h->dinv,
+                           h->logdet_part, info, nb);
     HIP_TRY(hipGetLastError());
     return GPIMHIP_OK;
 }

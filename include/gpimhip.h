@@ -98,6 +98,16 @@ int gpimhip_kmat(gpimhip_handle h, const gpimhip_model_t* m,
                  const double* X, int64_t N, const double* Z, int64_t M,
                  const double* theta, double diag_add, double* out, int64_t ld);
 
+/* Arithmetic of the exact-GP path (gpimhip_nll_grad, gpimhip_fit_exact*, gpimhip_predict_exact*,
+ * gpimhip_acquire_exact): bits = 64 (default) or 32 = the reconstructor's precision='single'
+ * (gpim/gpreg/gpr.py:104-113: float32 tensors end to end).  With 32 the N x N matrices (covariance, factor,
+ * inverse, K* slab) are float and every O(N^3) product runs on v_mfma_f32_16x16x4_f32 (twice the fp64 matrix
+ * rate, half the HBM bytes); diagonal blocks are factored in double and all O(N) vectors, reductions, the
+ * loss, the gradient and Adam stay double (wider than the reference's float32, never narrower).  Inputs and
+ * outputs of the C ABI remain double.  The fused trainer for N <= 128 computes in double on either setting.
+ * Entry points outside that path (kmat, potrf, vfe, dist) require bits = 64.  Switching releases the workspace. */
+int gpimhip_set_precision(gpimhip_handle h, int32_t bits);
+
 /* In-place lower Cholesky of the n x n matrix A (row-major, ld), n any size >= 1;
  * the strict upper triangle is left untouched.  info (device int32): 0, or 1 + first
  * failing column.  Replaces torch.linalg.cholesky inside Pyro (gpr.py:192,248). */

@@ -16,7 +16,7 @@ int main() {
         hipMemcpy(dA, A.data(), n * n * 8, hipMemcpyHostToDevice);
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         hipEventRecord(e0);
-        hipLaunchKernelGGL(potf2_kernel, dim3(1), dim3(512), 0, 0, dA, (int64_t)n, 0, dinv, ld, info, 1, prof);
+        hipLaunchKernelGGL(potf2_kernel<double>, dim3(1), dim3(512), 0, 0, dA, (int64_t)n, 0, dinv, ld, info, 1, prof);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         hipMemcpy(hp, prof, 32 * 8, hipMemcpyDeviceToHost);
