@@ -225,6 +225,32 @@ def extra_configs(gpim):
                                               "(reconstructor(structured=True)), RBF, T=200",
                                   "seconds": dt, "grid_points_per_s": cube4.size / dt,
                                   "ms_per_adam_iteration": dt / (5 * 200) * 1e3}
+    # C2 in single precision: the headline workload with reconstructor(precision='single') (float matrices, fp32
+    # matrix cores; gpimhip_set_precision) -- NOT the headline number, whose dtype is the reference's default f64
+    from problems import lattice_image
+    import gc
+    del bo
+    gc.collect()                      # handles of the earlier configs (and their side streams) go away
+    R2, _ = lattice_image(size=WORKLOAD["size"], frac=WORKLOAD["frac"], seed=1)
+    X2, Xf2 = gpim.utils.get_sparse_grid(R2), gpim.utils.get_full_grid(R2)
+    kw2 = dict(kernel=WORKLOAD["kernel"], lengthscale=WORKLOAD["lengthscale"], learning_rate=WORKLOAD["learning_rate"],
+               verbose=0, seed=0, precision="single")
+    rec2 = gpim.reconstructor(X2.astype(np.float32), R2.astype(np.float32), Xf2.astype(np.float32), iterations=2, **kw2)
+    rec2.run()                                                                         # workspace / plan warm-up
+    rec2.iterations = WORKLOAD["iterations"]
+    sync(); t0 = time.perf_counter()
+    rec2.train()
+    sync(); t1 = time.perf_counter()
+    rec2.predict()
+    sync(); dt = time.perf_counter() - t0
+    print("C2 single: train %.3f s, predict %.3f s" % (t1 - t0, dt - (t1 - t0)), file=sys.stderr)
+    n2, T2 = rec2.X.shape[0], WORKLOAD["iterations"]
+    flop2 = T2 * float(n2) ** 3 + 2 * float(n2) ** 3 / 3 + float(n2) ** 2 * R2.size
+    out["C2_single_precision"] = {"workload": "the headline workload with precision='single': 256x256, N=%d, M=%d, Matern52, "
+                                              "T=%d, fit + predict" % (n2, R2.size, T2),
+                                  "dtype": "f32 matrices and MFMA; f64 diagonal blocks, vectors, loss, gradient, Adam",
+                                  "seconds": dt, "grid_points_per_s": R2.size / dt, "tflops": flop2 / dt / 1e12,
+                                  "mfma_frac_of_fp32_peak": flop2 / dt / 1e12 / 157.3}
     return out
 
 

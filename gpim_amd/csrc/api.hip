@@ -4,6 +4,7 @@
 #include <string.h>
 #include <stdlib.h>
 #include <algorithm>
+#include <mutex>
 #include "common.hpp"
 
 // kernels implemented in the other translation units
@@ -376,38 +377,58 @@ static GemmArgs gemm_args(const double* A, int64_t lda, const double* B, int64_t
 // trail_next(p) touches exactly the columns panel(p+1) factors; trail_rest(p) touches the columns to
 // the right of them, so the two streams never write the same tile.  Both join the caller's stream
 // before the next round.
-// Side streams are created on first use: a process only has a few hardware queues (four by
-// default), and once more streams exist than queues the panel and bulk streams of the look-ahead
-// schedule end up sharing one and serialise (measured: +7 ms per factorisation at N = 16384 with one
-// extra stream).  Handles that only ever run the fused small-N trainer create none.
+// Side streams are created on first use and then SHARED by every handle of the device for the life of the
+// process: HIP maps streams onto a few hardware queues (four by default), and which queue a new stream gets depends
+// on every stream the process has created and destroyed before.  With side streams per handle the third handle of
+// a process that needed them ran its look-ahead 4-14 ms per factorisation slower than the first (N = 16384; panel,
+// bulk or the caller's stream ending up on one queue) -- a fixed set created once keeps the mapping, and the speed,
+// independent of the process's history.  Work of different handles on a shared stream only serialises (every
+// cross-stream dependency is an event of the handle that recorded it).  Handles that only ever run the fused
+// small-N trainer use none.
+struct SideStreams {
+    hipStream_t panel = nullptr, bulk = nullptr, capture = nullptr;
+    bool lookahead_tried = false, capture_tried = false;
+};
+static std::mutex g_side_mutex;
+static SideStreams g_side[64];
+
 static void ensure_lookahead_streams(gpimhip_ctx* h) {
     if (h->side_streams_tried) return;
     h->side_streams_tried = true;
-    int lo = 0, hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // hi = numerically lowest = highest priority
-    if (hipStreamCreateWithPriority(&h->panel_stream, hipStreamNonBlocking, hi) != hipSuccess) {
-        h->panel_stream = nullptr;                   // fall back to the in-order schedule
-        return;
+    std::lock_guard<std::mutex> lock(g_side_mutex);
+    SideStreams& S = g_side[h->device & 63];
+    if (!S.lookahead_tried) {
+        S.lookahead_tried = true;
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // hi = numerically lowest = highest priority
+        if (hipStreamCreateWithPriority(&S.panel, hipStreamNonBlocking, hi) != hipSuccess) S.panel = nullptr;
+        // The bulk trailing updates run on a stream whose CU mask leaves RESERVED_CUS compute units
+        // free (the mask is interleaved over the XCDs: 16 reserved = 2 per XCD, tools/cumask_probe.hip):
+        // potf2 needs ~135 KB of LDS, i.e. a whole CU, and would otherwise wait until the bulk kernel
+        // (2 x 74 KB per CU, thousands of workgroups queued) has drained.
+        hipDeviceProp_t prop;
+        if (S.panel && hipGetDeviceProperties(&prop, h->device) == hipSuccess && !getenv("GPIMHIP_NO_CUMASK")) {
+            const int ncu = prop.multiProcessorCount;
+            std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+            int reserved = RESERVED_CUS;
+            if (const char* e = getenv("GPIMHIP_RESERVED_CUS")) reserved = std::max(1, std::min(ncu / 2, atoi(e)));
+            for (int c = reserved; c < ncu; ++c) mask[c / 32] |= (1u << (c % 32));
+            if (hipExtStreamCreateWithCUMask(&S.bulk, (uint32_t)mask.size(), mask.data()) != hipSuccess) S.bulk = nullptr;
+        }
     }
-    // The bulk trailing updates run on a stream whose CU mask leaves RESERVED_CUS compute units
-    // free (the mask is interleaved over the XCDs: 16 reserved = 2 per XCD, tools/cumask_probe.hip):
-    // potf2 needs ~135 KB of LDS, i.e. a whole CU, and would otherwise wait until the bulk kernel
-    // (2 x 74 KB per CU, thousands of workgroups queued) has drained.
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && !getenv("GPIMHIP_NO_CUMASK")) {
-        const int ncu = prop.multiProcessorCount;
-        std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
-        int reserved = RESERVED_CUS;
-        if (const char* e = getenv("GPIMHIP_RESERVED_CUS")) reserved = std::max(1, std::min(ncu / 2, atoi(e)));
-        for (int c = reserved; c < ncu; ++c) mask[c / 32] |= (1u << (c % 32));
-        if (hipExtStreamCreateWithCUMask(&h->bulk_stream, (uint32_t)mask.size(), mask.data()) != hipSuccess)
-            h->bulk_stream = nullptr;
-    }
+    h->panel_stream = S.panel;                       // null: fall back to the in-order schedule
+    h->bulk_stream = S.bulk;
 }
 hipStream_t ensure_capture_stream(gpimhip_ctx* h) {
     if (!h->capture_stream && !h->capture_stream_tried) {
         h->capture_stream_tried = true;
-        if (hipStreamCreateWithFlags(&h->capture_stream, hipStreamNonBlocking) != hipSuccess) h->capture_stream = nullptr;
+        std::lock_guard<std::mutex> lock(g_side_mutex);
+        SideStreams& S = g_side[h->device & 63];
+        if (!S.capture_tried) {
+            S.capture_tried = true;
+            if (hipStreamCreateWithFlags(&S.capture, hipStreamNonBlocking) != hipSuccess) S.capture = nullptr;
+        }
+        h->capture_stream = S.capture;
     }
     return h->capture_stream;
 }
@@ -764,9 +785,7 @@ int gpimhip_destroy(gpimhip_handle h) {
     for (auto e : h->ra_ev)
         if (e) (void)hipEventDestroy(e);
     if (h->pinned_info) (void)hipHostFree(h->pinned_info);
-    if (h->panel_stream) (void)hipStreamDestroy(h->panel_stream);
-    if (h->bulk_stream) (void)hipStreamDestroy(h->bulk_stream);
-    if (h->capture_stream) (void)hipStreamDestroy(h->capture_stream);
+    // the side streams belong to the process (ensure_lookahead_streams), not to the handle
     delete h;
     return GPIMHIP_OK;
 }

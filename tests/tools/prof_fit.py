@@ -10,7 +10,7 @@ N, T = int(sys.argv[1]), int(sys.argv[2])
 M = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 kind = sys.argv[4] if len(sys.argv) > 4 else "RBF"
 dev = torch.device("cuda:0")
-H = _lib.Handle(); lib = H.lib
+H = _lib.Handle(precision=os.environ.get("PROF_PRECISION", "double")); lib = H.lib
 side = int(np.ceil(np.sqrt(N * 4)))
 rng = np.random.default_rng(0)
 flat = rng.choice(side * side, size=N, replace=False); flat.sort()
