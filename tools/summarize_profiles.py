@@ -26,9 +26,9 @@ lau = lambda k: "true, true" in k
 fl, n = avg(f, "FETCH_SIZE", lau)
 wl, _ = avg(w, "WRITE_SIZE", lau)
 tr, _ = avg(f, "FETCH_SIZE", lambda k: "trmv_lower" in k)
-lau_ms = float(stats["void gemm_tiles_kernel<true, true, 0, 4, 128, 128>(GemmArgs)"]["AverageNs"]) / 1e6
+lau_ms = float(stats["void gemm_tiles_kernel<double, true, true, 0, 4, 128, 128>(GemmArgs)"]["AverageNs"]) / 1e6
 out = {
-    "kernel": "gemm_tiles_kernel<true, true, 0, 4, 128, 128> (K^-1 = L^-T L^-1)", "N": N, "launches_sampled": n,
+    "kernel": "gemm_tiles_kernel<double, true, true, 0, 4, 128, 128> (K^-1 = L^-T L^-1)", "N": N, "launches_sampled": n,
     "FETCH_SIZE_KB_raw": fl, "WRITE_SIZE_KB_raw": wl,
     "calibration": {"trmv_lower_kernel_FETCH_SIZE_KB": tr, "its_true_read_KB": N * N / 2 * 8 / 1024,
                     "ratio": tr / (N * N / 2 * 8 / 1024),
@@ -65,9 +65,9 @@ def hbm_row(label, pred, statname):
     return "| %s | %.2f GB | %.0f us | %.1f TB/s |" % (label, byts / 1e9, ns / 1e3, byts / ns / 1e3)
 hbm = ["| kernel | bytes moved (FETCH x2 + WRITE) | duration | rate (peak ~ 8 TB/s) |", "|---|---|---|---|",
        hbm_row("`trmv_lower_kernel` (z = L^-1 y)", lambda k: "trmv_lower" in k, "trmv_lower_kernel"),
-       hbm_row("`kmat_kernel<1>` (lower tiles of K; one fp64 `exp` per entry)", lambda k: "kmat_kernel" in k, "kmat_kernel<1>"),
+       hbm_row("`kmat_kernel<1, double>` (lower tiles of K; one fp64 `exp` per entry)", lambda k: "kmat_kernel" in k, "kmat_kernel<1"),
        hbm_row("`gemv_t_kernel` (alpha = L^-T z; triangular: the first column block alone is 8 MB for one workgroup)", lambda k: "gemv_t" in k, "gemv_t_kernel"),
-       hbm_row("`grad_reduce_kernel<1>` (K^-1 . dK/dtheta sums; kernel derivative recomputed per entry)", lambda k: "grad_reduce" in k, "grad_reduce_kernel<1>")]
+       hbm_row("`grad_reduce_kernel<1, double>` (K^-1 . dK/dtheta sums; kernel derivative recomputed per entry)", lambda k: "grad_reduce" in k, "grad_reduce_kernel<1")]
 
 readme = open(os.path.join(P, "README.md")).read()
 readme = re.sub(r"<!-- MFMA_TABLE -->.*?<!-- /MFMA_TABLE -->", "<!-- MFMA_TABLE -->\n" + mfma_table + "\n<!-- /MFMA_TABLE -->", readme, flags=re.S)
