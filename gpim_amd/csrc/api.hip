@@ -1,6 +1,7 @@
 // api.hip -- host side of libgpimhip: workspace, launch plans, blocked-algorithm drivers and the
 // extern "C" entry points declared in include/gpimhip.h.
 #include <math.h>
+#include <stdio.h>
 #include <string.h>
 #include <stdlib.h>
 #include <algorithm>
@@ -1055,7 +1056,7 @@ int gpimhip_acquire_exact(gpimhip_handle h, const gpimhip_model_t* m, const doub
         if (h->acq_tmp_cap < 2 * Mobs + 2) {
             HIP_TRY(hipStreamSynchronize(h->stream));
             dev_free(h, &h->acq_tmp, h->acq_tmp_cap);
-    dev_free(h, &h->refine, h->refine_cap);
+
             h->acq_tmp_cap = 0;
             GP_TRY(dev_alloc(h, &h->acq_tmp, 2 * Mobs + 2));
             h->acq_tmp_cap = 2 * Mobs + 2;

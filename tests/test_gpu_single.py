@@ -174,3 +174,48 @@ def test_single_precision_not_positive_definite_is_reported(eng):
     rc = H32.lib.gpimhip_nll_grad(H32.h, ctypes.byref(m), _lib.ptr(Xd), _lib.ptr(yd), len(X), _lib.ptr(ud),
                                   ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(out.data_ptr() + 8))
     assert rc == _lib.E_NOT_PD
+
+
+@pytest.mark.parametrize("N", [150, 700])
+def test_acquire_exact_on_single_precision_handle(eng, N):
+    """The one-call acquisition entry point on a single-precision handle (slab path: the fused small-N kernel reads
+    L^-1 in double) against the double-precision handle."""
+    _lib, H32, H64 = eng
+    X, y, kp, spec, u, _ = problem(N, 2, "Matern52", seed=N + 5)
+    side = X.max() + 1
+    g = np.stack(np.meshgrid(np.linspace(0, side, 40), np.linspace(0, side, 40), indexing="ij"), -1).reshape(-1, 2)
+    out = {}
+    for name, H in (("s", H32), ("d", H64)):
+        Xd, yd, ud, gd = (torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in (X, y, u.numpy(), g))
+        M = len(g)
+        mean = torch.empty(M, dtype=torch.float64, device="cuda")
+        sd, acq = torch.empty_like(mean), torch.empty_like(mean)
+        m = spec.struct()
+        _lib.check(H.lib.gpimhip_acquire_exact(H.h, ctypes.byref(m), _lib.ptr(Xd), _lib.ptr(yd), N, _lib.ptr(ud),
+                                               _lib.ptr(gd), M, _lib.ptr(Xd), N, _lib.ACQ_IDS["ei"], 0.0, 0.01, None,
+                                               _lib.ptr(mean), _lib.ptr(sd), _lib.ptr(acq)))
+        out[name] = (mean.cpu().numpy(), sd.cpu().numpy(), acq.cpu().numpy())
+    assert_allclose(out["s"][0], out["d"][0], rtol=0, atol=2e-4)
+    assert_allclose(out["s"][1], out["d"][1], rtol=2e-3, atol=1e-5)
+    assert_allclose(out["s"][2], out["d"][2], rtol=0, atol=2e-3 * (np.abs(out["d"][2]).max() + 1e-12))
+
+
+def test_slices_and_bo_in_single_precision(ensure_built, tmp_path):
+    import gpim_amd as gpim
+    from gpim_amd import dist as gdist
+    from tests.problems import hyperspectral_cube, bo_test_problem
+    cube, _ = hyperspectral_cube(size=24, nspec=3, keep=0.4, seed=1)
+    kw = dict(kernel="RBF", lengthscale=[[1., 1.], [12., 12.]], learning_rate=0.1, iterations=30)
+    md, sd_ = gdist.reconstruct_slices(cube, axis=-1, batch=3, **kw)
+    ms, ss = gdist.reconstruct_slices(cube.astype(np.float32), axis=-1, batch=3, precision="single", **kw)
+    assert np.isfinite(ms).all() and np.isfinite(ss).all()
+    # float32 initial draws differ from the float64 ones (as in the reference): same model family, nearby optimum
+    assert np.abs(ms - md).max() < 0.2 and np.abs(ss - sd_).max() < 0.2
+    func, Z = bo_test_problem()
+    bo = gpim.boptimizer(gpim.utils.get_sparse_grid(Z), Z, gpim.utils.get_full_grid(Z), func, acquisition_function="ei",
+                         exploration_steps=4, gp_iterations=100, verbose=0, precision="single",
+                         filename=str(tmp_path / "bo"))
+    bo.run()
+    assert len(bo.indices_all) == 4 and all(0 <= i < 25 and 0 <= j < 25 for i, j in bo.indices_all)
+    mean, sd = bo.gp_predictions[-1]
+    assert np.asarray(mean).dtype == np.float32 and np.isfinite(np.asarray(mean)).all()
