@@ -416,7 +416,7 @@ def main():
                           "the Cholesky stage (its trailing updates are the <false,false,0,8,128,128> instance)",
                 "stages": stages,
                 "dominant_launch": {
-                    "kernel": "gemm_tiles_kernel<double, true, true, 0, 4, 128, 128> (K^-1 = L^-T L^-1: exactly one launch "
+                    "kernel": "gemm_tiles_kernel<true, true, 0, 4, 128, 128> (K^-1 = L^-T L^-1: exactly one launch "
                               "per Adam iteration, N^3/3 flop)",
                     "launches": lau_n, "avg_launch_ms": lau_ms / max(lau_n, 1),
                     "achieved": (n3 / 3 / (lau_ms / lau_n * 1e-3) / 1e12) if lau_n else None,

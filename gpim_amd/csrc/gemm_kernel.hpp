@@ -1,79 +1,89 @@
-// gemm.hip -- the fp64 MFMA tile engine of libgpimhip.
-//
-// One kernel template covers every O(N^3) stage of the exact-GP hot path
-// (SURVEY 8(a) rows a6, a8, a11): Cholesky panel solves and trailing SYRK updates,
-// the triangular inverse, K^-1 = L^-T L^-1 and the predictive-variance product
-// L^-1 K(X, X*).  Work is described by a list of 128x128 output tiles, each with its own
-// k-block range, so triangular operands simply get shorter ranges (no wasted MFMAs on
-// structural zeros) and the host can order the list for XCD/L2 locality.
-//
-// Tile engine: 256 threads = 4 waves (2x2), each wave owns a 64x64 sub-tile = 4x4
-// v_mfma_f64_16x16x4_f64 accumulators (128 VGPRs).  Two more shapes serve launches that cannot fill
-// the chip with one 4-wave workgroup per 128x128 tile: 8 waves per tile (two MFMA waves on every
-// SIMD of the tile's CU) and 64x64 sub-tiles (a 128x128 tile spread over 4 CUs) -- the panel
-// solves / in-panel updates of the Cholesky are latency-bound chains of such small launches.
-// Operand tiles are double-buffered in LDS, one barrier per 16-deep k-step.  128-wide tiles are staged
-// global -> LDS directly (global_load_lds_dwordx4, one wave-wide 16-byte load per 1 KB of LDS, no
-// VGPR staging and no ds_write); 64-wide tiles go global -> registers -> LDS.  Every global access is
-// a coalesced 16-byte load whatever the transpose:
-//   "KM" operand (row-major, m contiguous):  lds[16][128+16]; one load per k-row
-//   "MK" operand (row-major, k contiguous):  1 KB groups of 8 rows x 8 chunks, chunk index XOR row
-//                                            (direct), or lds[64][16+2] (through registers)
-// The MFMA block of a k-step runs at raised wave priority (s_setprio).
-// v_mfma_f64_16x16x4_f64 lane maps (cdna_hip_programming.md section 3):
-//   A[l&15][l>>4], B[l>>4][l&15], C/D col = l&15, row = (l>>4) + 4*reg.
+// gemm_kernel.hpp -- the tile engine of gemm.hip written once for both element types (kernel template + launch
+// dispatch by shape); instantiated for float in gemm32.hip (precision = 'single').  The double kernels of
+// gemm.hip are the same algorithm in its original, non-generic form (see the note there).  Design notes: gemm.hip.
+#pragma once
 #include <stdlib.h>
 #include "common.hpp"
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
 
-#define LD_MK (GEMM_BK + 2)
+// The engine is written once for both element types (precision = 'double' / 'single' of the reconstructor,
+// gpim/gpreg/gpr.py:104-113).  What depends on the type:
+//   CH    16-byte chunk (2 doubles / 4 floats), EPC elements per chunk
+//   BK    k-depth of one LDS stage = 8 chunks = 128 bytes of a k-contiguous row (16 doubles / 32 floats), so the
+//         byte geometry of every staging scheme is the same for both types
+//   MFMA  v_mfma_f64_16x16x4_f64 (64 cycles) / v_mfma_f32_16x16x4_f32 (32 cycles): same A/B lane maps, different
+//         C/D row map -- f64: row = (lane>>4) + 4*reg, f32: row = 4*(lane>>4) + reg (cdna_hip_programming.md 3)
+template <typename R> struct RT;
+template <> struct RT<double> {
+    typedef d2 CH; typedef d4 ACC;
+    static constexpr int EPC = 2, BK = 16;
+    static __device__ __forceinline__ ACC mfma(double a, double b, ACC c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ int drow(int lane, int reg) { return (lane >> 4) + 4 * reg; }
+};
+template <> struct RT<float> {
+    typedef f4 CH; typedef f4 ACC;
+    static constexpr int EPC = 4, BK = 32;
+    static __device__ __forceinline__ ACC mfma(float a, float b, ACC c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ int drow(int lane, int reg) { return 4 * (lane >> 4) + reg; }
+};
+
+// padded row strides of the register-staged LDS layouts (elements): k-contiguous rows BK + one chunk, m-contiguous
+// rows TS + 16 -- both spread the four k-rows of a fragment read over distinct banks for either type
+#define LD_MK_OF(R) (RT<R>::BK + RT<R>::EPC)
 
 // TS = tile side handled by one workgroup (128 or 64); NT = threads.  One staged operand tile is
-// TS x 16 doubles = 8*TS 16-byte chunks whatever its orientation.
-template <bool KM, int NT, int TS>
-__device__ __forceinline__ void stage_load(d2 (&r)[8 * TS / NT], const double* __restrict__ base, int64_t ld,
+// TS x BK elements = 8*TS 16-byte chunks whatever its orientation and type.
+template <typename R, bool KM, int NT, int TS>
+__device__ __forceinline__ void stage_load(typename RT<R>::CH (&r)[8 * TS / NT], const R* __restrict__ base, int64_t ld,
                                            int64_t mrow0, int64_t kcol0, int tid) {
     // MK: tile element (m,k) lives at base[(mrow0+m)*ld + kcol0 + k]
     // KM: tile element (k,m) lives at base[(kcol0+k)*ld + mrow0 + m]
+    typedef typename RT<R>::CH CH;
+    constexpr int EPC = RT<R>::EPC;
 #pragma unroll
     for (int i = 0; i < 8 * TS / NT; ++i) {
         const int c = tid + NT * i;
         if (!KM) {
             const int row = c >> 3, c16 = c & 7;
-            r[i] = *reinterpret_cast<const d2*>(base + (mrow0 + row) * ld + kcol0 + c16 * 2);
+            r[i] = *reinterpret_cast<const CH*>(base + (mrow0 + row) * ld + kcol0 + c16 * EPC);
         } else {
-            const int krow = c / (TS / 2), c16 = c % (TS / 2);
-            r[i] = *reinterpret_cast<const d2*>(base + (kcol0 + krow) * ld + mrow0 + c16 * 2);
+            const int krow = c / (TS / EPC), c16 = c % (TS / EPC);
+            r[i] = *reinterpret_cast<const CH*>(base + (kcol0 + krow) * ld + mrow0 + c16 * EPC);
         }
     }
 }
 
-template <bool KM, int NT, int TS>
-__device__ __forceinline__ void stage_store(const d2 (&r)[8 * TS / NT], double* lds, int tid) {
+template <typename R, bool KM, int NT, int TS>
+__device__ __forceinline__ void stage_store(const typename RT<R>::CH (&r)[8 * TS / NT], R* lds, int tid) {
+    typedef typename RT<R>::CH CH;
+    constexpr int EPC = RT<R>::EPC;
 #pragma unroll
     for (int i = 0; i < 8 * TS / NT; ++i) {
         const int c = tid + NT * i;
         if (!KM) {
             const int row = c >> 3, c16 = c & 7;
-            *reinterpret_cast<d2*>(lds + row * LD_MK + c16 * 2) = r[i];
+            *reinterpret_cast<CH*>(lds + row * LD_MK_OF(R) + c16 * EPC) = r[i];
         } else {
-            const int krow = c / (TS / 2), c16 = c % (TS / 2);
-            *reinterpret_cast<d2*>(lds + krow * (TS + 16) + c16 * 2) = r[i];
+            const int krow = c / (TS / EPC), c16 = c % (TS / EPC);
+            *reinterpret_cast<CH*>(lds + krow * (TS + 16) + c16 * EPC) = r[i];
         }
     }
 }
 
-// Direct global -> LDS staging (global_load_lds_dwordx4) of an m-contiguous ("KM") operand tile with
+// Direct global -> LDS staging (global_load_lds_dwordx4) of an m-contiguous ("KM") fp64 operand tile with
 // TS = 128: one k-row is 128 doubles = 1 KB = one wave-wide 16-byte load, written by the hardware to
 // lds[krow][lane*2 .. lane*2+1] without passing through VGPRs -- no ds_write, no register staging.
 // Tracked by vmcnt; the caller waits for vmcnt(0) before the barrier that publishes the stage.
 // (tools/gemm_ablate.hip: 66.1 -> 68.5 TFLOP/s for the loop with both operands staged this way.)
+// (fp32: a k-row is only half a wave-wide load and two rows would land back to back, without the padding that
+// keeps fragment reads conflict free -- m-contiguous float tiles go through registers.)
 template <int NW>
 __device__ __forceinline__ void stage_direct_km(const double* __restrict__ base, int64_t ld, int64_t mrow0,
                                                 int64_t kcol0, double* lds, int wave, int lane) {
-    constexpr int ROWS = GEMM_BK / NW;      // k-rows per wave
+    constexpr int ROWS = 16 / NW;           // k-rows per wave
 #pragma unroll
     for (int i = 0; i < ROWS; ++i) {
         const int krow = wave * ROWS + i;
@@ -83,42 +93,45 @@ __device__ __forceinline__ void stage_direct_km(const double* __restrict__ base,
     }
 }
 
-// The same for a k-contiguous ("MK") operand tile with TS = 128 rows of 16 doubles (128 B): one wave-wide
+// The same for a k-contiguous ("MK") operand tile of TS rows of 128 bytes (16 doubles / 32 floats): one wave-wide
 // load fetches 8 rows x 8 sixteen-byte chunks (fully coalesced: whole 128-byte lines) and lands as one
 // contiguous 1 KB group in LDS.  LDS position p = lane of the group holds row p>>3, chunk (p&7) ^ (p>>3):
-// the XOR swizzle spreads the fragment reads over the banks (element (m,k) sits at
-// (m>>3)*128 + ((m&7)*8 + ((k>>1) ^ (m&7)))*2 + (k&1); two rows 8 apart share a bank, nothing worse --
+// the XOR swizzle spreads the fragment reads over the banks (element (m,k) sits in chunk (k / EPC) ^ (m&7) of
+// row m&7 of group m>>3; two rows 8 apart share a bank, nothing worse --
 // 0.4 TFLOP/s in tools/gemm_ablate.hip against the padded [128][18] layout it replaces).
-template <int NW, int TS>
-__device__ __forceinline__ void stage_direct_mk(const double* __restrict__ base, int64_t ld, int64_t mrow0,
-                                                int64_t kcol0, double* lds, int wave, int lane) {
+template <typename R, int NW, int TS>
+__device__ __forceinline__ void stage_direct_mk(const R* __restrict__ base, int64_t ld, int64_t mrow0,
+                                                int64_t kcol0, R* lds, int wave, int lane) {
     constexpr int GROUPS = (TS / 8) / NW;   // 8-row groups per wave
+    constexpr int EPC = RT<R>::EPC;
     const int r8 = lane >> 3, c8 = (lane & 7) ^ r8;
 #pragma unroll
     for (int i = 0; i < GROUPS; ++i) {
         const int q = wave * GROUPS + i;
         __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void*)(base + (mrow0 + q * 8 + r8) * ld + kcol0 + c8 * 2),
-            (__attribute__((address_space(3))) void*)(lds + q * 128), 16, 0, 0);
+            (const __attribute__((address_space(1))) void*)(base + (mrow0 + q * 8 + r8) * ld + kcol0 + c8 * EPC),
+            (__attribute__((address_space(3))) void*)(lds + q * (64 * EPC)), 16, 0, 0);
     }
 }
-__device__ __forceinline__ double frag_mk_swz(const double* lds, int m0, int kk, int lane) {
+template <typename R>
+__device__ __forceinline__ R frag_mk_swz(const R* lds, int m0, int kk, int lane) {
+    constexpr int EPC = RT<R>::EPC;
     const int m = m0 + (lane & 15), k = kk * 4 + (lane >> 4);
-    return lds[(m >> 3) * 128 + ((m & 7) * 8 + ((k >> 1) ^ (m & 7))) * 2 + (k & 1)];
+    return lds[(m >> 3) * (64 * EPC) + ((m & 7) * 8 + ((k / EPC) ^ (m & 7))) * EPC + (k % EPC)];
 }
 
-template <bool KM, int NW, int TS>
-__device__ __forceinline__ void stage_direct(const double* __restrict__ base, int64_t ld, int64_t mrow0, int64_t kcol0,
-                                             double* lds, int wave, int lane) {
-    if (KM) stage_direct_km<NW>(base, ld, mrow0, kcol0, lds, wave, lane);
-    else stage_direct_mk<NW, TS>(base, ld, mrow0, kcol0, lds, wave, lane);
+template <typename R, bool KM, int NW, int TS>
+__device__ __forceinline__ void stage_direct(const R* __restrict__ base, int64_t ld, int64_t mrow0, int64_t kcol0,
+                                             R* lds, int wave, int lane) {
+    if constexpr (KM) stage_direct_km<NW>(base, ld, mrow0, kcol0, lds, wave, lane);   // fp64 only (see ADIR / BDIR)
+    else stage_direct_mk<R, NW, TS>(base, ld, mrow0, kcol0, lds, wave, lane);
 }
 
-template <bool KM, int TS>
-__device__ __forceinline__ double frag(const double* lds, int m0, int kk, int lane) {
+template <typename R, bool KM, int TS>
+__device__ __forceinline__ R frag(const R* lds, int m0, int kk, int lane) {
     // element (m = m0 + (lane&15), k = kk*4 + (lane>>4)) of the staged tile; both layouts are
-    // bank-conflict free for ds_read_b64: [TS][18] (18 % 32 == 18 -> rows spread), [16][TS+16]
-    if (!KM) return lds[(m0 + (lane & 15)) * LD_MK + kk * 4 + (lane >> 4)];
+    // bank-conflict free: [TS][BK + chunk] (rows spread), [BK][TS+16]
+    if (!KM) return lds[(m0 + (lane & 15)) * LD_MK_OF(R) + kk * 4 + (lane >> 4)];
     return lds[(kk * 4 + (lane >> 4)) * (TS + 16) + m0 + (lane & 15)];
 }
 
@@ -129,8 +142,12 @@ __device__ __forceinline__ double frag(const double* lds, int m0, int kk, int la
 //   (4,  64,  64)  2x2 waves of 32x32 on a quadrant: few tiles, each spread over four CUs
 //   (8,  64, 128)  4x2 waves of 16x64 on a row half: in-place panel solves (a workgroup must own
 //                  whole rows of the tile it overwrites), each tile spread over two CUs
-template <bool A_KM, bool B_KM, int EPI, int NW, int TSM, int TSN>
-__global__ __launch_bounds__(NW * 64, 2) void gemm_tiles_kernel(GemmArgs g) {
+template <typename R, bool A_KM, bool B_KM, int EPI, int NW, int TSM, int TSN>
+__global__ __launch_bounds__(NW * 64, 2) void gemm_tiles_kernel_t(GemmArgs g) {
+    typedef typename RT<R>::CH CH;
+    typedef typename RT<R>::ACC ACC;
+    constexpr int BK = RT<R>::BK;           // k-depth of one stage
+    constexpr int KSTEPS = BK / 4;          // MFMA k-steps per stage
     constexpr int NT = NW * 64;             // threads
     constexpr int WGM = NW / 2;             // waves along m (2 along n)
     constexpr int WROWS = TSM / WGM;        // rows per wave
@@ -138,12 +155,13 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_tiles_kernel(GemmArgs g) {
     constexpr int MT = WROWS / 16;          // 16x16 accumulators per wave: MT x NTL
     constexpr int NTL = WCOLS / 16;
     constexpr int TSX = TSM > TSN ? TSM : TSN;
-    constexpr int STAGE = (TSX * LD_MK > GEMM_BK * (TSX + 16)) ? TSX * LD_MK : GEMM_BK * (TSX + 16);
+    constexpr int STAGE = (TSX * LD_MK_OF(R) > BK * (TSX + 16)) ? TSX * LD_MK_OF(R) : BK * (TSX + 16);
     constexpr int NCHA = 8 * TSM / NT, NCHB = 8 * TSN / NT;   // 16-byte chunks per thread per stage
-    // staged straight into LDS: every 128-wide operand tile, and 64-wide k-contiguous ones (a 64-wide
-    // m-contiguous k-row is only half a wave-wide load)
-    constexpr bool ADIR = TSM == 128 || !A_KM, BDIR = TSN == 128 || !B_KM;
-    __shared__ __attribute__((aligned(16))) double smem[4 * STAGE];
+    // staged straight into LDS: every k-contiguous operand tile, and 128-wide m-contiguous fp64 ones (a 64-wide
+    // m-contiguous k-row, or a float one, is only half a wave-wide load)
+    constexpr bool F64 = sizeof(R) == 8;
+    constexpr bool ADIR = !A_KM || (F64 && TSM == 128), BDIR = !B_KM || (F64 && TSN == 128);
+    __shared__ __attribute__((aligned(16))) R smem[4 * STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
 
@@ -174,12 +192,13 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_tiles_kernel(GemmArgs g) {
     }
     TileDesc t = g.tiles[p];
     if (g.kfix1 > g.kfix0) { t.kb0 = g.kfix0; t.kb1 = g.kfix1; }
-    const int nsteps = (t.kb1 - t.kb0) * (NB / GEMM_BK);
+    const int nsteps = (t.kb1 - t.kb0) * (NB / BK);
     const int qi = (quad / QN) * TSM, qj = (quad % QN) * TSN;
-    // batch: blockIdx.y selects the problem; operands advance by their per-problem strides
-    g.A += blockIdx.y * g.sA;
-    g.B += blockIdx.y * g.sB;
-    if (g.C) g.C += blockIdx.y * g.sC;
+    // batch: blockIdx.y selects the problem; operands advance by their per-problem strides.  The pointers of
+    // GemmArgs are typed double* on the host side whatever the handle's precision.
+    const R* gA = reinterpret_cast<const R*>(g.A) + blockIdx.y * g.sA;
+    const R* gB = reinterpret_cast<const R*>(g.B) + blockIdx.y * g.sB;
+    R* gC = g.C ? reinterpret_cast<R*>(g.C) + blockIdx.y * g.sC : nullptr;
     if (g.colpart) g.colpart += blockIdx.y * g.sColpart;
 
     // operand origins (element units)
@@ -188,94 +207,94 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_tiles_kernel(GemmArgs g) {
     const int64_t b_n0 = (int64_t)(t.cj + (B_KM ? g.b_coff : g.b_roff)) * NB + qj;
     const int64_t b_k0 = (int64_t)(t.kb0 + (B_KM ? g.b_roff : g.b_coff)) * NB;
 
-    d4 acc[MT][NTL];
+    ACC acc[MT][NTL];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < NTL; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+        for (int j = 0; j < NTL; ++j) acc[i][j] = (ACC){0, 0, 0, 0};
 
     // krev: walk the k-range from its END.  Tiles of one patch whose ranges share their upper end
     // (K^-1 = L^-T L^-1: [ci, nb)) then sweep the same operand rows at the same time, so the panels
     // they share are still in the XCD's L2 when the next tile asks for them.
-    const int64_t kfirst = g.krev ? (int64_t)(nsteps - 1) * GEMM_BK : 0;
-    const int64_t kstride = g.krev ? -GEMM_BK : GEMM_BK;
-    d2 ra[NCHA], rb[NCHB];
+    const int64_t kfirst = g.krev ? (int64_t)(nsteps - 1) * BK : 0;
+    const int64_t kstride = g.krev ? -BK : BK;
+    CH ra[NCHA], rb[NCHB];
     if (nsteps > 0) {
-        if (ADIR) stage_direct<A_KM, NW, TSM>(g.A, g.lda, a_m0, a_k0 + kfirst, smem, wave, lane);
-        else stage_load<A_KM, NT, TSM>(ra, g.A, g.lda, a_m0, a_k0 + kfirst, tid);
-        if (BDIR) stage_direct<B_KM, NW, TSN>(g.B, g.ldb, b_n0, b_k0 + kfirst, smem + STAGE, wave, lane);
-        else stage_load<B_KM, NT, TSN>(rb, g.B, g.ldb, b_n0, b_k0 + kfirst, tid);
-        if (!ADIR) stage_store<A_KM, NT, TSM>(ra, smem, tid);
-        if (!BDIR) stage_store<B_KM, NT, TSN>(rb, smem + STAGE, tid);
+        if constexpr (ADIR) stage_direct<R, A_KM, NW, TSM>(gA, g.lda, a_m0, a_k0 + kfirst, smem, wave, lane);
+        else stage_load<R, A_KM, NT, TSM>(ra, gA, g.lda, a_m0, a_k0 + kfirst, tid);
+        if constexpr (BDIR) stage_direct<R, B_KM, NW, TSN>(gB, g.ldb, b_n0, b_k0 + kfirst, smem + STAGE, wave, lane);
+        else stage_load<R, B_KM, NT, TSN>(rb, gB, g.ldb, b_n0, b_k0 + kfirst, tid);
+        if constexpr (!ADIR) stage_store<R, A_KM, NT, TSM>(ra, smem, tid);
+        if constexpr (!BDIR) stage_store<R, B_KM, NT, TSN>(rb, smem + STAGE, tid);
         if (ADIR || BDIR) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
 
     for (int s = 0; s < nsteps; ++s) {
-        const double* As = smem + (s & 1) * 2 * STAGE;
-        const double* Bs = As + STAGE;
+        const R* As = smem + (s & 1) * 2 * STAGE;
+        const R* Bs = As + STAGE;
         const bool more = (s + 1 < nsteps);
         if (more) {
             // the other stage buffer was last read in step s-1: every wave is past that barrier
-            double* An = smem + ((s + 1) & 1) * 2 * STAGE;
+            R* An = smem + ((s + 1) & 1) * 2 * STAGE;
             const int64_t koff = kfirst + (int64_t)(s + 1) * kstride;
-            if (ADIR) stage_direct<A_KM, NW, TSM>(g.A, g.lda, a_m0, a_k0 + koff, An, wave, lane);
-            else stage_load<A_KM, NT, TSM>(ra, g.A, g.lda, a_m0, a_k0 + koff, tid);
-            if (BDIR) stage_direct<B_KM, NW, TSN>(g.B, g.ldb, b_n0, b_k0 + koff, An + STAGE, wave, lane);
-            else stage_load<B_KM, NT, TSN>(rb, g.B, g.ldb, b_n0, b_k0 + koff, tid);
+            if constexpr (ADIR) stage_direct<R, A_KM, NW, TSM>(gA, g.lda, a_m0, a_k0 + koff, An, wave, lane);
+            else stage_load<R, A_KM, NT, TSM>(ra, gA, g.lda, a_m0, a_k0 + koff, tid);
+            if constexpr (BDIR) stage_direct<R, B_KM, NW, TSN>(gB, g.ldb, b_n0, b_k0 + koff, An + STAGE, wave, lane);
+            else stage_load<R, B_KM, NT, TSN>(rb, gB, g.ldb, b_n0, b_k0 + koff, tid);
         }
         // The MFMA block runs at raised wave priority: the arbiter then prefers this wave's MFMAs and
         // fragment reads over the other resident wave's staging instructions, which otherwise steal
         // issue slots from the matrix pipe (tools/gemm_ablate.hip: 66.1 -> 71.2 TFLOP/s for this loop).
         __builtin_amdgcn_s_setprio(3);
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            double a[MT], bb[NTL];
+        for (int kk = 0; kk < KSTEPS; ++kk) {
+            R a[MT], bb[NTL];
 #pragma unroll
             for (int i = 0; i < MT; ++i)
-                a[i] = (ADIR && !A_KM) ? frag_mk_swz(As, wm * WROWS + i * 16, kk, lane)
-                                       : frag<A_KM, TSM>(As, wm * WROWS + i * 16, kk, lane);
+                a[i] = (ADIR && !A_KM) ? frag_mk_swz<R>(As, wm * WROWS + i * 16, kk, lane)
+                                       : frag<R, A_KM, TSM>(As, wm * WROWS + i * 16, kk, lane);
 #pragma unroll
             for (int j = 0; j < NTL; ++j)
-                bb[j] = (BDIR && !B_KM) ? frag_mk_swz(Bs, wn * WCOLS + j * 16, kk, lane)
-                                        : frag<B_KM, TSN>(Bs, wn * WCOLS + j * 16, kk, lane);
+                bb[j] = (BDIR && !B_KM) ? frag_mk_swz<R>(Bs, wn * WCOLS + j * 16, kk, lane)
+                                        : frag<R, B_KM, TSN>(Bs, wn * WCOLS + j * 16, kk, lane);
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int j = 0; j < NTL; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bb[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NTL; ++j) acc[i][j] = RT<R>::mfma(a[i], bb[j], acc[i][j]);
         }
         __builtin_amdgcn_s_setprio(0);
         if (more) {
-            double* An = smem + ((s + 1) & 1) * 2 * STAGE;
-            if (!ADIR) stage_store<A_KM, NT, TSM>(ra, An, tid);
-            if (!BDIR) stage_store<B_KM, NT, TSN>(rb, An + STAGE, tid);
+            R* An = smem + ((s + 1) & 1) * 2 * STAGE;
+            if constexpr (!ADIR) stage_store<R, A_KM, NT, TSM>(ra, An, tid);
+            if constexpr (!BDIR) stage_store<R, B_KM, NT, TSN>(rb, An + STAGE, tid);
             if (ADIR || BDIR) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads();
     }
 
     if (EPI == EPI_STORE) {
-        const int64_t crow0 = (int64_t)(t.ci + g.c_roff) * NB + qi + wm * WROWS + (lane >> 4);
+        // element (16-row band i, reg rg) of the wave's sub-tile sits in row crow0 + i*16 + drow(lane, rg)
+        const int64_t crow0 = (int64_t)(t.ci + g.c_roff) * NB + qi + wm * WROWS;
         const int64_t ccol0 = (int64_t)(t.cj + g.c_coff) * NB + qj + wn * WCOLS + (lane & 15);
-        const double alpha = g.alpha, beta = g.beta;
-        if (beta != 0.0) {
+        const R alpha = (R)g.alpha, beta = (R)g.beta;
+        if (g.beta != 0.0) {
             // accumulate into C: fetch one 16-row band of the wave's sub-tile (NTL x 4 values per lane)
             // with all loads in flight, then combine and store -- element by element the loads and
             // stores serialise into 2 x 64 memory round trips per tile
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
-                double cv[NTL][4];
+                R cv[NTL][4];
 #pragma unroll
                 for (int j = 0; j < NTL; ++j)
 #pragma unroll
                     for (int rg = 0; rg < 4; ++rg)
-                        cv[j][rg] = g.C[(crow0 + i * 16 + 4 * rg) * g.ldc + ccol0 + j * 16];
+                        cv[j][rg] = gC[(crow0 + i * 16 + RT<R>::drow(lane, rg)) * g.ldc + ccol0 + j * 16];
 #pragma unroll
                 for (int j = 0; j < NTL; ++j)
 #pragma unroll
                     for (int rg = 0; rg < 4; ++rg)
-                        g.C[(crow0 + i * 16 + 4 * rg) * g.ldc + ccol0 + j * 16] = alpha * acc[i][j][rg] + beta * cv[j][rg];
+                        gC[(crow0 + i * 16 + RT<R>::drow(lane, rg)) * g.ldc + ccol0 + j * 16] = alpha * acc[i][j][rg] + beta * cv[j][rg];
             }
         } else {
 #pragma unroll
@@ -284,18 +303,19 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_tiles_kernel(GemmArgs g) {
                 for (int j = 0; j < NTL; ++j)
 #pragma unroll
                     for (int rg = 0; rg < 4; ++rg)
-                        g.C[(crow0 + i * 16 + 4 * rg) * g.ldc + ccol0 + j * 16] = alpha * acc[i][j][rg];
+                        gC[(crow0 + i * 16 + RT<R>::drow(lane, rg)) * g.ldc + ccol0 + j * 16] = alpha * acc[i][j][rg];
         }
     } else {
-        // column sums of squares of the 128x128 product tile -> colpart[ci][cj*128 + col]  (full tiles only)
-        double* red = smem;      // [WGM][128]; all waves are past the last barrier of the k-loop
+        // column sums of squares of the 128x128 product tile -> colpart[ci][cj*128 + col]  (full tiles only);
+        // accumulated and stored in double for either element type
+        double* red = reinterpret_cast<double*>(smem);      // [WGM][128]; all waves are past the last barrier of the k-loop
 #pragma unroll
         for (int j = 0; j < NTL; ++j) {
             double s = 0.0;
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int rg = 0; rg < 4; ++rg) s += acc[i][j][rg] * acc[i][j][rg];
+                for (int rg = 0; rg < 4; ++rg) s += (double)acc[i][j][rg] * (double)acc[i][j][rg];
             s += __shfl_xor(s, 16);
             s += __shfl_xor(s, 32);
             if (lane < 16) red[wm * 128 + wn * WCOLS + j * 16 + lane] = s;
@@ -319,54 +339,47 @@ static int mid_tiles() {
     return v;
 }
 
-template <bool A_KM, bool B_KM, int EPI>
+template <typename R, bool A_KM, bool B_KM, int EPI>
 static int launch_one(gpimhip_ctx* h, const GemmArgs& g) {
     if (g.ntiles <= 0) return GPIMHIP_OK;
     const int64_t total = (int64_t)g.ntiles * h->nbatch;
     const bool small = total <= 256 && !getenv("GPIMHIP_NO_TILE64");
     if (EPI == EPI_STORE && small && !g.inplace)
         // few tiles: spread each over four CUs (64x64 quadrants)
-        hipLaunchKernelGGL((gemm_tiles_kernel<A_KM, B_KM, EPI_STORE, 4, 64, 64>), dim3(g.ntiles * 4, h->nbatch),
+        hipLaunchKernelGGL((gemm_tiles_kernel_t<R, A_KM, B_KM, EPI_STORE, 4, 64, 64>), dim3(g.ntiles * 4, h->nbatch),
                            dim3(256), 0, h->stream, g);
     else if (EPI == EPI_STORE && small)
         // in-place panel solve: row halves (the workgroup owns the rows it overwrites), 8 waves
-        hipLaunchKernelGGL((gemm_tiles_kernel<A_KM, B_KM, EPI_STORE, 8, 64, 128>), dim3(g.ntiles * 2, h->nbatch),
+        hipLaunchKernelGGL((gemm_tiles_kernel_t<R, A_KM, B_KM, EPI_STORE, 8, 64, 128>), dim3(g.ntiles * 2, h->nbatch),
                            dim3(512), 0, h->stream, g);
     else if (EPI == EPI_STORE && total > 256 && total <= mid_tiles())
         // one tile per CU (see mid_tiles()).  Not for the column-sum epilogue: its cross-wave summation order
         // follows the wave layout, and batched and stand-alone predictions must stay bit-identical.
-        hipLaunchKernelGGL((gemm_tiles_kernel<A_KM, B_KM, EPI, 8, 128, 128>), dim3(g.ntiles, h->nbatch), dim3(512),
+        hipLaunchKernelGGL((gemm_tiles_kernel_t<R, A_KM, B_KM, EPI, 8, 128, 128>), dim3(g.ntiles, h->nbatch), dim3(512),
                            24 * 1024, h->stream, g);
     else if (total <= 256 || (!A_KM && !B_KM && !getenv("GPIMHIP_NT_4WAVE")) || getenv("GPIMHIP_ALL_8WAVE"))
         // (also every SYRK-shaped update of the Cholesky: measured 8 % faster factorisation at N = 16384,
         // the 512-thread workgroups interleave better with the concurrent panel chain)
         // at most one tile per CU: 8-wave workgroup so every SIMD still holds two MFMA waves
-        hipLaunchKernelGGL((gemm_tiles_kernel<A_KM, B_KM, EPI, 8, 128, 128>), dim3(g.ntiles, h->nbatch), dim3(512), 0,
+        hipLaunchKernelGGL((gemm_tiles_kernel_t<R, A_KM, B_KM, EPI, 8, 128, 128>), dim3(g.ntiles, h->nbatch), dim3(512), 0,
                            h->stream, g);
     else
-        hipLaunchKernelGGL((gemm_tiles_kernel<A_KM, B_KM, EPI, 4, 128, 128>), dim3(g.ntiles, h->nbatch), dim3(256), 0,
+        hipLaunchKernelGGL((gemm_tiles_kernel_t<R, A_KM, B_KM, EPI, 4, 128, 128>), dim3(g.ntiles, h->nbatch), dim3(256), 0,
                            h->stream, g);
     HIP_TRY(hipGetLastError());
     return GPIMHIP_OK;
 }
 
-// Single-precision handles (gpimhip_set_precision) run the float instantiation of the same engine, written once
-// for both element types in gemm_kernel.hpp and compiled in gemm32.hip.  The double kernels stay the hand-tuned
-// source of this file: instantiating the generic template for double gives the same instruction counts but a
-// schedule that is 0.5 - 0.9 % slower on the triangular inverse and the factorisation at N = 16384 (A/B on one box).
-int launch_gemm_f32(gpimhip_ctx* h, bool a_km, bool b_km, int epi, const GemmArgs& g);
-static int launch_gemm_f64(gpimhip_ctx* h, bool a_km, bool b_km, int epi, const GemmArgs& g) {
+template <typename R>
+static int launch_gemm_t(gpimhip_ctx* h, bool a_km, bool b_km, int epi, const GemmArgs& g) {
     if (epi == EPI_STORE) {
-        if (!a_km && !b_km) return launch_one<false, false, EPI_STORE>(h, g);   // NT
-        if (!a_km && b_km) return launch_one<false, true, EPI_STORE>(h, g);     // NN
-        if (a_km && b_km) return launch_one<true, true, EPI_STORE>(h, g);       // TN
+        if (!a_km && !b_km) return launch_one<R, false, false, EPI_STORE>(h, g);   // NT
+        if (!a_km && b_km) return launch_one<R, false, true, EPI_STORE>(h, g);     // NN
+        if (a_km && b_km) return launch_one<R, true, true, EPI_STORE>(h, g);       // TN
     } else {
-        if (!a_km && b_km) return launch_one<false, true, EPI_COLSUMSQ>(h, g);
+        if (!a_km && b_km) return launch_one<R, false, true, EPI_COLSUMSQ>(h, g);
     }
     gpim_set_error("launch_gemm: unsupported operand layout combination");
     return GPIMHIP_E_BADARG;
 }
 
-int launch_gemm(gpimhip_ctx* h, bool a_km, bool b_km, int epi, const GemmArgs& g) {
-    return h->fp32 ? launch_gemm_f32(h, a_km, b_km, epi, g) : launch_gemm_f64(h, a_km, b_km, epi, g);
-}

@@ -26,9 +26,9 @@ lau = lambda k: "true, true" in k
 fl, n = avg(f, "FETCH_SIZE", lau)
 wl, _ = avg(w, "WRITE_SIZE", lau)
 tr, _ = avg(f, "FETCH_SIZE", lambda k: "trmv_lower" in k)
-lau_ms = float(stats["void gemm_tiles_kernel<double, true, true, 0, 4, 128, 128>(GemmArgs)"]["AverageNs"]) / 1e6
+lau_ms = float(stats["void gemm_tiles_kernel<true, true, 0, 4, 128, 128>(GemmArgs)"]["AverageNs"]) / 1e6
 out = {
-    "kernel": "gemm_tiles_kernel<double, true, true, 0, 4, 128, 128> (K^-1 = L^-T L^-1)", "N": N, "launches_sampled": n,
+    "kernel": "gemm_tiles_kernel<true, true, 0, 4, 128, 128> (K^-1 = L^-T L^-1)", "N": N, "launches_sampled": n,
     "FETCH_SIZE_KB_raw": fl, "WRITE_SIZE_KB_raw": wl,
     "calibration": {"trmv_lower_kernel_FETCH_SIZE_KB": tr, "its_true_read_KB": N * N / 2 * 8 / 1024,
                     "ratio": tr / (N * N / 2 * 8 / 1024),
