@@ -307,9 +307,8 @@ def _fit_once(_lib, H, N, T, seed):
     """T Adam iterations on a seeded problem through one handle; returns (history, final u)."""
     from gpim_amd.kernels import KernelSpec
     X, y = scattered(N, 2, seed=seed, grid=64 if N <= 3000 else 128)
-    torch.manual_seed(seed)
     spec = KernelSpec("RBF", 2, [[1., 1.], [20., 20.]], jitter=1e-5)
-    u = spec.draw_initial_u().cuda()
+    u = spec.draw_initial_u(generator=torch.Generator().manual_seed(seed)).cuda()      # private: thread-safe
     m = spec.struct()
     Xd, yd = X.cuda().contiguous(), y.cuda().contiguous()
     hist = torch.empty(T, spec.n_params, dtype=torch.float64, device="cuda")
@@ -363,3 +362,40 @@ def test_user_stream_matches_default_stream(eng, N, T):
             H2.close()
     s.synchronize()
     assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+
+
+def test_concurrent_handles_share_side_streams(eng):
+    """The capture / panel / bulk side streams are per device, shared by all handles (api.hip:
+    ensure_lookahead_streams).  Two threads, each with its own handle on its own torch stream, train at the same
+    time in the look-ahead regime (N = 6200) and in the graph-replayed regime (N = 800): every cross-stream
+    dependency is an event of the handle that recorded it, so the interleaving on the shared streams cannot mix
+    the two models up -- results are bit-identical to the sequential ones."""
+    import threading
+    _lib, H = eng
+    jobs = [(6200, 2, 11), (800, 10, 12), (6200, 2, 13), (800, 10, 14)]
+    want = [_fit_once(_lib, H, N, T, seed) for N, T, seed in jobs]
+    got = [None] * len(jobs)
+    errors = []
+
+    def work(i):
+        try:
+            N, T, seed = jobs[i]
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                Hi = _lib.Handle()
+                try:
+                    got[i] = _fit_once(_lib, Hi, N, T, seed)
+                finally:
+                    Hi.close()
+            s.synchronize()
+        except Exception as e:                                   # surfaced in the main thread
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(jobs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for g, w, job in zip(got, want, jobs):
+        assert np.array_equal(g[0], w[0]) and np.array_equal(g[1], w[1]), job
