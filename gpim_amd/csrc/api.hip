@@ -101,6 +101,7 @@ static void ws_release_matrix(gpimhip_ctx* h) {
     dev_free(h, &h->B, mat_doubles(h, B * np * h->ld));
     dev_free(h, &h->Tm, mat_doubles(h, B * np * h->ld));
     dev_free(h, &h->dinv, mat_doubles(h, B * nb * NB * NB));
+    dev_free(h, &h->dinvB, B * nb * NB * NB);
     dev_free(h, &h->ypad, B * np);
     dev_free(h, &h->z, B * np);
     dev_free(h, &h->alpha, B * np);
@@ -110,6 +111,9 @@ static void ws_release_matrix(gpimhip_ctx* h) {
     dev_free(h, &h->adam_m, B * MAXP);
     dev_free(h, &h->adam_v, B * MAXP);
     dev_free(h, &h->iter, B);
+    // the trailing-update tile lists of the distributed factorisation cover block rows up to nb - 1
+    for (auto& d : h->dist_lists) dev_free(h, &d.tiles, d.n);
+    h->dist_lists.clear();
     h->np = 0;
     h->ws_batch = 0;
 }
@@ -139,6 +143,7 @@ static int ws_ensure_b(gpimhip_ctx* h, int64_t N, int B, int padded, bool matric
                       (rc = dev_alloc(h, &h->B, mat_doubles(h, B * np * ld))) ||
                       (rc = dev_alloc(h, &h->Tm, mat_doubles(h, B * np * ld))))) ||
         (rc = dev_alloc(h, &h->dinv, mat_doubles(h, B * nb * NB * NB))) ||
+        (matrices && !h->fp32 && (rc = dev_alloc(h, &h->dinvB, B * nb * NB * NB))) ||
         (rc = dev_alloc(h, &h->ypad, B * np)) || (rc = dev_alloc(h, &h->z, B * np)) ||
         (rc = dev_alloc(h, &h->alpha, B * np)) || (rc = dev_alloc(h, &h->logdet_part, B * nb)) ||
         (rc = dev_alloc(h, &h->grad_part, B * nb * (nb + 1) / 2 * 8)) || (rc = dev_alloc(h, &h->theta, (int64_t)B)) ||
@@ -150,10 +155,16 @@ static int ws_ensure_b(gpimhip_ctx* h, int64_t N, int B, int padded, bool matric
     if (h->fp32 && h->refine_cap < 10 * (int64_t)B * np) {
         dev_free(h, &h->refine, h->refine_cap);
         h->refine_cap = 0;
-        GP_TRY(dev_alloc(h, &h->refine, 10 * (int64_t)B * np));
+        if ((rc = dev_alloc(h, &h->refine, 10 * (int64_t)B * np))) {
+            ws_release_matrix(h);       // the next call with this N must not take the early return without it
+            return rc;
+        }
         h->refine_cap = 10 * (int64_t)B * np;
     }
-    return plan_ensure(h, (int)nb);
+    GP_TRY(plan_ensure(h, (int)nb));
+    // (the step schedule's plan too: building it synchronises the stream, which a graph capture does not allow)
+    if (h->dinvB) GP_TRY(step_plan_ensure(h, (int)nb));
+    return GPIMHIP_OK;
 }
 int ws_ensure(gpimhip_ctx* h, int64_t N) { return ws_ensure_b(h, N, h->nbatch, 0); }
 static int ws_ensure_padded(gpimhip_ctx* h, int64_t N) { return ws_ensure_b(h, N, h->nbatch, 1); }
@@ -420,6 +431,13 @@ static void ensure_lookahead_streams(gpimhip_ctx* h) {
     h->panel_stream = S.panel;                       // null: fall back to the in-order schedule
     h->bulk_stream = S.bulk;
 }
+// The capture stream is shared by every handle of a device: two threads fitting at the same time must not
+// interleave their Begin..EndCapture sections on it (the second BeginCapture would fail and that fit would
+// silently run un-graphed).  Capture itself is short (host-side recording of one iteration).
+static std::mutex g_capture_mutex[64];
+void capture_lock(gpimhip_ctx* h) { g_capture_mutex[h->device & 63].lock(); }
+void capture_unlock(gpimhip_ctx* h) { g_capture_mutex[h->device & 63].unlock(); }
+
 hipStream_t ensure_capture_stream(gpimhip_ctx* h) {
     if (!h->capture_stream && !h->capture_stream_tried) {
         h->capture_stream_tried = true;
@@ -453,7 +471,22 @@ static int panel_steps(gpimhip_ctx* h, double* A, int64_t ld, int32_t* info, int
     return GPIMHIP_OK;
 }
 
+// Which schedule factors a matrix of order np: the single-stream step schedule of cholstep.hip (the launch that
+// factors a diagonal block hosts the trailing-update tiles) up to STEP_MAX_NP, the two-stream look-ahead below
+// beyond it (measured, potrf alone: 0.51 vs 0.66 ms at 1280, 1.86 vs 2.72 at 4224, 6.4 vs 7.05 at 8192, but
+// 33.3 - 35.2 vs 33.0 at 16384, where one workgroup per CU -- the occupancy the 134 KB diagonal-block role
+// imposes on the hosting launch -- costs the bulk tiles 7 %).
+static int64_t step_max_np() {
+    static const int64_t v = getenv("GPIMHIP_STEP_MAX_NP") ? atoll(getenv("GPIMHIP_STEP_MAX_NP")) : 12288;
+    return v;
+}
+static bool use_step_schedule(const gpimhip_ctx* h, int64_t np) {
+    static const bool off = getenv("GPIMHIP_OLD_POTRF") != nullptr;
+    return !off && !h->fp32 && h->dinvB != nullptr && np < step_max_np();
+}
+
 int launch_potrf(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_t* info) {
+    if (use_step_schedule(h, np)) return launch_potrf_steps(h, A, np, ld, info);
     const int nb = (int)(np / NB);
     GP_TRY(plan_ensure(h, nb));
     const LinalgPlan& P = h->plan;
@@ -629,7 +662,7 @@ static int loss_grad_at_u(gpimhip_ctx* h, const gpimhip_model_t* m, const double
     // In the look-ahead regime the panel stream exists and is idle after the factorisation: the two
     // HBM-bound mat-vecs over L^-1 run there, next to the MFMA-bound K^-1 product (both only read L^-1).
     const bool side = h->panel_stream != nullptr && (int)((np / NB + OUTER_W - 1) / OUTER_W) >= LOOKAHEAD_MIN_PANELS &&
-                      h->ev_pool.size() >= 2;
+                      h->ev_pool.size() >= 2 && !use_step_schedule(h, np);
     GP_TRY(factor_at_u(h, m, X, x_bs, N, u, side));
     if (side) {
         hipStream_t main_s = h->stream;
@@ -781,7 +814,7 @@ int gpimhip_destroy(gpimhip_handle h) {
     dev_free(h, &h->theta1, 1);
     dev_free(h, &h->info, 4);
     if (h->plan.d_tiles) (void)hipFree(h->plan.d_tiles);
-    for (auto& d : h->dist_lists) dev_free(h, &d.tiles, d.n);
+    step_plan_release(h);
     for (auto e : h->ev_pool) (void)hipEventDestroy(e);
     for (auto e : h->ra_ev)
         if (e) (void)hipEventDestroy(e);
@@ -887,19 +920,21 @@ static int fit_impl(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X, i
     // of one launch call per kernel.  Not used with the multi-stream look-ahead schedule (large N,
     // where launch cost is irrelevant), while stage timing is on, or for very short fits.
     const int npanel = (int)((h->np / NB + OUTER_W - 1) / OUTER_W);
-    bool use_graph = T >= 8 && !h->timing && npanel < LOOKAHEAD_MIN_PANELS && ensure_capture_stream(h) &&
-                     !getenv("GPIMHIP_NO_GRAPH");
+    bool use_graph = T >= 8 && !h->timing && (npanel < LOOKAHEAD_MIN_PANELS || use_step_schedule(h, h->np)) &&
+                     ensure_capture_stream(h) && !getenv("GPIMHIP_NO_GRAPH");
     if (use_graph) {
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;
         hipStream_t main_s = h->stream;
         h->stream = h->capture_stream;
+        capture_lock(h);
         hipError_t e = hipStreamBeginCapture(h->capture_stream, hipStreamCaptureModeRelaxed);
         int rc = GPIMHIP_OK;
         if (e == hipSuccess) {
             rc = loss_grad_at_u(h, m, X, x_bs, N, u, 1, st, nullptr, nullptr, nullptr, &tab);
             e = hipStreamEndCapture(h->capture_stream, &graph);
         }
+        capture_unlock(h);
         h->stream = main_s;
         if (rc != GPIMHIP_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
         if (e == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {

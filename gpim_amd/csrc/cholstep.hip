@@ -1,0 +1,270 @@
+// cholstep.hip -- the blocked Cholesky as a single in-order stream of two kinds of launches (SURVEY 8(a) row a6;
+// replaces torch.linalg.cholesky at gpim/gpreg/gpr.py:192,248).
+//
+// The diagonal-block factorisation (potf2, one workgroup, 128 serial pivots, ~36 us) is the one step of the
+// factorisation that cannot be spread over the chip.  Instead of hiding it behind a second stream, its launch
+// HOSTS the trailing update: workgroup 0 of `chol_step_kernel` factors block j, every other workgroup of the same
+// launch computes one tile of pending trailing-update work with the MFMA tile engine ("fillers").  To make enough
+// filler work independent of block j the update order is left-looking inside a window of two outer panels and
+// right-looking beyond it:
+//
+//   H_j  (chol_step_kernel)   potf2(j)  ||  column j, rows i > j:  A[i,j] -= sum_{c in [p0(j)-W, j)} L[i,c] L[j,c]^T
+//                                       ||  a share of bulk(P-1): tiles (i,jj), jj >= p0(P)+W, -= L[i,P-1] L[jj,P-1]^T
+//   F_j  (panel_solve_kernel) L[i,j] = A[i,j] * inv(L[j,j])^T for all rows i > j, one-shot: the whole strip and the
+//                             inverse (in MFMA operand order, written by potf2) are fetched with every load in
+//                             flight at once -- no k-loop of load/barrier/compute rounds
+//   D_j  (tile engine)        the next diagonal tiles (jj,jj), j < jj < p1(j)+W:  A[jj,jj] -= L[jj,j] L[jj,j]^T
+//
+// P = outer panel of W = 4 block columns, p0/p1 its first / one-past-last column.  Per block column the chain is
+// H_j -> F_j -> D_j; nothing else is ever on it.  Every tile receives each k-block exactly once: columns of the
+// two most recent panels through the left-looking column updates (off-diagonal) or D (diagonal), older ones
+// through bulk() -- see build_step_plan().
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include "potf2_body.hpp"
+#include "gemm_body.hpp"
+
+#define STEP_W 4
+
+struct StepArgs {
+    double* A; int64_t ld; int kblk; int nb;
+    double* dinv_all; double* dinvB_all; double* logdet; int32_t* info;
+    GemmArgs g;                 // filler tiles (NT, alpha = -1, beta = 1)
+};
+
+// blockIdx.x == 0: potf2 of block kblk; 1..7: idle (keeps filler b on XCD b % 8, which the tile engine's
+// XCD-aware list mapping assumes); >= 8: filler tile b - 8.  FTS: 128 = one workgroup per 128x128 tile,
+// 64 = one per 64x64 quadrant (few tiles: spread each over four CUs).
+template <int FTM, int FTN>
+__global__ __launch_bounds__(NTH, 1) void chol_step_kernel(StepArgs a) {
+    constexpr int SM = POTF2_SMEM_DOUBLES > gemm_smem_doubles<FTM, FTN>() ? POTF2_SMEM_DOUBLES : gemm_smem_doubles<FTM, FTN>();
+    __shared__ __attribute__((aligned(16))) double smem[SM];
+    const int b = blockIdx.x;
+    if (b >= 8) {
+        gemm_tile_body<false, false, EPI_STORE, 8, FTM, FTN>(a.g, b - 8, (int)blockIdx.y, smem);
+        return;
+    }
+    if (b != 0) return;
+    potf2_body<double>(smem, (int)blockIdx.y, a.A, a.ld, a.kblk, a.dinv_all, a.dinvB_all, a.logdet, a.info, a.nb);
+}
+
+// Panel solve, one workgroup (4 waves) per 32-row strip of the block column below the diagonal block:
+// S = P * Dinv^T, in place.  Wave w owns the 16-column tiles w and 7 - w of the strip (Dinv is lower triangular:
+// tile t needs k-steps 0 .. 4t+3, so every wave runs 36 of them per 16 rows).
+__global__ __launch_bounds__(256) void panel_solve_kernel(double* __restrict__ A, int64_t ld, int kblk, int nb,
+                                                          const double* __restrict__ dinvB_all) {
+    constexpr int LDS_LD = 130;             // 130 % 32 == 2: the A-fragment reads below are bank-conflict free
+    __shared__ __attribute__((aligned(16))) double S[32 * LDS_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    A += (int64_t)blockIdx.y * nb * NB * ld;
+    const d2* DB = reinterpret_cast<const d2*>(dinvB_all + ((int64_t)blockIdx.y * nb + kblk) * (NB * NB));
+    double* P = A + ((int64_t)(kblk + 1) * NB + (int64_t)blockIdx.x * 32) * ld + (int64_t)kblk * NB;
+    // the strip: one 1 KB row per wave-wide load, global -> LDS directly
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = wave * 8 + i;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(P + (int64_t)row * ld + lane * 2),
+                                         (__attribute__((address_space(3))) void*)(S + row * LDS_LD), 16, 0, 0);
+    }
+    // B fragments of both tiles: 18 sixteen-byte loads per lane, all in flight
+    const int t0 = wave, t1 = 7 - wave, n0 = 2 * t0 + 2;
+    d2 bf[18];
+#pragma unroll
+    for (int q = 0; q < 18; ++q) {
+        const int t = q < n0 ? t0 : t1, s2 = q < n0 ? q : q - n0;
+        bf[q] = DB[(t * 16 + s2) * 64 + lane];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const d4 zero = (d4){0.0, 0.0, 0.0, 0.0};
+    d4 acc[2][2] = {{zero, zero}, {zero, zero}};
+    const double* Sa = S + (lane & 15) * LDS_LD + (lane >> 4);
+#pragma unroll
+    for (int q = 0; q < 18; ++q) {
+        const bool first = q < n0;          // wave-uniform
+        const int s2 = first ? q : q - n0;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int s = 2 * s2 + e;
+            const double a0 = Sa[4 * s], a1 = Sa[16 * LDS_LD + 4 * s];
+            if (first) {
+                acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bf[q][e], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bf[q][e], acc[0][1], 0, 0, 0);
+            } else {
+                acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bf[q][e], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bf[q][e], acc[1][1], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+        const int t = x == 0 ? t0 : t1;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg)
+                P[(int64_t)(mt * 16 + (lane >> 4) + 4 * rg) * ld + t * 16 + (lane & 15)] = acc[x][mt][rg];
+    }
+}
+
+// Diagonal tiles (jj,jj), jj = kblk+1 .. kblk+ntile, -= L[jj,kblk] L[jj,kblk]^T, one workgroup (4 waves, one
+// 16x16 MFMA tile each) per 32x32 quadrant of the lower half; one-shot like the panel solve: both 32x128
+// operand strips go straight to LDS, the C values to registers, all loads in flight together.
+__global__ __launch_bounds__(256) void diag_update_kernel(double* __restrict__ A, int64_t ld, int kblk, int nb) {
+    constexpr int LDS_LD = 130;
+    __shared__ __attribute__((aligned(16))) double S[64 * LDS_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    A += (int64_t)blockIdx.y * nb * NB * ld;
+    const int jj = kblk + 1 + blockIdx.x / 10, q = blockIdx.x % 10;
+    // q -> (a, b), a >= b, a, b in 0..3
+    const int a = q < 1 ? 0 : q < 3 ? 1 : q < 6 ? 2 : 3, b = q - a * (a + 1) / 2;
+    const double* Pa = A + ((int64_t)jj * NB + a * 32) * ld + (int64_t)kblk * NB;
+    const double* Pb = A + ((int64_t)jj * NB + b * 32) * ld + (int64_t)kblk * NB;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = wave * 8 + i;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Pa + (int64_t)row * ld + lane * 2),
+                                         (__attribute__((address_space(3))) void*)(S + row * LDS_LD), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Pb + (int64_t)row * ld + lane * 2),
+                                         (__attribute__((address_space(3))) void*)(S + (32 + row) * LDS_LD), 16, 0, 0);
+    }
+    const int wm = wave >> 1, wn = wave & 1;
+    double* C = A + ((int64_t)jj * NB + a * 32 + wm * 16 + (lane >> 4)) * ld + (int64_t)jj * NB + b * 32 + wn * 16 + (lane & 15);
+    double cv[4];
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) cv[rg] = C[(int64_t)(4 * rg) * ld];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    d4 acc0 = (d4){0.0, 0.0, 0.0, 0.0}, acc1 = acc0;      // two chains: a lone dependent fp64 MFMA chain issues at half rate
+    const double* Sa = S + (wm * 16 + (lane & 15)) * LDS_LD + (lane >> 4);
+    const double* Sb = S + (32 + wn * 16 + (lane & 15)) * LDS_LD + (lane >> 4);
+#pragma unroll
+    for (int s = 0; s < 32; s += 2) {
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Sa[4 * s], Sb[4 * s], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Sa[4 * s + 4], Sb[4 * s + 4], acc1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) C[(int64_t)(4 * rg) * ld] = cv[rg] - (acc0[rg] + acc1[rg]);
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+static void lower_patches(std::vector<TileDesc>& out, int lo, int hi, int kb0, int kb1) {
+    for (int ig = lo / 8; ig <= (hi - 1) / 8; ++ig)
+        for (int jg = lo / 8; jg <= ig; ++jg)
+            for (int i = std::max(lo, ig * 8); i < std::min(hi, ig * 8 + 8); ++i)
+                for (int j = std::max(lo, jg * 8); j < std::min(hi, jg * 8 + 8); ++j)
+                    if (j <= i) out.push_back({i, j, kb0, kb1});
+}
+
+// share of the previous panel's bulk update hosted by one step launch: at most this many tiles; what is left
+// runs as a plain tile-engine launch (two workgroups per CU) before the panel's first step
+static int fill_cap() {
+    static const int v = getenv("GPIMHIP_FILL_CAP") ? atoi(getenv("GPIMHIP_FILL_CAP")) : (1 << 30);
+    return v;
+}
+
+int step_plan_ensure(gpimhip_ctx* h, int nb) {
+    StepPlan& P = h->splan;
+    if (P.nb == nb) return GPIMHIP_OK;
+    if (P.d_tiles) { (void)hipFree(P.d_tiles); P.d_tiles = nullptr; }
+    const int W = STEP_W;
+    std::vector<TileDesc> tl;
+    auto mark = [&](size_t start) { return PlanRange{(int64_t)start, (int32_t)(tl.size() - start)}; };
+    P.fill.assign(nb, {0, 0});
+    P.diag.assign(nb, {0, 0});
+    const int npanel = (nb + W - 1) / W;
+    P.bulk_rest.assign(npanel, {0, 0});
+    for (int p = 0; p < npanel; ++p) {
+        const int p0 = p * W, p1 = std::min(p0 + W, nb), ncol = p1 - p0;
+        // bulk(p-1): columns >= p0 + W, k-blocks = the columns of panel p-1
+        std::vector<TileDesc> bulk;
+        if (p > 0 && p0 + W < nb) lower_patches(bulk, p0 + W, nb, p0 - W, p0);
+        const int per = std::min<int>(fill_cap(), (int)((bulk.size() + ncol - 1) / ncol));
+        size_t taken = 0;
+        for (int j = p0; j < p1; ++j) {
+            size_t s = tl.size();
+            const int kb0 = std::max(0, p0 - W);
+            if (j > kb0)
+                for (int i = j + 1; i < nb; ++i) tl.push_back({i, j, kb0, j});
+            for (int q = 0; q < per && taken < bulk.size(); ++q) tl.push_back(bulk[taken++]);
+            P.fill[j] = mark(s);
+            s = tl.size();
+            for (int jj = j + 1; jj < std::min(nb, p1 + W); ++jj) tl.push_back({jj, jj, j, j + 1});
+            P.diag[j] = mark(s);
+        }
+        size_t s = tl.size();
+        while (taken < bulk.size()) tl.push_back(bulk[taken++]);
+        P.bulk_rest[p] = mark(s);
+    }
+    P.n_tiles = (int64_t)tl.size();
+    void* q = nullptr;
+    HIP_TRY(hipMalloc(&q, std::max<size_t>(tl.size(), 1) * sizeof(TileDesc)));
+    P.d_tiles = (TileDesc*)q;
+    HIP_TRY(hipMemcpyAsync(P.d_tiles, tl.data(), tl.size() * sizeof(TileDesc), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    P.nb = nb;
+    return GPIMHIP_OK;
+}
+
+void step_plan_release(gpimhip_ctx* h) {
+    if (h->splan.d_tiles) (void)hipFree(h->splan.d_tiles);
+    h->splan.d_tiles = nullptr;
+    h->splan.nb = 0;
+}
+
+static GemmArgs nt_update(double* A, int64_t ld, const TileDesc* tiles, int n, int64_t rows) {
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A = A; g.lda = ld; g.B = A; g.ldb = ld; g.C = A; g.ldc = ld;
+    g.alpha = -1.0; g.beta = 1.0; g.tiles = tiles; g.ntiles = n;
+    g.sA = g.sB = g.sC = rows * ld;
+    return g;
+}
+
+// lower Cholesky of the np x np matrix A (np = nb * 128), in place, on h->stream; h->dinv / h->dinvB / h->logdet_part
+// receive the inverses of the diagonal blocks and the log-determinant partials like the in-order driver of api.hip.
+int launch_potrf_steps(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_t* info) {
+    const int nb = (int)(np / NB), W = STEP_W;
+    GP_TRY(step_plan_ensure(h, nb));
+    const StepPlan& P = h->splan;
+    const int B = h->nbatch;
+    static const int quad_max = getenv("GPIMHIP_FILL_QUAD_MAX") ? atoi(getenv("GPIMHIP_FILL_QUAD_MAX")) : 128;
+    static const int half_max = getenv("GPIMHIP_FILL_HALF_MAX") ? atoi(getenv("GPIMHIP_FILL_HALF_MAX")) : 512;
+    static const bool old_diag = getenv("GPIMHIP_OLD_DIAG") != nullptr;
+    for (int j = 0; j < nb; ++j) {
+        if (j % W == 0 && P.bulk_rest[j / W].n) {
+            GemmArgs g = nt_update(A, ld, P.d_tiles + P.bulk_rest[j / W].off, P.bulk_rest[j / W].n, h->np);
+            GP_TRY(launch_gemm(h, false, false, EPI_STORE, g));
+        }
+        StepArgs a;
+        a.A = A; a.ld = ld; a.kblk = j; a.nb = nb;
+        a.dinv_all = h->dinv; a.dinvB_all = h->dinvB; a.logdet = h->logdet_part; a.info = info;
+        a.g = nt_update(A, ld, P.d_tiles + P.fill[j].off, P.fill[j].n, h->np);
+        const int nf = P.fill[j].n;
+        // mixed k-ranges (column updates are up to 2W-1 blocks deep, bulk tiles W): deal the list to the XCDs in chunks
+        a.g.chunk = std::max(1, std::min(64, nf / 512));
+        if ((int64_t)nf * B <= quad_max)
+            hipLaunchKernelGGL((chol_step_kernel<64, 64>), dim3(nf ? 8 + 4 * nf : 1, B), dim3(NTH), 0, h->stream, a);
+        else if ((int64_t)nf * B <= half_max)
+            hipLaunchKernelGGL((chol_step_kernel<128, 64>), dim3(8 + 2 * nf, B), dim3(NTH), 0, h->stream, a);
+        else
+            hipLaunchKernelGGL((chol_step_kernel<128, 128>), dim3(8 + nf, B), dim3(NTH), 0, h->stream, a);
+        HIP_TRY(hipGetLastError());
+        if (j + 1 < nb) {
+            hipLaunchKernelGGL(panel_solve_kernel, dim3(4 * (nb - j - 1), B), dim3(256), 0, h->stream, A, ld, j, nb,
+                               (const double*)h->dinvB);
+            HIP_TRY(hipGetLastError());
+            if (old_diag) {
+                GemmArgs g = nt_update(A, ld, P.d_tiles + P.diag[j].off, P.diag[j].n, h->np);
+                GP_TRY(launch_gemm(h, false, false, EPI_STORE, g));
+            } else {
+                hipLaunchKernelGGL(diag_update_kernel, dim3(10 * P.diag[j].n, B), dim3(256), 0, h->stream, A, ld, j, nb);
+                HIP_TRY(hipGetLastError());
+            }
+        }
+    }
+    return GPIMHIP_OK;
+}

@@ -73,6 +73,16 @@ struct LinalgPlan {
     PlanRange lauum{0, 0};
 };
 
+// Launch plan of the step schedule of the Cholesky (cholstep.hip): per block column the tiles hosted by the launch
+// that factors its diagonal block and the diagonal tiles updated after its panel solve; per outer panel what is
+// left of the previous panel's bulk update.
+struct StepPlan {
+    int nb = 0;
+    TileDesc* d_tiles = nullptr;
+    int64_t n_tiles = 0;
+    std::vector<PlanRange> fill, diag, bulk_rest;
+};
+
 struct gpimhip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -90,6 +100,7 @@ struct gpimhip_ctx {
     double* B = nullptr;            // np x np : K^-1 (lower)
     double* Tm = nullptr;           // np x np : trtri temporary
     double* dinv = nullptr;         // nb x 128 x 128 inverses of diagonal blocks
+    double* dinvB = nullptr;        // the same in MFMA B-operand order (panel solve of cholstep.hip); fp64 handles
     double* ypad = nullptr;         // np
     double* z = nullptr;            // np  (L^-1 y)
     double* alpha = nullptr;        // np  (K^-1 y)
@@ -112,6 +123,7 @@ struct gpimhip_ctx {
     int64_t pred_ntiles = 0;
     int64_t bytes = 0;
     LinalgPlan plan;
+    StepPlan splan;
     // optional stage timing (bench.py): HIP event pairs on the handle's stream
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[4];
@@ -155,6 +167,10 @@ static inline int64_t pad_to(int64_t n, int64_t m) { return (n + m - 1) / m * m;
 int ws_ensure(gpimhip_ctx* h, int64_t N);
 int ws_ensure_predict(gpimhip_ctx* h, int64_t np, int64_t mc);
 int plan_ensure(gpimhip_ctx* h, int nb);
+// cholstep.hip
+int launch_potrf_steps(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_t* info);
+void step_plan_release(gpimhip_ctx* h);
+int step_plan_ensure(gpimhip_ctx* h, int nb);
 int launch_theta(gpimhip_ctx* h, const gpimhip_model_t* m, const double* u);
 // predict.hip
 bool fused_predict_fits(int64_t np);

@@ -23,291 +23,12 @@
 // v_mfma_f64_16x16x4_f64 lane maps (cdna_hip_programming.md section 3):
 //   A[l&15][l>>4], B[l>>4][l&15], C/D col = l&15, row = (l>>4) + 4*reg.
 #include <stdlib.h>
-#include "common.hpp"
+#include "gemm_body.hpp"
 
-typedef double d4 __attribute__((ext_vector_type(4)));
-typedef double d2 __attribute__((ext_vector_type(2)));
-
-#define LD_MK (GEMM_BK + 2)
-
-// TS = tile side handled by one workgroup (128 or 64); NT = threads.  One staged operand tile is
-// TS x 16 doubles = 8*TS 16-byte chunks whatever its orientation.
-template <bool KM, int NT, int TS>
-__device__ __forceinline__ void stage_load(d2 (&r)[8 * TS / NT], const double* __restrict__ base, int64_t ld,
-                                           int64_t mrow0, int64_t kcol0, int tid) {
-    // MK: tile element (m,k) lives at base[(mrow0+m)*ld + kcol0 + k]
-    // KM: tile element (k,m) lives at base[(kcol0+k)*ld + mrow0 + m]
-#pragma unroll
-    for (int i = 0; i < 8 * TS / NT; ++i) {
-        const int c = tid + NT * i;
-        if (!KM) {
-            const int row = c >> 3, c16 = c & 7;
-            r[i] = *reinterpret_cast<const d2*>(base + (mrow0 + row) * ld + kcol0 + c16 * 2);
-        } else {
-            const int krow = c / (TS / 2), c16 = c % (TS / 2);
-            r[i] = *reinterpret_cast<const d2*>(base + (kcol0 + krow) * ld + mrow0 + c16 * 2);
-        }
-    }
-}
-
-template <bool KM, int NT, int TS>
-__device__ __forceinline__ void stage_store(const d2 (&r)[8 * TS / NT], double* lds, int tid) {
-#pragma unroll
-    for (int i = 0; i < 8 * TS / NT; ++i) {
-        const int c = tid + NT * i;
-        if (!KM) {
-            const int row = c >> 3, c16 = c & 7;
-            *reinterpret_cast<d2*>(lds + row * LD_MK + c16 * 2) = r[i];
-        } else {
-            const int krow = c / (TS / 2), c16 = c % (TS / 2);
-            *reinterpret_cast<d2*>(lds + krow * (TS + 16) + c16 * 2) = r[i];
-        }
-    }
-}
-
-// Direct global -> LDS staging (global_load_lds_dwordx4) of an m-contiguous ("KM") operand tile with
-// TS = 128: one k-row is 128 doubles = 1 KB = one wave-wide 16-byte load, written by the hardware to
-// lds[krow][lane*2 .. lane*2+1] without passing through VGPRs -- no ds_write, no register staging.
-// Tracked by vmcnt; the caller waits for vmcnt(0) before the barrier that publishes the stage.
-// (tools/gemm_ablate.hip: 66.1 -> 68.5 TFLOP/s for the loop with both operands staged this way.)
-template <int NW>
-__device__ __forceinline__ void stage_direct_km(const double* __restrict__ base, int64_t ld, int64_t mrow0,
-                                                int64_t kcol0, double* lds, int wave, int lane) {
-    constexpr int ROWS = GEMM_BK / NW;      // k-rows per wave
-#pragma unroll
-    for (int i = 0; i < ROWS; ++i) {
-        const int krow = wave * ROWS + i;
-        __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void*)(base + (kcol0 + krow) * ld + mrow0 + lane * 2),
-            (__attribute__((address_space(3))) void*)(lds + krow * (128 + 16)), 16, 0, 0);
-    }
-}
-
-// The same for a k-contiguous ("MK") operand tile with TS = 128 rows of 16 doubles (128 B): one wave-wide
-// load fetches 8 rows x 8 sixteen-byte chunks (fully coalesced: whole 128-byte lines) and lands as one
-// contiguous 1 KB group in LDS.  LDS position p = lane of the group holds row p>>3, chunk (p&7) ^ (p>>3):
-// the XOR swizzle spreads the fragment reads over the banks (element (m,k) sits at
-// (m>>3)*128 + ((m&7)*8 + ((k>>1) ^ (m&7)))*2 + (k&1); two rows 8 apart share a bank, nothing worse --
-// 0.4 TFLOP/s in tools/gemm_ablate.hip against the padded [128][18] layout it replaces).
-template <int NW, int TS>
-__device__ __forceinline__ void stage_direct_mk(const double* __restrict__ base, int64_t ld, int64_t mrow0,
-                                                int64_t kcol0, double* lds, int wave, int lane) {
-    constexpr int GROUPS = (TS / 8) / NW;   // 8-row groups per wave
-    const int r8 = lane >> 3, c8 = (lane & 7) ^ r8;
-#pragma unroll
-    for (int i = 0; i < GROUPS; ++i) {
-        const int q = wave * GROUPS + i;
-        __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void*)(base + (mrow0 + q * 8 + r8) * ld + kcol0 + c8 * 2),
-            (__attribute__((address_space(3))) void*)(lds + q * 128), 16, 0, 0);
-    }
-}
-__device__ __forceinline__ double frag_mk_swz(const double* lds, int m0, int kk, int lane) {
-    const int m = m0 + (lane & 15), k = kk * 4 + (lane >> 4);
-    return lds[(m >> 3) * 128 + ((m & 7) * 8 + ((k >> 1) ^ (m & 7))) * 2 + (k & 1)];
-}
-
-template <bool KM, int NW, int TS>
-__device__ __forceinline__ void stage_direct(const double* __restrict__ base, int64_t ld, int64_t mrow0, int64_t kcol0,
-                                             double* lds, int wave, int lane) {
-    if (KM) stage_direct_km<NW>(base, ld, mrow0, kcol0, lds, wave, lane);
-    else stage_direct_mk<NW, TS>(base, ld, mrow0, kcol0, lds, wave, lane);
-}
-
-template <bool KM, int TS>
-__device__ __forceinline__ double frag(const double* lds, int m0, int kk, int lane) {
-    // element (m = m0 + (lane&15), k = kk*4 + (lane>>4)) of the staged tile; both layouts are
-    // bank-conflict free for ds_read_b64: [TS][18] (18 % 32 == 18 -> rows spread), [16][TS+16]
-    if (!KM) return lds[(m0 + (lane & 15)) * LD_MK + kk * 4 + (lane >> 4)];
-    return lds[(kk * 4 + (lane >> 4)) * (TS + 16) + m0 + (lane & 15)];
-}
-
-// NW = waves per workgroup, TSM x TSN = the part of a 128x128 tile one workgroup computes:
-//   (4, 128, 128)  2x2 waves of 64x64: bulk launches, two workgroups share a CU
-//   (8, 128, 128)  4x2 waves of 32x64: at most one tile per CU -> still two MFMA waves per SIMD (a
-//                  lone fp64-MFMA wave issues only every ~140 cycles)
-//   (4,  64,  64)  2x2 waves of 32x32 on a quadrant: few tiles, each spread over four CUs
-//   (8,  64, 128)  4x2 waves of 16x64 on a row half: in-place panel solves (a workgroup must own
-//                  whole rows of the tile it overwrites), each tile spread over two CUs
 template <bool A_KM, bool B_KM, int EPI, int NW, int TSM, int TSN>
 __global__ __launch_bounds__(NW * 64, 2) void gemm_tiles_kernel(GemmArgs g) {
-    constexpr int NT = NW * 64;             // threads
-    constexpr int WGM = NW / 2;             // waves along m (2 along n)
-    constexpr int WROWS = TSM / WGM;        // rows per wave
-    constexpr int WCOLS = TSN / 2;          // cols per wave
-    constexpr int MT = WROWS / 16;          // 16x16 accumulators per wave: MT x NTL
-    constexpr int NTL = WCOLS / 16;
-    constexpr int TSX = TSM > TSN ? TSM : TSN;
-    constexpr int STAGE = (TSX * LD_MK > GEMM_BK * (TSX + 16)) ? TSX * LD_MK : GEMM_BK * (TSX + 16);
-    constexpr int NCHA = 8 * TSM / NT, NCHB = 8 * TSN / NT;   // 16-byte chunks per thread per stage
-    // staged straight into LDS: every 128-wide operand tile, and 64-wide k-contiguous ones (a 64-wide
-    // m-contiguous k-row is only half a wave-wide load)
-    constexpr bool ADIR = TSM == 128 || !A_KM, BDIR = TSN == 128 || !B_KM;
-    __shared__ __attribute__((aligned(16))) double smem[4 * STAGE];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-
-    // XCD-aware bijective remap (block b runs on XCD b%8, in order b/8 on that XCD).
-    //  chunk == 0: every XCD gets one contiguous slice of the tile list -- best L2 reuse when all
-    //              tiles cost the same (SYRK-shaped trailing updates).
-    //  chunk  > 0: the list is dealt to the XCDs in chunks of that many tiles (one 8x8 patch), back
-    //              and forth, so lists sorted by decreasing k-range stay balanced across XCDs.
-    constexpr int QN = 128 / TSN;                       // workgroups per tile along n
-    constexpr int QUADS = (128 / TSM) * QN;             // workgroups per 128x128 tile
-    const int n = g.ntiles, b = blockIdx.x / QUADS, quad = blockIdx.x % QUADS;
-    int p;
-    if (QUADS > 1) {
-        p = b;
-    } else if (g.chunk == 0) {
-        const int q = n >> 3, r = n & 7, x = b & 7, yy = b >> 3;
-        p = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + yy;
-    } else {
-        const int C = g.chunk, full = (n / (8 * C)) * (8 * C);
-        if (b < full) {
-            // serpentine: odd rounds deal in reverse, so that on a list sorted by cost no XCD always
-            // gets the most expensive chunk of the round (16 % spread between XCD 0 and 7 otherwise)
-            const int x = b & 7, y = b >> 3, round = y / C;
-            p = (round * 8 + ((round & 1) ? 7 - x : x)) * C + (y % C);
-        } else {
-            p = b;
-        }
-    }
-    TileDesc t = g.tiles[p];
-    if (g.kfix1 > g.kfix0) { t.kb0 = g.kfix0; t.kb1 = g.kfix1; }
-    const int nsteps = (t.kb1 - t.kb0) * (NB / GEMM_BK);
-    const int qi = (quad / QN) * TSM, qj = (quad % QN) * TSN;
-    // batch: blockIdx.y selects the problem; operands advance by their per-problem strides
-    g.A += blockIdx.y * g.sA;
-    g.B += blockIdx.y * g.sB;
-    if (g.C) g.C += blockIdx.y * g.sC;
-    if (g.colpart) g.colpart += blockIdx.y * g.sColpart;
-
-    // operand origins (element units)
-    const int64_t a_m0 = (int64_t)(t.ci + (A_KM ? g.a_coff : g.a_roff)) * NB + qi;
-    const int64_t a_k0 = (int64_t)(t.kb0 + (A_KM ? g.a_roff : g.a_coff)) * NB;
-    const int64_t b_n0 = (int64_t)(t.cj + (B_KM ? g.b_coff : g.b_roff)) * NB + qj;
-    const int64_t b_k0 = (int64_t)(t.kb0 + (B_KM ? g.b_roff : g.b_coff)) * NB;
-
-    d4 acc[MT][NTL];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NTL; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
-
-    // krev: walk the k-range from its END.  Tiles of one patch whose ranges share their upper end
-    // (K^-1 = L^-T L^-1: [ci, nb)) then sweep the same operand rows at the same time, so the panels
-    // they share are still in the XCD's L2 when the next tile asks for them.
-    const int64_t kfirst = g.krev ? (int64_t)(nsteps - 1) * GEMM_BK : 0;
-    const int64_t kstride = g.krev ? -GEMM_BK : GEMM_BK;
-    d2 ra[NCHA], rb[NCHB];
-    if (nsteps > 0) {
-        if (ADIR) stage_direct<A_KM, NW, TSM>(g.A, g.lda, a_m0, a_k0 + kfirst, smem, wave, lane);
-        else stage_load<A_KM, NT, TSM>(ra, g.A, g.lda, a_m0, a_k0 + kfirst, tid);
-        if (BDIR) stage_direct<B_KM, NW, TSN>(g.B, g.ldb, b_n0, b_k0 + kfirst, smem + STAGE, wave, lane);
-        else stage_load<B_KM, NT, TSN>(rb, g.B, g.ldb, b_n0, b_k0 + kfirst, tid);
-        if (!ADIR) stage_store<A_KM, NT, TSM>(ra, smem, tid);
-        if (!BDIR) stage_store<B_KM, NT, TSN>(rb, smem + STAGE, tid);
-        if (ADIR || BDIR) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __syncthreads();
-
-    for (int s = 0; s < nsteps; ++s) {
-        const double* As = smem + (s & 1) * 2 * STAGE;
-        const double* Bs = As + STAGE;
-        const bool more = (s + 1 < nsteps);
-        if (more) {
-            // the other stage buffer was last read in step s-1: every wave is past that barrier
-            double* An = smem + ((s + 1) & 1) * 2 * STAGE;
-            const int64_t koff = kfirst + (int64_t)(s + 1) * kstride;
-            if (ADIR) stage_direct<A_KM, NW, TSM>(g.A, g.lda, a_m0, a_k0 + koff, An, wave, lane);
-            else stage_load<A_KM, NT, TSM>(ra, g.A, g.lda, a_m0, a_k0 + koff, tid);
-            if (BDIR) stage_direct<B_KM, NW, TSN>(g.B, g.ldb, b_n0, b_k0 + koff, An + STAGE, wave, lane);
-            else stage_load<B_KM, NT, TSN>(rb, g.B, g.ldb, b_n0, b_k0 + koff, tid);
-        }
-        // The MFMA block runs at raised wave priority: the arbiter then prefers this wave's MFMAs and
-        // fragment reads over the other resident wave's staging instructions, which otherwise steal
-        // issue slots from the matrix pipe (tools/gemm_ablate.hip: 66.1 -> 71.2 TFLOP/s for this loop).
-        __builtin_amdgcn_s_setprio(3);
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            double a[MT], bb[NTL];
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-                a[i] = (ADIR && !A_KM) ? frag_mk_swz(As, wm * WROWS + i * 16, kk, lane)
-                                       : frag<A_KM, TSM>(As, wm * WROWS + i * 16, kk, lane);
-#pragma unroll
-            for (int j = 0; j < NTL; ++j)
-                bb[j] = (BDIR && !B_KM) ? frag_mk_swz(Bs, wn * WCOLS + j * 16, kk, lane)
-                                        : frag<B_KM, TSN>(Bs, wn * WCOLS + j * 16, kk, lane);
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NTL; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bb[j], acc[i][j], 0, 0, 0);
-        }
-        __builtin_amdgcn_s_setprio(0);
-        if (more) {
-            double* An = smem + ((s + 1) & 1) * 2 * STAGE;
-            if (!ADIR) stage_store<A_KM, NT, TSM>(ra, An, tid);
-            if (!BDIR) stage_store<B_KM, NT, TSN>(rb, An + STAGE, tid);
-            if (ADIR || BDIR) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __syncthreads();
-    }
-
-    if (EPI == EPI_STORE) {
-        const int64_t crow0 = (int64_t)(t.ci + g.c_roff) * NB + qi + wm * WROWS + (lane >> 4);
-        const int64_t ccol0 = (int64_t)(t.cj + g.c_coff) * NB + qj + wn * WCOLS + (lane & 15);
-        const double alpha = g.alpha, beta = g.beta;
-        if (beta != 0.0) {
-            // accumulate into C: fetch one 16-row band of the wave's sub-tile (NTL x 4 values per lane)
-            // with all loads in flight, then combine and store -- element by element the loads and
-            // stores serialise into 2 x 64 memory round trips per tile
-#pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                double cv[NTL][4];
-#pragma unroll
-                for (int j = 0; j < NTL; ++j)
-#pragma unroll
-                    for (int rg = 0; rg < 4; ++rg)
-                        cv[j][rg] = g.C[(crow0 + i * 16 + 4 * rg) * g.ldc + ccol0 + j * 16];
-#pragma unroll
-                for (int j = 0; j < NTL; ++j)
-#pragma unroll
-                    for (int rg = 0; rg < 4; ++rg)
-                        g.C[(crow0 + i * 16 + 4 * rg) * g.ldc + ccol0 + j * 16] = alpha * acc[i][j][rg] + beta * cv[j][rg];
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NTL; ++j)
-#pragma unroll
-                    for (int rg = 0; rg < 4; ++rg)
-                        g.C[(crow0 + i * 16 + 4 * rg) * g.ldc + ccol0 + j * 16] = alpha * acc[i][j][rg];
-        }
-    } else {
-        // column sums of squares of the 128x128 product tile -> colpart[ci][cj*128 + col]  (full tiles only)
-        double* red = smem;      // [WGM][128]; all waves are past the last barrier of the k-loop
-#pragma unroll
-        for (int j = 0; j < NTL; ++j) {
-            double s = 0.0;
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int rg = 0; rg < 4; ++rg) s += acc[i][j][rg] * acc[i][j][rg];
-            s += __shfl_xor(s, 16);
-            s += __shfl_xor(s, 32);
-            if (lane < 16) red[wm * 128 + wn * WCOLS + j * 16 + lane] = s;
-        }
-        __syncthreads();
-        if (tid < 128) {
-            double tot = 0.0;
-#pragma unroll
-            for (int w = 0; w < WGM; ++w) tot += red[w * 128 + tid];
-            g.colpart[(int64_t)t.ci * g.ld_colpart + (int64_t)(t.cj + g.c_coff) * NB + tid] = tot;
-        }
-    }
+    __shared__ __attribute__((aligned(16))) double smem[gemm_smem_doubles<TSM, TSN>()];
+    gemm_tile_body<A_KM, B_KM, EPI, NW, TSM, TSN>(g, (int)blockIdx.x, (int)blockIdx.y, smem);
 }
 
 // Launches of a few tiles per CU with very different k-ranges (mid-size N): the launch lasts as long as its
@@ -323,7 +44,12 @@ template <bool A_KM, bool B_KM, int EPI>
 static int launch_one(gpimhip_ctx* h, const GemmArgs& g) {
     if (g.ntiles <= 0) return GPIMHIP_OK;
     const int64_t total = (int64_t)g.ntiles * h->nbatch;
-    const bool small = total <= 256 && !getenv("GPIMHIP_NO_TILE64");
+    // up to 640 tiles: 64x64 quadrants, four co-resident workgroups per CU.  A launch of a few hundred tiles whose
+    // k-ranges differ by an order of magnitude (triangular inverse, K^-1 product at N ~ 4000) lasts as long as its
+    // longest tile; dealt longest-first over 4 x 256 slots, every CU gets a mix (N = 4206: inverse 0.92 -> 0.80 ms,
+    // K^-1 product 0.57 -> 0.48; 1200 / 2400 measure the same)
+    static const int tile64_max = getenv("GPIMHIP_TILE64_MAX") ? atoi(getenv("GPIMHIP_TILE64_MAX")) : 640;
+    const bool small = total <= tile64_max && !getenv("GPIMHIP_NO_TILE64");
     if (EPI == EPI_STORE && small && !g.inplace)
         // few tiles: spread each over four CUs (64x64 quadrants)
         hipLaunchKernelGGL((gemm_tiles_kernel<A_KM, B_KM, EPI_STORE, 4, 64, 64>), dim3(g.ntiles * 4, h->nbatch),

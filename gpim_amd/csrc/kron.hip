@@ -31,6 +31,8 @@
 #include "blocklds.hpp"      // wave_sum: DPP / readlane reduction (no LDS crossbar round trips)
 
 hipStream_t ensure_capture_stream(gpimhip_ctx* h);
+void capture_lock(gpimhip_ctx* h);
+void capture_unlock(gpimhip_ctx* h);
 int ws_ensure(gpimhip_ctx* h, int64_t N);
 int check_model(const gpimhip_model_t* m);
 int upload_bc_table(gpimhip_ctx* h, double lr, int T);
@@ -758,12 +760,14 @@ int gpimhip_fit_kron(gpimhip_handle h, const gpimhip_model_t* m, int32_t d, cons
         hipGraphExec_t exec = nullptr;
         hipStream_t main_s = h->stream;
         h->stream = h->capture_stream;
+        capture_lock(h);
         hipError_t e = hipStreamBeginCapture(h->capture_stream, hipStreamCaptureModeRelaxed);
         int rc = GPIMHIP_OK;
         if (e == hipSuccess) {
             rc = kron_loss_grad(h, *w, m, y, u_inout, 1, nullptr, nullptr, &it);
             e = hipStreamEndCapture(h->capture_stream, &graph);
         }
+        capture_unlock(h);
         h->stream = main_s;
         if (rc != GPIMHIP_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
         if (e == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {

@@ -34,6 +34,8 @@ int launch_trtri(gpimhip_ctx* h, double* A, double* Tm, int64_t np, int64_t ld);
 int launch_lauum(gpimhip_ctx* h, const double* A, double* B, int64_t np, int64_t ld);
 int launch_trmv_lower(gpimhip_ctx* h, const double* L, int64_t ld, int64_t np, const double* y, double* z);
 hipStream_t ensure_capture_stream(gpimhip_ctx* h);
+void capture_lock(gpimhip_ctx* h);
+void capture_unlock(gpimhip_ctx* h);
 int launch_gemv_t(gpimhip_ctx* h, const double* A, int64_t ld, int64_t nrows, int64_t ncols, const double* x,
                   double* out, int tri, int64_t a_bs, int64_t x_bs, int64_t o_bs);
 int launch_pad_copy(gpimhip_ctx* h, const double* src, int64_t n, double* dst, int64_t np);
@@ -661,12 +663,14 @@ int gpimhip_fit_vfe(gpimhip_handle h, const gpimhip_model_t* m, const double* X,
         hipGraphExec_t exec = nullptr;
         hipStream_t main_s = h->stream;
         h->stream = h->capture_stream;
+        capture_lock(h);
         hipError_t e = hipStreamBeginCapture(h->capture_stream, hipStreamCaptureModeRelaxed);
         int rc = GPIMHIP_OK;
         if (e == hipSuccess) {
             rc = vfe_loss_grad(h, *w, m, X, N, Mu, u_inout, P, 1, &it, nullptr, nullptr);
             e = hipStreamEndCapture(h->capture_stream, &graph);
         }
+        capture_unlock(h);
         h->stream = main_s;
         if (rc != GPIMHIP_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
         if (e == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {

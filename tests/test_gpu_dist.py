@@ -1,7 +1,8 @@
 """
 One exact GP across GPUs -- gpim_amd/dist_chol.py on the HIP tile engine, single process (P = 1): the
-block-column-cyclic driver performs the tile operations of gpimhip_potrf in the same order, so the factor
-is bit-identical; log det / solve / NLL / posterior mean against torch and the dense oracle.  The multi-rank
+block-column-cyclic driver (right-looking by 512-column panels) against gpimhip_potrf (left-looking step schedule
+below N = 12288: a different summation order of the same tile products) and torch.linalg.cholesky, entry-wise to
+1e-12 of the largest entry; log det / solve / NLL / posterior mean against torch and the dense oracle.  The multi-rank
 schedule itself (ownership, broadcasts, small collectives of the solves) is covered on CPU ranks in
 tests/test_dist_gloo.py with a stub engine; a multi-GPU run needs the driver's 8-GPU node.
 """
@@ -18,7 +19,7 @@ from oracle import gpim_oracle as O
 
 
 @pytest.mark.parametrize("n", [700, 1500, 4096])
-def test_p1_bit_identical_to_potrf(ensure_built, n):
+def test_p1_factor_vs_potrf(ensure_built, n):
     from gpim_amd import _lib
     from gpim_amd.dist_chol import DistributedCholesky
     rng = np.random.default_rng(n)
@@ -33,8 +34,10 @@ def test_p1_bit_identical_to_potrf(ensure_built, n):
     _lib.check(H.lib.gpimhip_potrf(H.h, _lib.ptr(Lp), n, n, _lib.ptr(info)))
     torch.cuda.synchronize()
     assert info.item() == 0
-    assert torch.equal(Ld, torch.tril(Lp))
     ref = torch.linalg.cholesky(A)
+    scale = ref.abs().max().item()
+    assert (Ld - torch.tril(Lp)).abs().max().item() <= 1e-12 * scale
+    assert (Ld - ref).abs().max().item() <= 1e-12 * scale
     assert_allclose(ch.logdet(), 2 * torch.log(torch.diagonal(ref)).sum().item(), rtol=1e-12)
     y = torch.from_numpy(rng.standard_normal(n)).cuda()
     alpha = ch.solve(y)
