@@ -16,8 +16,14 @@ N > 1   : one process per GPU (torchrun contract).
           --workload c2 (default): every rank reconstructs its own image of a stack (seed = rank) --
               independent units, no collective on the data path -- and the (mean, sd) maps are gathered
               to rank 0 over RCCL inside the timed region.  Weak scaling.
+          --workload c1: config C1 as the reference defines it -- the 128x128 PFM spiral scan of
+              expdata/spiral_s_00010_2019.npy (committed data fixture, N = 4212, M = 16384), RBF, T = 300 --
+              one image per GPU, same step and gather as c2.  Weak scaling.
           --workload c3: the 64 spectral slices of ONE 64x64x64 cube (config C3) are dealt to the ranks
               and fitted in lock-step batches per GPU; total work fixed.  Strong scaling.
+          c1 and c3 carry the same ``roofline.stages`` breakdown as c2 (collected in one extra, untimed step with
+          the stage timers on, so that the timed steps run the hipGraph-replayed path a user gets) plus
+          ``chain_us_per_128`` = Cholesky time per 128-column block step.
           --workload c2full: the COMPLETE 256x256 image of config C2 as ONE exact GP (N = 65536, a 32 GiB
               covariance) across the GPUs: block-column-cyclic Cholesky with one panel broadcast per 512
               columns (gpim_amd/dist_chol.py), distributed solves, posterior mean and sd on the grid, at
@@ -29,8 +35,9 @@ roofline: fp64 MFMA.  Top level = algorithmic flop of one step (T*N^3 for the fi
           ONE kernel launch (K^-1 = L^-T L^-1), whose average duration is what the rocprofv3 kernel
           trace under profiles/ reports for the same command.
 cpu_baseline: the CPU oracle (torch fp64 + autograd restatement of the reference, kind "port")
-          timed on rank 0's host cores at three sizes; iteration and prediction times are fitted to
-          a*N^2 + b*N^3 (resp. c*N*M + e*N^2*M) and evaluated at the full size.
+          timed on rank 0's host cores AT THE FULL SIZE of the workload: one Adam iteration (loss + backward +
+          step) and one prediction, value = M / (T * t_iteration + t_predict).  Two smaller sizes are timed
+          too and fitted to a*N^2 + b*N^3 (resp. c*N*M + e*N^2*M) as a cross-check of the measurement.
 extra   : driver-run throughputs of the other BASELINE.json configs (C1, C3, C4, C5) on one GPU.
 """
 import argparse
@@ -60,25 +67,35 @@ C3 = dict(kernel="RBF", lengthscale=[[1., 1.], [20., 20.]], learning_rate=0.1, i
 # ------------------------------------------------------------------------------------------------
 # CPU baseline (oracle on the host cores)
 # ------------------------------------------------------------------------------------------------
-def cpu_baseline(N, M, T, budget_s=40.0):
-    """Times the oracle's Adam iteration (loss + backward + step, 2 iterations per size) and its
-    prediction at N ~ 2048, 4096 (and the iteration at 8192) of the same workload, fits
-        t_iter(N) = a N^2 + b N^3          (kernel build / autograd temporaries + factorisations)
-        t_pred(N, M) = c N M + e N^2 M     (K* build + triangular solve)
-    by least squares and evaluates the fits at the full size."""
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(N, M, T, workload=None, full=True):
+    """Times the oracle (a) at the FULL size of the workload -- one Adam iteration (loss + backward + step;
+    every iteration does the same work) and one prediction on all M grid points -- and (b) at N ~ 2048 and
+    4096 of the same workload, fitted to  t_iter(N) = a N^2 + b N^3,  t_pred(N, M) = c N M + e N^2 M  and
+    evaluated at the full size as a cross-check.  value = M / (T * t_iter + t_pred) from (a)."""
     from oracle import gpim_oracle as O
     from problems import lattice_image
+    W = workload or WORKLOAD
     # LAPACK/BLAS on this path stop scaling (and oversubscribe badly) far below the 100+ hardware
     # threads of a GPU host; 32 threads is where the oracle's iteration time bottoms out
     threads = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(threads)
 
     def sample(n, iters, predict):
-        size = int(round(math.sqrt(n / WORKLOAD["frac"])))
-        R, _ = lattice_image(size=size, frac=WORKLOAD["frac"], seed=1)
+        size = int(round(math.sqrt(n / W["frac"])))
+        R, _ = lattice_image(size=size, frac=W["frac"], seed=1)
         X, Xf = O.get_sparse_grid(R), O.get_full_grid(R)
-        rec = O.reconstructor(X, R, Xf, kernel=WORKLOAD["kernel"], lengthscale=WORKLOAD["lengthscale"],
-                              learning_rate=WORKLOAD["learning_rate"], iterations=iters, verbose=0)
+        rec = O.reconstructor(X, R, Xf, kernel=W["kernel"], lengthscale=W["lengthscale"],
+                              learning_rate=W["learning_rate"], iterations=iters, verbose=0)
         t0 = time.time()
         rec.train()
         t_it = (time.time() - t0) / iters
@@ -90,20 +107,11 @@ def cpu_baseline(N, M, T, budget_s=40.0):
         return rec.X.shape[0], size * size, t_it, t_pr
 
     sample(256, 1, True)                          # thread-pool / allocator warm-up, not timed
-    pts, spent = [], 0.0
-    # (N, iterations timed, time the prediction too?)  The largest size is half the target N: small
-    # sizes run BLAS/LAPACK far below their large-N efficiency and would overstate the cubic term.
-    for n, iters, pred in ((2048, 2, True), (4096, 2, True), (8192, 1, False)):
-        if pts and spent + 8.5 * iters * pts[-1][2] + (9 * pts[-1][3] if pred else 0) > budget_s:
-            break
-        pts.append(sample(n, iters, pred))
-        spent += iters * pts[-1][2] + (pts[-1][3] or 0)
+    pts = [sample(2048, 2, True), sample(4096, 2, True)]
     n_ = np.array([p[0] for p in pts], dtype=float)
+    m_ = np.array([p[1] for p in pts], dtype=float)
     t_it = np.array([p[2] for p in pts])
-    pp = [p for p in pts if p[3] is not None]
-    np_ = np.array([p[0] for p in pp], dtype=float)
-    m_ = np.array([p[1] for p in pp], dtype=float)
-    t_pr = np.array([p[3] for p in pp])
+    t_pr = np.array([p[3] for p in pts])
 
     def nnls2(A, y):
         # two-term non-negative least squares in relative error (every sample weighs the same)
@@ -112,48 +120,80 @@ def cpu_baseline(N, M, T, budget_s=40.0):
         for cols in ([0, 1], [1], [0]):
             c, *_ = np.linalg.lstsq(Aw[:, cols], yw, rcond=None)
             if (c >= 0).all():
-                full = np.zeros(2)
-                full[cols] = c
-                res = float(np.sqrt(np.mean((Aw @ full - 1.0) ** 2)))
+                full_c = np.zeros(2)
+                full_c[cols] = c
+                res = float(np.sqrt(np.mean((Aw @ full_c - 1.0) ** 2)))
                 if best is None or res < best[1]:
-                    best = (full, res)
+                    best = (full_c, res)
         return best
 
-    (a, b), res_it = nnls2(np.stack([n_ ** 2, n_ ** 3], 1), t_it)
-    (c, e), res_pr = nnls2(np.stack([np_ * m_, np_ ** 2 * m_], 1), t_pr)
-    t_iter_full = a * N ** 2 + b * N ** 3
-    t_pred_full = c * N * M + e * N ** 2 * M
+    (a, b), _ = nnls2(np.stack([n_ ** 2, n_ ** 3], 1), t_it)
+    (c, e), _ = nnls2(np.stack([n_ * m_, n_ ** 2 * m_], 1), t_pr)
+    fit_iter, fit_pred = a * N ** 2 + b * N ** 3, c * N * M + e * N ** 2 * M
+    # (a) the measurement.  The oracle's predict holds K*, L^-1 K* and its square (3 x 8 N M bytes) plus K and L.
+    need = 3 * 8.0 * N * M + 6 * 8.0 * N * N
+    try:
+        import psutil
+        avail = psutil.virtual_memory().available
+    except Exception:
+        avail = None
+    measured = full and (avail is None or avail > 1.3 * need)
+    if measured:
+        n_full, m_full, t_iter_full, t_pred_full = sample(N, 1, True)
+        assert n_full == N and m_full == M, (n_full, m_full)
+    else:
+        t_iter_full, t_pred_full = fit_iter, fit_pred
     t_full = T * t_iter_full + t_pred_full
-    # local scaling exponent between the two largest samples, for the record
-    expo = (math.log(t_it[-1] / t_it[-2]) / math.log(n_[-1] / n_[-2])) if len(pts) >= 2 else None
-    text = ("oracle (torch CPU fp64, autograd), %d threads; samples (N, M, s/iteration, s/predict): %s; fit "
-            "t_iter = %.3e N^2 + %.3e N^3 (rms rel. residual %.1f%%, local exponent %.2f), t_pred = %.3e N M + "
-            "%.3e N^2 M (residual %.1f%%); at N=%d, M=%d: %.1f s/iteration, %.1f s/predict, T=%d"
-            % (threads, [(int(p[0]), int(p[1]), round(p[2], 3), None if p[3] is None else round(p[3], 3)) for p in pts], a, b,
-               100 * res_it, expo if expo else float("nan"), c, e, 100 * res_pr, N, M, t_iter_full, t_pred_full, T))
+    text = ("oracle (torch CPU fp64, autograd), %d threads on '%s' (os.cpu_count() = %s); %s at N=%d, M=%d: "
+            "%.1f s per Adam iteration (1 timed), %.1f s per prediction (1 timed); whole job = T=%d iterations + 1 "
+            "prediction; cross-check from samples (N, M, s/iteration, s/predict) %s fitted to a N^2 + b N^3 and "
+            "c N M + e N^2 M: %.1f s / %.1f s"
+            % (threads, _cpu_model(), os.cpu_count(), "MEASURED" if measured else "NOT measured (host memory), fit evaluated",
+               N, M, t_iter_full, t_pred_full, T,
+               [(int(p[0]), int(p[1]), round(p[2], 3), round(p[3], 3)) for p in pts], fit_iter, fit_pred))
     return {"value": M / t_full, "unit": "grid-points/s", "cores": threads, "kind": "port", "sample": text,
-            "fit": {"t_iter": {"N2": a, "N3": b, "rms_rel_residual": res_it, "local_exponent": expo},
-                    "t_pred": {"NM": c, "N2M": e, "rms_rel_residual": res_pr}},
-            "s_per_iteration_full": t_iter_full, "s_per_predict_full": t_pred_full}
+            "measured_at_full_size": bool(measured), "cpu_model": _cpu_model(), "os_cpu_count": os.cpu_count(),
+            "torch_num_threads": torch.get_num_threads(),
+            "s_per_iteration_full": t_iter_full, "s_per_predict_full": t_pred_full,
+            "fit_cross_check": {"t_iter": {"N2": a, "N3": b, "at_full_size": fit_iter},
+                                "t_pred": {"NM": c, "N2M": e, "at_full_size": fit_pred}}}
+
+
+def cpu_baseline_c1(R, T):
+    """Config C1 on the host cores: 3 oracle Adam iterations + 1 prediction at the full size (N = 4212, M = 16384);
+    value = M / (T * t_iteration + t_predict)."""
+    from oracle import gpim_oracle as O
+    threads = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(threads)
+    X, Xf = O.get_sparse_grid(R), O.get_full_grid(R)
+    O.reconstructor(X, R, Xf, **dict(C1, iterations=1, verbose=0)).train()             # warm-up
+    rec = O.reconstructor(X, R, Xf, **dict(C1, iterations=3, verbose=0))
+    t0 = time.time(); rec.train(); t_it = (time.time() - t0) / 3
+    t0 = time.time(); rec.predict(); t_pr = time.time() - t0
+    return {"value": R.size / (T * t_it + t_pr), "unit": "grid-points/s", "cores": threads, "kind": "port",
+            "measured_at_full_size": True, "cpu_model": _cpu_model(), "os_cpu_count": os.cpu_count(),
+            "torch_num_threads": torch.get_num_threads(), "s_per_iteration_full": t_it, "s_per_predict_full": t_pr,
+            "sample": "oracle, %d threads: 3 Adam iterations (%.2f s each) + 1 prediction (%.2f s) at N=%d, M=%d; whole job "
+                      "= T=%d iterations + 1 prediction" % (threads, t_it, t_pr, int(np.isfinite(R).sum()), R.size, T)}
 
 
 # ------------------------------------------------------------------------------------------------
 # the other half of the metric: posterior RMSE vs the reference restatement
 # ------------------------------------------------------------------------------------------------
 def rmse_vs_oracle(gpim, iterations=5):
-    """Config C1 twin (128x128 spiral, N = 4206, M = 16384, RBF): HIP engine vs oracle, same inputs,
-    same seed, `iterations` Adam steps (the oracle needs ~1 s per step on the host)."""
+    """Config C1 (the reference's 128x128 PFM spiral scan, N = 4212, M = 16384, RBF): HIP engine vs oracle, same
+    inputs, same seed, `iterations` Adam steps (the oracle needs ~1 s per step on the host)."""
     from oracle import gpim_oracle as O
-    from problems import spiral_image
-    R, _ = spiral_image()
+    from problems import spiral_pfm_image
+    R = spiral_pfm_image()
     X, Xf = gpim.utils.get_sparse_grid(R), gpim.utils.get_full_grid(R)
     kw = dict(C1, iterations=iterations, verbose=0)
     mean, sd, hyper = gpim.reconstructor(X, R, Xf, **kw).run()
     torch.set_num_threads(min(os.cpu_count() or 1, 32))
     mo, so, ho = O.reconstructor(X, R, Xf, **kw).run()
     rel = lambda a, b: float(np.max(np.abs(np.asarray(a) - np.asarray(b)) / np.abs(np.asarray(b))))
-    return {"config": "C1 twin: 128x128 spiral, N=%d, M=%d, RBF, %d Adam its, fp64" % (np.isfinite(R).sum(), R.size,
-                                                                                       iterations),
+    return {"config": "C1: 128x128 PFM spiral scan (expdata/spiral_s_00010_2019.npy), N=%d, M=%d, RBF, %d Adam its, fp64"
+                      % (np.isfinite(R).sum(), R.size, iterations),
             "rmse_mean": float(np.sqrt(np.mean((mean - mo) ** 2))),
             "rmse_sd": float(np.sqrt(np.mean((sd - so) ** 2))),
             "max_abs_mean": float(np.max(np.abs(mean - mo))), "max_abs_sd": float(np.max(np.abs(sd - so))),
@@ -166,18 +206,19 @@ def rmse_vs_oracle(gpim, iterations=5):
 # ------------------------------------------------------------------------------------------------
 def extra_configs(gpim):
     from gpim_amd import dist as gdist
-    from problems import ckpfm_cube, hyperspectral_cube, notebook_problem, spiral_image
+    from problems import ckpfm_cube, hyperspectral_cube, notebook_problem, spiral_pfm_image
     out = {}
     sync = torch.cuda.synchronize
-    # C1: 128x128 spiral twin, RBF, T = 300
-    R, _ = spiral_image()
+    # C1: the reference's 128x128 PFM spiral scan, RBF, T = 300
+    R = spiral_pfm_image()
     X, Xf = gpim.utils.get_sparse_grid(R), gpim.utils.get_full_grid(R)
     gpim.reconstructor(X, R, Xf, **dict(C1, iterations=3, verbose=0)).run()          # workspace / plan warm-up
     sync(); t0 = time.perf_counter()
     gpim.reconstructor(X, R, Xf, verbose=0, **C1).run()
     sync(); dt = time.perf_counter() - t0
     n1 = int(np.isfinite(R).sum())
-    out["C1"] = {"workload": "128x128 spiral twin, N=%d, M=%d, RBF, T=300, reconstructor.run()" % (n1, R.size),
+    out["C1"] = {"workload": "128x128 PFM spiral scan (expdata/spiral_s_00010_2019.npy), N=%d, M=%d, RBF, T=300, "
+                             "reconstructor.run()" % (n1, R.size),
                  "seconds": dt, "grid_points_per_s": R.size / dt, "ms_per_adam_iteration": dt / 300 * 1e3,
                  "mfma_frac": (300 * n1 ** 3 + 2 * n1 ** 3 / 3 + n1 ** 2 * R.size) / dt / 1e12 / FP64_MFMA_PEAK_TFLOPS}
     # C3: 64 slices of 64x64, RBF, T = 250, lock-step batch of 64 on one GPU
@@ -259,9 +300,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", choices=["c2", "c3", "c2full"], default="c2")
+    ap.add_argument("--workload", choices=["c2", "c1", "c3", "c2full"], default="c2")
     ap.add_argument("--iterations", type=int, default=None,
-                    help="Adam iterations per step (the named workloads use 100 (c2) / 250 (c3))")
+                    help="Adam iterations per step (the named workloads use 100 (c2) / 300 (c1) / 250 (c3))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip rmse_vs_oracle and the C1/C3/C4 extras")
     ap.add_argument("--extras-only", action="store_true",
@@ -273,7 +314,7 @@ def main():
     import torch.distributed as dist
     import gpim_amd
     from gpim_amd import _lib, dist as gdist
-    from problems import hyperspectral_cube, lattice_image
+    from problems import hyperspectral_cube, lattice_image, spiral_pfm_image
 
     if args.extras_only:
         torch.cuda.set_device(0)
@@ -298,13 +339,19 @@ def main():
         fence()
 
     stage_ms = {}
-    if args.workload == "c2":
-        T = args.iterations or WORKLOAD["iterations"]
+    nprob = 1                       # problems advancing together through every launch (c3: the lock-step batch)
+    if args.workload in ("c2", "c1"):
         # ---- build this rank's unit and move it to HBM (untimed)
-        R, _ = lattice_image(size=WORKLOAD["size"], frac=WORKLOAD["frac"], seed=1 + 10 * rank)
+        if args.workload == "c2":
+            T = args.iterations or WORKLOAD["iterations"]
+            R, _ = lattice_image(size=WORKLOAD["size"], frac=WORKLOAD["frac"], seed=1 + 10 * rank)
+            kw = dict(kernel=WORKLOAD["kernel"], lengthscale=WORKLOAD["lengthscale"], learning_rate=WORKLOAD["learning_rate"])
+        else:
+            T = args.iterations or C1["iterations"]
+            R = spiral_pfm_image()                       # every rank: the same scan (a stack of equal frames)
+            kw = dict(kernel=C1["kernel"], lengthscale=C1["lengthscale"], learning_rate=C1["learning_rate"])
         X, Xf = gpim_amd.utils.get_sparse_grid(R), gpim_amd.utils.get_full_grid(R)
-        rec = gpim_amd.reconstructor(X, R, Xf, kernel=WORKLOAD["kernel"], lengthscale=WORKLOAD["lengthscale"],
-                                     learning_rate=WORKLOAD["learning_rate"], iterations=T, verbose=0, seed=0)
+        rec = gpim_amd.reconstructor(X, R, Xf, iterations=T, verbose=0, seed=0, **kw)
         N, M = rec.X.shape[0], rec.Xtest.shape[0]
         u0 = rec._u.clone()
         lib, h = rec._handle.lib, rec._handle.h
@@ -337,15 +384,21 @@ def main():
         cube, _ = hyperspectral_cube()
         N, M = int(np.isfinite(cube[..., 0]).sum()), cube.shape[0] * cube.shape[1]
         units_per_step, scaling = cube.size, "strong"
-        lib = h = None
+        Hc3 = _lib.Handle()
+        lib, h = Hc3.lib, Hc3.h
+        nprob = min(64, len(gdist.shard_units(64, rank, world)))
 
         def step():
-            return gdist.reconstruct_slices(cube, axis=-1, batch=64, **dict(C3, iterations=T))
+            return gdist.reconstruct_slices(cube, axis=-1, batch=64, handle=Hc3, **dict(C3, iterations=T))
 
     for _ in range(args.warmup):
         step()
     tot, cnt = ctypes.c_double(), ctypes.c_int64()
-    if lib is not None:
+    # c2 runs the multi-stream look-ahead schedule, which is never graph-captured: its stage timers sit inside the
+    # timed region.  c1 / c3 replay one captured iteration per Adam step, which the timers would switch off: their
+    # stage breakdown comes from ONE extra step after the timed ones.
+    timers_inside = args.workload == "c2"
+    if lib is not None and timers_inside:
         lib.gpimhip_timing_enable(h, 1)
         for s in range(4):
             lib.gpimhip_timing_read(h, s, ctypes.byref(tot), ctypes.byref(cnt))     # clear
@@ -355,7 +408,15 @@ def main():
         res = step()
     fence()
     elapsed = time.perf_counter() - t0
+    stage_steps = args.steps
     if lib is not None:
+        if not timers_inside:
+            lib.gpimhip_timing_enable(h, 1)
+            for s in range(4):
+                lib.gpimhip_timing_read(h, s, ctypes.byref(tot), ctypes.byref(cnt))
+            step()
+            fence()
+            stage_steps = 1
         lib.gpimhip_timing_enable(h, 0)
         for s, name in enumerate(["potrf", "trtri", "lauum", "predict_var"]):
             lib.gpimhip_timing_read(h, s, ctypes.byref(tot), ctypes.byref(cnt))
@@ -376,48 +437,66 @@ def main():
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
         }
-        if args.workload == "c2":
-            # sanity: the timed output is finite and shaped (units, 2, M)
-            assert res.shape == (world, 2, M) and bool(torch.isfinite(res).all())
-            out["config"] = {"workload": ("C2: 256x256 synthetic twisted-lattice image, 25%% observed "
-                                          "(N=%d, M=%d, d=2), Matern52 exact GP, T=%d Adam its (lr 0.1) + predict; "
-                                          "one image per GPU") % (N, M, T),
-                             "N": N, "M": M, "iterations": T, "kernel": WORKLOAD["kernel"]}
-            n3 = float(N) ** 3
-            flop_step = T * n3 + 2.0 * n3 / 3.0 + float(N) ** 2 * M       # per GPU
-            achieved = flop_step / (ms_step * 1e-3) / 1e12
-            # large N: the factorisation and the row-wise triangular inverse run as ONE interleaved stage
-            # (timer 0 covers both, timer 1 stays empty)
-            fused = stage_ms["trtri"][1] == 0
-            per_call = {"potrf": (2 * n3 / 3) if fused else n3 / 3, "trtri": n3 / 3, "lauum": n3 / 3}
-            label = {"potrf": "potrf+inverse (fused, 2N^3/3)" if fused else "potrf", "trtri": "trtri",
-                     "lauum": "lauum (K^-1 = L^-T L^-1)", "predict_var": "predict_var (L^-1 K*)"}
+        def stage_breakdown(n_obs, nprob_):
+            """roofline.stages from the HIP-event stage timers: per blocked-algorithm stage the calls, ms per call,
+            flop per call (all `nprob_` problems of a lock-step batch), TFLOP/s, fraction of the fp64 MFMA peak and
+            share of the time of the step(s) the timers covered."""
+            n3 = float(n_obs) ** 3 * nprob_
+            per_call = {"potrf": n3 / 3, "trtri": n3 / 3, "lauum": n3 / 3}
+            label = {"potrf": "potrf", "trtri": "trtri", "lauum": "lauum (K^-1 = L^-T L^-1)",
+                     "predict_var": "predict_var (L^-1 K*)"}
             stages = []
             for name in ("potrf", "trtri", "lauum", "predict_var"):
                 ms, n = stage_ms[name]
                 if not n:
                     continue
-                # predict_var: one launch per slab of test points, N^2*M flop over all slabs of a step
-                fl = per_call.get(name, float(N) ** 2 * M * args.steps / n)
+                # predict_var: one launch per slab of test points, N^2*M flop per problem over all slabs of a step
+                fl = per_call.get(name, float(n_obs) ** 2 * M * nprob_ * stage_steps / n)
                 tf = fl / (ms / n * 1e-3) / 1e12
                 stages.append({"stage": label[name], "calls": n, "ms_per_call": ms / n, "flop_per_call": fl,
                                "tflops": tf, "frac": tf / FP64_MFMA_PEAK_TFLOPS,
-                               "share_of_step": ms / (ms_step * args.steps)})
+                               "share_of_step": ms / (ms_step * stage_steps)})
+            return stages
+
+        if args.workload in ("c2", "c1"):
+            # sanity: the timed output is finite and shaped (units, 2, M)
+            assert res.shape == (world, 2, M) and bool(torch.isfinite(res).all())
+            if args.workload == "c2":
+                out["config"] = {"workload": ("C2: 256x256 synthetic twisted-lattice image, 25%% observed "
+                                              "(N=%d, M=%d, d=2), Matern52 exact GP, T=%d Adam its (lr 0.1) + predict; "
+                                              "one image per GPU") % (N, M, T),
+                                 "N": N, "M": M, "iterations": T, "kernel": WORKLOAD["kernel"]}
+            else:
+                out["data"] = "reference data file expdata/spiral_s_00010_2019.npy (committed fixture tests/golden/)"
+                out["config"] = {"workload": ("C1: 128x128 PFM spiral scan (expdata/spiral_s_00010_2019.npy, background "
+                                              "masked as in examples/notebooks/GP_2D3D_images.ipynb: N=%d, M=%d, d=2), RBF "
+                                              "exact GP, lengthscale in [1,4], T=%d Adam its (lr 0.1) + predict; one "
+                                              "image per GPU") % (N, M, T),
+                                 "N": N, "M": M, "iterations": T, "kernel": C1["kernel"]}
+            n3 = float(N) ** 3
+            flop_step = T * n3 + 2.0 * n3 / 3.0 + float(N) ** 2 * M       # per GPU
+            achieved = flop_step / (ms_step * 1e-3) / 1e12
+            stages = stage_breakdown(N, 1)
             lau_ms, lau_n = stage_ms["lauum"]
+            pot_ms, pot_n = stage_ms["potrf"]
             traffic = None
             pmc = os.path.join(ROOT, "profiles", "pmc_lauum.json")
-            if os.path.exists(pmc):
+            if args.workload == "c2" and os.path.exists(pmc):
                 traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            lauum_kernel = ("gemm_tiles_kernel<true, true, 0, 4, 128, 128>" if args.workload == "c2" else
+                            "gemm_tiles_kernel<true, true, 0, 4, 64, 64> (64x64 quadrants: 561 tiles)")
             out["roofline"] = {
                 "bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
                 "scope": "whole step: algorithmic flop (T*N^3 + 2N^3/3 + N^2*M = %.4g per GPU) / ms_per_step" % flop_step,
-                "kernel": "gemm_tiles_kernel (fp64 MFMA tile engine, every O(N^3) stage); largest share of the step: "
-                          "the Cholesky stage (its trailing updates are the <false,false,0,8,128,128> instance)",
+                "kernel": "gemm_tiles_kernel / chol_step_kernel (fp64 MFMA tile engine, every O(N^3) stage); largest "
+                          "share of the step: the Cholesky stage",
                 "stages": stages,
+                "stages_from": "the timed steps" if timers_inside else "one extra step after the timed ones (timers off "
+                               "in the timed steps: they replay a captured iteration)",
+                "chain_us_per_128": (pot_ms / pot_n * 1e3 / math.ceil(N / 128.0)) if pot_n else None,
                 "dominant_launch": {
-                    "kernel": "gemm_tiles_kernel<true, true, 0, 4, 128, 128> (K^-1 = L^-T L^-1: exactly one launch "
-                              "per Adam iteration, N^3/3 flop)",
+                    "kernel": lauum_kernel + " (K^-1 = L^-T L^-1: exactly one launch per Adam iteration, N^3/3 flop)",
                     "launches": lau_n, "avg_launch_ms": lau_ms / max(lau_n, 1),
                     "achieved": (n3 / 3 / (lau_ms / lau_n * 1e-3) / 1e12) if lau_n else None,
                     "traffic": traffic},
@@ -448,12 +527,25 @@ def main():
                                          % (N, M, T), "N": N, "M": M, "iterations": T, "kernel": "RBF", "slices": 64}
             flop_step = 64 * (T * float(N) ** 3 + 2.0 * float(N) ** 3 / 3.0 + float(N) ** 2 * M)
             achieved = flop_step / (ms_step * 1e-3) / 1e12 / world
+            pot_ms, pot_n = stage_ms["potrf"]
             out["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
-                               "scope": "whole step per GPU; N ~ 1200 problems are latency-bound (10-block panel "
-                                        "chains), not MFMA-bound -- see DESIGN.md"}
+                               "scope": "whole step per GPU: 64 x (T*N^3 + 2N^3/3 + N^2*M) flop / ms_per_step / n_gpus; "
+                                        "stages: rank 0's lock-step batch of %d problems per launch" % nprob,
+                               "stages": stage_breakdown(N, nprob),
+                               "stages_from": "one extra step after the timed ones (timers off in the timed steps: they "
+                                              "replay a captured iteration)",
+                               "chain_us_per_128": (pot_ms / pot_n * 1e3 / math.ceil(N / 128.0)) if pot_n else None}
+            out["stages_ms_per_call"] = {k: (v[0] / v[1] if v[1] else None) for k, v in stage_ms.items()}
         if world == 1:
-            out["cpu_baseline"] = cpu_baseline(N, M, T) if (args.workload == "c2" and not args.no_cpu_baseline) else None
+            if args.no_cpu_baseline:
+                out["cpu_baseline"] = None
+            elif args.workload == "c2":
+                out["cpu_baseline"] = cpu_baseline(N, M, T)
+            elif args.workload == "c1":
+                out["cpu_baseline"] = cpu_baseline_c1(R, T)
+            else:
+                out["cpu_baseline"] = None
             if not args.no_extra and args.workload == "c2":
                 # in a child process: the other configs launch the same kernel instantiations at other sizes,
                 # and would blur the per-kernel averages of a `rocprofv3 --stats` run of this command

@@ -482,7 +482,10 @@ static int64_t step_max_np() {
 }
 static bool use_step_schedule(const gpimhip_ctx* h, int64_t np) {
     static const bool off = getenv("GPIMHIP_OLD_POTRF") != nullptr;
-    return !off && !h->fp32 && h->dinvB != nullptr && np < step_max_np();
+    // (not for large batches: with dozens of problems per launch the chip is saturated anyway, and the hosted
+    // tiles -- one workgroup per CU next to the 134 KB factorisation role -- run slower than in their own launches:
+    // C3, 64 problems of N = 1207, 1.21 vs 1.15 s)
+    return !off && !h->fp32 && h->dinvB != nullptr && np < step_max_np() && h->nbatch <= 4;
 }
 
 int launch_potrf(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_t* info) {

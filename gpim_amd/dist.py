@@ -108,12 +108,13 @@ def run_units(units, unit_fn, out_shape, device=None, concurrency=1):
     return full[:, 0], full[:, 1]
 
 
-def reconstruct_slices(cube, axis=-1, batch=16, return_hyperparams=False, **recon_kwargs):
+def reconstruct_slices(cube, axis=-1, batch=16, return_hyperparams=False, handle=None, **recon_kwargs):
     """Independent GP reconstruction of every slice of a 3D / 4D cube along `axis` (configs C3 and
     C5 of SURVEY 8(d)).  Slices are sharded over the ranks; on each GPU the owned slices with the same
     number of observations advance in lock-step, `batch` at a time, through the batched engine
     (gpim_amd.batch) -- a single ~1000-point fit is latency-bound and leaves most of the chip idle.
     Per-slice results are those of ``reconstructor(X_slice, R_slice, X_full, **recon_kwargs).run()``.
+    handle: an existing ``_lib.Handle`` for the batched fits (its workspace is reused between calls).
     Returns (mean, sd) cubes on rank 0 (None elsewhere)."""
     from . import gprutils
     from .batch import fit_predict_batch
@@ -121,7 +122,7 @@ def reconstruct_slices(cube, axis=-1, batch=16, return_hyperparams=False, **reco
     cube = np.moveaxis(np.asarray(cube), axis, 0)
     nunits = cube.shape[0]
     rank, ws = world()
-    dev = torch.device("cuda", torch.cuda.current_device())
+    dev = handle.device if handle is not None else torch.device("cuda", torch.cuda.current_device())
     owned = shard_units(nunits, rank, ws)
     Xf = gprutils.get_full_grid(cube[0])
     mine, hyper = {}, {}
@@ -148,7 +149,7 @@ def reconstruct_slices(cube, axis=-1, batch=16, return_hyperparams=False, **reco
         for s in range(0, len(idxs), batch):
             grp = idxs[s:s + batch]
             Xs = [grid_of(cube[i]) for i in grp]
-            mean, sd, hist = fit_predict_batch(Xs, [cube[i] for i in grp], Xf, **recon_kwargs)
+            mean, sd, hist = fit_predict_batch(Xs, [cube[i] for i in grp], Xf, handle=handle, **recon_kwargs)
             for k, i in enumerate(grp):
                 mine[i] = torch.stack([mean[k], sd[k]])
                 hyper[i] = hist[k].cpu().numpy()

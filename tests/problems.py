@@ -60,6 +60,18 @@ def spiral_image(size=128, keep=0.257, seed=0):
     return R, img
 
 
+def spiral_pfm_image():
+    """Config C1 as the reference defines it (SURVEY 8(d) "Config 1"): the 128x128 PFM spiral scan
+    ``expdata/spiral_s_00010_2019.npy`` (a data file of the reference, committed as the fixture
+    tests/golden/spiral_s_00010_2019.npy), normalised (x - min) / ptp, the constant background set to NaN
+    as examples/notebooks/GP_2D3D_images.ipynb does: N = 4212 observations, M = 16384."""
+    import os
+    img = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "spiral_s_00010_2019.npy"))
+    R = (img - np.amin(img)) / np.ptp(img)
+    R[R == R[1, 1]] = np.nan
+    return R
+
+
 def lattice_image(size=256, frac=0.25, seed=1):
     """Synthetic twin of config C2: twisted-bilayer hexagonal lattice image,
     `frac` of the pixels observed uniformly at random."""
