@@ -471,21 +471,18 @@ static int panel_steps(gpimhip_ctx* h, double* A, int64_t ld, int32_t* info, int
     return GPIMHIP_OK;
 }
 
-// Which schedule factors a matrix of order np: the single-stream step schedule of cholstep.hip (the launch that
-// factors a diagonal block hosts the trailing-update tiles) up to STEP_MAX_NP, the two-stream look-ahead below
-// beyond it (measured, potrf alone: 0.51 vs 0.66 ms at 1280, 1.86 vs 2.72 at 4224, 6.4 vs 7.05 at 8192, but
-// 33.3 - 35.2 vs 33.0 at 16384, where one workgroup per CU -- the occupancy the 134 KB diagonal-block role
-// imposes on the hosting launch -- costs the bulk tiles 7 %).
-static int64_t step_max_np() {
-    static const int64_t v = getenv("GPIMHIP_STEP_MAX_NP") ? atoll(getenv("GPIMHIP_STEP_MAX_NP")) : 12288;
-    return v;
-}
+// Which schedule factors a matrix: the single-stream step schedule of cholstep.hip (the launch that factors a
+// diagonal block hosts the pending column updates) for double-precision handles, the two-stream look-ahead below
+// for single-precision ones.  Measured, potrf alone, step schedule vs look-ahead: 0.51 vs 0.66 ms at N = 1280,
+// 1.86 vs 2.72 at 4224, 6.4 vs 7.05 at 8192, 10.2 vs 10.8 at 10240, 15.7 vs 16.1 at 12288, 32.1 vs 32.9 at 16384,
+// 57.9 vs 59.2 at 20480.
 static bool use_step_schedule(const gpimhip_ctx* h, int64_t np) {
     static const bool off = getenv("GPIMHIP_OLD_POTRF") != nullptr;
+    (void)np;
     // (not for large batches: with dozens of problems per launch the chip is saturated anyway, and the hosted
     // tiles -- one workgroup per CU next to the 134 KB factorisation role -- run slower than in their own launches:
     // C3, 64 problems of N = 1207, 1.21 vs 1.15 s)
-    return !off && !h->fp32 && h->dinvB != nullptr && np < step_max_np() && h->nbatch <= 4;
+    return !off && !h->fp32 && h->dinvB != nullptr && h->nbatch <= 4;
 }
 
 int launch_potrf(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_t* info) {
@@ -664,8 +661,16 @@ static int loss_grad_at_u(gpimhip_ctx* h, const gpimhip_model_t* m, const double
     const int64_t np = h->np;
     // In the look-ahead regime the panel stream exists and is idle after the factorisation: the two
     // HBM-bound mat-vecs over L^-1 run there, next to the MFMA-bound K^-1 product (both only read L^-1).
-    const bool side = h->panel_stream != nullptr && (int)((np / NB + OUTER_W - 1) / OUTER_W) >= LOOKAHEAD_MIN_PANELS &&
-                      h->ev_pool.size() >= 2 && !use_step_schedule(h, np);
+    bool side = (int)((np / NB + OUTER_W - 1) / OUTER_W) >= LOOKAHEAD_MIN_PANELS;
+    if (side) {
+        ensure_lookahead_streams(h);
+        while (h->ev_pool.size() < 2) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            h->ev_pool.push_back(e);
+        }
+        side = h->panel_stream != nullptr;
+    }
     GP_TRY(factor_at_u(h, m, X, x_bs, N, u, side));
     if (side) {
         hipStream_t main_s = h->stream;
@@ -923,8 +928,8 @@ static int fit_impl(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X, i
     // of one launch call per kernel.  Not used with the multi-stream look-ahead schedule (large N,
     // where launch cost is irrelevant), while stage timing is on, or for very short fits.
     const int npanel = (int)((h->np / NB + OUTER_W - 1) / OUTER_W);
-    bool use_graph = T >= 8 && !h->timing && (npanel < LOOKAHEAD_MIN_PANELS || use_step_schedule(h, h->np)) &&
-                     ensure_capture_stream(h) && !getenv("GPIMHIP_NO_GRAPH");
+    bool use_graph = T >= 8 && !h->timing && npanel < LOOKAHEAD_MIN_PANELS && ensure_capture_stream(h) &&
+                     !getenv("GPIMHIP_NO_GRAPH");
     if (use_graph) {
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;

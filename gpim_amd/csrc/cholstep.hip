@@ -36,13 +36,24 @@ struct StepArgs {
 // blockIdx.x == 0: potf2 of block kblk; 1..7: idle (keeps filler b on XCD b % 8, which the tile engine's
 // XCD-aware list mapping assumes); >= 8: filler tile b - 8.  FTS: 128 = one workgroup per 128x128 tile,
 // 64 = one per 64x64 quadrant (few tiles: spread each over four CUs).
+// The hosted tiles run one workgroup per CU.  A ring of 3 - 6 LDS stages (the factorisation role's 134 KB are
+// reserved anyway; gemm_tile_body<..., NSTG>, build with -DGPIMHIP_STEP_RING) that keeps the loads of several
+// k-steps in flight was measured and does NOT help: potrf 1.91 vs 1.86 ms at N = 4224, 6.58 vs 6.39 at 8192,
+// 32.7 vs 32.1 at 16384 -- what a lone 8-wave workgroup lacks is not load latency cover.
 template <int FTM, int FTN>
 __global__ __launch_bounds__(NTH, 1) void chol_step_kernel(StepArgs a) {
-    constexpr int SM = POTF2_SMEM_DOUBLES > gemm_smem_doubles<FTM, FTN>() ? POTF2_SMEM_DOUBLES : gemm_smem_doubles<FTM, FTN>();
+#ifdef GPIMHIP_STEP_RING
+    constexpr int NSTG = (FTM == 128 && FTN == 128) ? 3 : (FTM == 128 ? 4 : 6);
+#else
+    constexpr int NSTG = 2;
+#endif
+    constexpr int SM = POTF2_SMEM_DOUBLES > gemm_smem_doubles<FTM, FTN, NSTG>() ? POTF2_SMEM_DOUBLES
+                                                                                : gemm_smem_doubles<FTM, FTN, NSTG>();
+    static_assert(SM * 8 <= 160 * 1024, "LDS");
     __shared__ __attribute__((aligned(16))) double smem[SM];
     const int b = blockIdx.x;
     if (b >= 8) {
-        gemm_tile_body<false, false, EPI_STORE, 8, FTM, FTN>(a.g, b - 8, (int)blockIdx.y, smem);
+        gemm_tile_body<false, false, EPI_STORE, 8, FTM, FTN, NSTG>(a.g, b - 8, (int)blockIdx.y, smem);
         return;
     }
     if (b != 0) return;
@@ -159,11 +170,16 @@ static void lower_patches(std::vector<TileDesc>& out, int lo, int hi, int kb0, i
                     if (j <= i) out.push_back({i, j, kb0, kb1});
 }
 
-// share of the previous panel's bulk update hosted by one step launch: at most this many tiles; what is left
-// runs as a plain tile-engine launch (two workgroups per CU) before the panel's first step
-static int fill_cap() {
-    static const int v = getenv("GPIMHIP_FILL_CAP") ? atoi(getenv("GPIMHIP_FILL_CAP")) : (1 << 30);
-    return v;
+// Share of the previous panel's bulk update hosted by one step launch: at most this many tiles; what is left runs
+// as a plain tile-engine launch before the panel's first step.  Hosted tiles run one workgroup per CU (the 134 KB
+// factorisation role sets the launch's LDS size), 7 % slower than in their own launch (two per CU): up to
+// nb = 63 everything is hosted (the factorisation is bound by the chain of diagonal blocks, hosted tiles are
+// free), beyond that 32 tiles per launch (N = 16384: 32.1 ms with 0 / 32 / 128, 34.0 with everything hosted;
+// N = 10240: 10.6 / 10.2 / 10.8 / 10.6).
+static int fill_cap(int nb) {
+    static const int v = getenv("GPIMHIP_FILL_CAP") ? atoi(getenv("GPIMHIP_FILL_CAP")) : -1;
+    if (v >= 0) return v;
+    return nb < 64 ? (1 << 30) : 32;
 }
 
 int step_plan_ensure(gpimhip_ctx* h, int nb) {
@@ -182,7 +198,7 @@ int step_plan_ensure(gpimhip_ctx* h, int nb) {
         // bulk(p-1): columns >= p0 + W, k-blocks = the columns of panel p-1
         std::vector<TileDesc> bulk;
         if (p > 0 && p0 + W < nb) lower_patches(bulk, p0 + W, nb, p0 - W, p0);
-        const int per = std::min<int>(fill_cap(), (int)((bulk.size() + ncol - 1) / ncol));
+        const int per = std::min<int>(fill_cap(nb), (int)((bulk.size() + ncol - 1) / ncol));
         size_t taken = 0;
         for (int j = p0; j < p1; ++j) {
             size_t s = tl.size();

@@ -109,12 +109,16 @@ __device__ __forceinline__ double frag(const double* lds, int m0, int kk, int la
 // bx / by: the workgroup's position in a plain tile launch (block index x / y); smem: gemm_smem_doubles<TSM, TSN>()
 // doubles of LDS.  A device function so that other kernels can host tile work next to their own (cholstep.hip:
 // the diagonal-block factorisation shares its launch with trailing-update tiles).
-template <int TSM, int TSN>
+// NSTG: LDS stages.  2 = double buffering (prefetch distance 1; with two or more workgroups per CU the other
+// workgroup's MFMAs cover a stage's load latency).  > 2 = a ring with prefetch distance NSTG - 1 for launches that
+// can only have ONE workgroup per CU (tiles hosted by the Cholesky step kernel, whose factorisation role sizes the
+// launch's LDS): the loads of NSTG - 1 k-steps are in flight while one is consumed.
+template <int TSM, int TSN, int NSTG = 2>
 __host__ __device__ constexpr int gemm_smem_doubles() {
     constexpr int TSX = TSM > TSN ? TSM : TSN;
-    return 4 * ((TSX * LD_MK > GEMM_BK * (TSX + 16)) ? TSX * LD_MK : GEMM_BK * (TSX + 16));
+    return 2 * NSTG * ((TSX * LD_MK > GEMM_BK * (TSX + 16)) ? TSX * LD_MK : GEMM_BK * (TSX + 16));
 }
-template <bool A_KM, bool B_KM, int EPI, int NW, int TSM, int TSN>
+template <bool A_KM, bool B_KM, int EPI, int NW, int TSM, int TSN, int NSTG = 2>
 __device__ __forceinline__ void gemm_tile_body(GemmArgs g, const int bx, const int by, double* __restrict__ smem) {
     constexpr int NT = NW * 64;             // threads
     constexpr int WGM = NW / 2;             // waves along m (2 along n)
@@ -183,60 +187,102 @@ __device__ __forceinline__ void gemm_tile_body(GemmArgs g, const int bx, const i
     // they share are still in the XCD's L2 when the next tile asks for them.
     const int64_t kfirst = g.krev ? (int64_t)(nsteps - 1) * GEMM_BK : 0;
     const int64_t kstride = g.krev ? -GEMM_BK : GEMM_BK;
-    d2 ra[NCHA], rb[NCHB];
-    if (nsteps > 0) {
-        if (ADIR) stage_direct<A_KM, NW, TSM>(g.A, g.lda, a_m0, a_k0 + kfirst, smem, wave, lane);
-        else stage_load<A_KM, NT, TSM>(ra, g.A, g.lda, a_m0, a_k0 + kfirst, tid);
-        if (BDIR) stage_direct<B_KM, NW, TSN>(g.B, g.ldb, b_n0, b_k0 + kfirst, smem + STAGE, wave, lane);
-        else stage_load<B_KM, NT, TSN>(rb, g.B, g.ldb, b_n0, b_k0 + kfirst, tid);
-        if (!ADIR) stage_store<A_KM, NT, TSM>(ra, smem, tid);
-        if (!BDIR) stage_store<B_KM, NT, TSN>(rb, smem + STAGE, tid);
-        if (ADIR || BDIR) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __syncthreads();
-
-    for (int s = 0; s < nsteps; ++s) {
-        const double* As = smem + (s & 1) * 2 * STAGE;
-        const double* Bs = As + STAGE;
-        const bool more = (s + 1 < nsteps);
-        if (more) {
-            // the other stage buffer was last read in step s-1: every wave is past that barrier
-            double* An = smem + ((s + 1) & 1) * 2 * STAGE;
-            const int64_t koff = kfirst + (int64_t)(s + 1) * kstride;
-            if (ADIR) stage_direct<A_KM, NW, TSM>(g.A, g.lda, a_m0, a_k0 + koff, An, wave, lane);
-            else stage_load<A_KM, NT, TSM>(ra, g.A, g.lda, a_m0, a_k0 + koff, tid);
-            if (BDIR) stage_direct<B_KM, NW, TSN>(g.B, g.ldb, b_n0, b_k0 + koff, An + STAGE, wave, lane);
-            else stage_load<B_KM, NT, TSN>(rb, g.B, g.ldb, b_n0, b_k0 + koff, tid);
-        }
-        // The MFMA block runs at raised wave priority: the arbiter then prefers this wave's MFMAs and
-        // fragment reads over the other resident wave's staging instructions, which otherwise steal
-        // issue slots from the matrix pipe (tools/gemm_ablate.hip: 66.1 -> 71.2 TFLOP/s for this loop).
-        __builtin_amdgcn_s_setprio(3);
+    if constexpr (NSTG > 2) {
+        static_assert(ADIR && BDIR, "the stage ring needs both operands staged global -> LDS directly");
+        constexpr int DIST = NSTG - 1;                                  // prefetch distance in k-steps
+        constexpr int LPS = (A_KM ? GEMM_BK / NW : (TSM / 8) / NW) + (B_KM ? GEMM_BK / NW : (TSN / 8) / NW);   // loads per wave per stage
+        static_assert(LPS * (DIST - 1) < 64, "vmcnt is a 6-bit counter");
+        auto issue = [&](int st) {
+            double* An = smem + (st % NSTG) * 2 * STAGE;
+            const int64_t koff = kfirst + (int64_t)st * kstride;
+            stage_direct<A_KM, NW, TSM>(g.A, g.lda, a_m0, a_k0 + koff, An, wave, lane);
+            stage_direct<B_KM, NW, TSN>(g.B, g.ldb, b_n0, b_k0 + koff, An + STAGE, wave, lane);
+        };
+        for (int st = 0; st < DIST && st < nsteps; ++st) issue(st);
+        for (int s = 0; s < nsteps; ++s) {
+            // stage s has landed once at most the DIST - 1 younger stages are still in flight (loads retire in order)
+            if (s + DIST - 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS * (DIST - 1)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();        // ... for every wave; and every wave is done with stage s - 1, whose slot is refilled now
+            if (s + DIST < nsteps) issue(s + DIST);
+            const double* As = smem + (s % NSTG) * 2 * STAGE;
+            const double* Bs = As + STAGE;
+            __builtin_amdgcn_s_setprio(3);
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            double a[MT], bb[NTL];
+            for (int kk = 0; kk < 4; ++kk) {
+                double a[MT], bb[NTL];
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
-                a[i] = (ADIR && !A_KM) ? frag_mk_swz(As, wm * WROWS + i * 16, kk, lane)
-                                       : frag<A_KM, TSM>(As, wm * WROWS + i * 16, kk, lane);
-#pragma unroll
-            for (int j = 0; j < NTL; ++j)
-                bb[j] = (BDIR && !B_KM) ? frag_mk_swz(Bs, wn * WCOLS + j * 16, kk, lane)
-                                        : frag<B_KM, TSN>(Bs, wn * WCOLS + j * 16, kk, lane);
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
+                for (int i = 0; i < MT; ++i)
+                    a[i] = (!A_KM) ? frag_mk_swz(As, wm * WROWS + i * 16, kk, lane) : frag<A_KM, TSM>(As, wm * WROWS + i * 16, kk, lane);
 #pragma unroll
                 for (int j = 0; j < NTL; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bb[j], acc[i][j], 0, 0, 0);
+                    bb[j] = (!B_KM) ? frag_mk_swz(Bs, wn * WCOLS + j * 16, kk, lane) : frag<B_KM, TSN>(Bs, wn * WCOLS + j * 16, kk, lane);
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NTL; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bb[j], acc[i][j], 0, 0, 0);
+            }
+            __builtin_amdgcn_s_setprio(0);
         }
-        __builtin_amdgcn_s_setprio(0);
-        if (more) {
-            double* An = smem + ((s + 1) & 1) * 2 * STAGE;
-            if (!ADIR) stage_store<A_KM, NT, TSM>(ra, An, tid);
-            if (!BDIR) stage_store<B_KM, NT, TSN>(rb, An + STAGE, tid);
+        __syncthreads();
+    } else {
+        d2 ra[NCHA], rb[NCHB];
+        if (nsteps > 0) {
+            if (ADIR) stage_direct<A_KM, NW, TSM>(g.A, g.lda, a_m0, a_k0 + kfirst, smem, wave, lane);
+            else stage_load<A_KM, NT, TSM>(ra, g.A, g.lda, a_m0, a_k0 + kfirst, tid);
+            if (BDIR) stage_direct<B_KM, NW, TSN>(g.B, g.ldb, b_n0, b_k0 + kfirst, smem + STAGE, wave, lane);
+            else stage_load<B_KM, NT, TSN>(rb, g.B, g.ldb, b_n0, b_k0 + kfirst, tid);
+            if (!ADIR) stage_store<A_KM, NT, TSM>(ra, smem, tid);
+            if (!BDIR) stage_store<B_KM, NT, TSN>(rb, smem + STAGE, tid);
             if (ADIR || BDIR) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads();
+
+        for (int s = 0; s < nsteps; ++s) {
+            const double* As = smem + (s & 1) * 2 * STAGE;
+            const double* Bs = As + STAGE;
+            const bool more = (s + 1 < nsteps);
+            if (more) {
+                // the other stage buffer was last read in step s-1: every wave is past that barrier
+                double* An = smem + ((s + 1) & 1) * 2 * STAGE;
+                const int64_t koff = kfirst + (int64_t)(s + 1) * kstride;
+                if (ADIR) stage_direct<A_KM, NW, TSM>(g.A, g.lda, a_m0, a_k0 + koff, An, wave, lane);
+                else stage_load<A_KM, NT, TSM>(ra, g.A, g.lda, a_m0, a_k0 + koff, tid);
+                if (BDIR) stage_direct<B_KM, NW, TSN>(g.B, g.ldb, b_n0, b_k0 + koff, An + STAGE, wave, lane);
+                else stage_load<B_KM, NT, TSN>(rb, g.B, g.ldb, b_n0, b_k0 + koff, tid);
+            }
+            // The MFMA block runs at raised wave priority: the arbiter then prefers this wave's MFMAs and
+            // fragment reads over the other resident wave's staging instructions, which otherwise steal
+            // issue slots from the matrix pipe (tools/gemm_ablate.hip: 66.1 -> 71.2 TFLOP/s for this loop).
+            __builtin_amdgcn_s_setprio(3);
+    #pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                double a[MT], bb[NTL];
+    #pragma unroll
+                for (int i = 0; i < MT; ++i)
+                    a[i] = (ADIR && !A_KM) ? frag_mk_swz(As, wm * WROWS + i * 16, kk, lane)
+                                           : frag<A_KM, TSM>(As, wm * WROWS + i * 16, kk, lane);
+    #pragma unroll
+                for (int j = 0; j < NTL; ++j)
+                    bb[j] = (BDIR && !B_KM) ? frag_mk_swz(Bs, wn * WCOLS + j * 16, kk, lane)
+                                            : frag<B_KM, TSN>(Bs, wn * WCOLS + j * 16, kk, lane);
+    #pragma unroll
+                for (int i = 0; i < MT; ++i)
+    #pragma unroll
+                    for (int j = 0; j < NTL; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bb[j], acc[i][j], 0, 0, 0);
+            }
+            __builtin_amdgcn_s_setprio(0);
+            if (more) {
+                double* An = smem + ((s + 1) & 1) * 2 * STAGE;
+                if (!ADIR) stage_store<A_KM, NT, TSM>(ra, An, tid);
+                if (!BDIR) stage_store<B_KM, NT, TSN>(rb, An + STAGE, tid);
+                if (ADIR || BDIR) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __syncthreads();
+        }
+
     }
 
     if (EPI == EPI_STORE) {
