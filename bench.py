@@ -329,13 +329,13 @@ def main():
 
     def fence():
         if world > 1:
-            dist.barrier(device_ids=[local_rank])
+            gdist.barrier()
         torch.cuda.synchronize()
 
     if world > 1:
         # bring the RCCL communicators up outside the timed region even when --warmup 0
         probe = torch.zeros(8, dtype=torch.float64, device=dev)
-        dist.all_gather([torch.empty_like(probe) for _ in range(world)], probe)
+        gdist.all_gather([torch.empty_like(probe) for _ in range(world)], probe)
         fence()
 
     stage_ms = {}
@@ -558,7 +558,7 @@ def main():
                     out["extra"] = {"error": (child.stderr or child.stdout)[-400:]}
         print(json.dumps(out))
     if world > 1:
-        dist.barrier(device_ids=[local_rank])
+        gdist.barrier()
         dist.destroy_process_group()
 
 

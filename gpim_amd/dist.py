@@ -20,19 +20,60 @@ import torch.distributed as dist
 
 def init_from_env(backend=None):
     """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun contract).
-    Returns (rank, world_size, local_rank).  Single-process runs need no initialisation."""
+    Returns (rank, world_size, local_rank).  Single-process runs need no initialisation.
+    backend: "nccl" (= RCCL; the default on a GPU box), "gloo", or the environment variable GPIM_DIST_BACKEND.
+    With gloo several ranks may share one GPU (local_rank is taken modulo the device count) -- RCCL refuses
+    that -- which is how the multi-rank code paths are exercised on a one-GPU box (tests/test_gpu_dist2.py)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.is_available():
+        local_rank %= max(1, torch.cuda.device_count())
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
+            backend = os.environ.get("GPIM_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if torch.cuda.is_available():
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local_rank
+
+
+def _host_staged(t):
+    """gloo moves device tensors only for broadcast and all_reduce: the other collectives stage through the host."""
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
+def barrier():
+    if dist.is_available() and dist.is_initialized():
+        if dist.get_backend() == "nccl":
+            dist.barrier(device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier()
+
+
+def all_gather(parts, t, group=None):
+    """dist.all_gather(parts, t) for either backend (parts: list of tensors like t, filled in place)."""
+    if _host_staged(t):
+        host = [torch.empty(p.shape, dtype=p.dtype) for p in parts]
+        dist.all_gather(host, t.cpu(), group=group)
+        for p, hp in zip(parts, host):
+            p.copy_(hp)
+    else:
+        dist.all_gather(parts, t, group=group)
+
+
+def gather(t, parts, dst=0, group=None):
+    """dist.gather(t, gather_list=parts, dst) for either backend (parts: list on the root, None elsewhere)."""
+    if _host_staged(t):
+        host = [torch.empty(p.shape, dtype=p.dtype) for p in parts] if parts is not None else None
+        dist.gather(t.cpu(), gather_list=host, dst=dst, group=group)
+        if parts is not None:
+            for p, hp in zip(parts, host):
+                p.copy_(hp)
+    else:
+        dist.gather(t, gather_list=parts, dst=dst, group=group)
 
 
 def world():
@@ -65,10 +106,10 @@ def gather_to_root(local, n_units, unit_shape, device=None, dtype=torch.float64)
         # one gather to rank 0 (RCCL ncclGather = grouped send/recv): only the root receives the slabs
         parts = [torch.empty_like(slab) for _ in range(ws)] if rank == 0 else None
         try:
-            dist.gather(slab, gather_list=parts, dst=0)
+            gather(slab, parts, dst=0)
         except (RuntimeError, NotImplementedError):      # a backend without gather: every rank takes every slab
             parts = [torch.empty_like(slab) for _ in range(ws)]
-            dist.all_gather(parts, slab)
+            all_gather(parts, slab)
         if rank != 0:
             return None
     full = torch.empty((n_units,) + tuple(unit_shape), dtype=dtype, device=device)
@@ -100,8 +141,7 @@ def run_units(units, unit_fn, out_shape, device=None, concurrency=1):
     if device is None and mine:
         device = next(iter(mine.values())).device
     if device is None:
-        device = torch.device("cuda", torch.cuda.current_device()) if (
-            dist.is_initialized() and dist.get_backend() == "nccl") else torch.device("cpu")
+        device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
     full = gather_to_root(mine, len(units), (2,) + tuple(out_shape), device=device)
     if full is None:
         return None
@@ -181,8 +221,8 @@ def global_topk(local_vals, local_idx, k, nan_first=False):
     if ws > 1:
         vs = [torch.empty_like(vals) for _ in range(ws)]
         ix = [torch.empty_like(idx) for _ in range(ws)]
-        dist.all_gather(vs, vals)
-        dist.all_gather(ix, idx)
+        all_gather(vs, vals)
+        all_gather(ix, idx)
         vals, idx = torch.cat(vs), torch.cat(ix)
     keep = idx >= 0
     if not nan_first:
@@ -208,6 +248,6 @@ def all_gather_blocks(block, M):
     pad = torch.full((per,), float("nan"), dtype=block.dtype, device=block.device)
     pad[:block.numel()] = block
     parts = [torch.empty_like(pad) for _ in range(ws)]
-    dist.all_gather(parts, pad)
+    all_gather(parts, pad)
     return torch.cat(parts)[:M] if per * ws == M else torch.cat(
         [parts[r][:max(0, min(per, M - r * per))] for r in range(ws)])

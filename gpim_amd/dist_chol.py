@@ -318,8 +318,9 @@ def exact_gp_posterior(X, y, Xtest, kernel="Matern52", lengthscale=None, varianc
             q = chol.solve_colsumsq(Ks)
             part[1, s0 - lo:s1 - lo] = torch.sqrt(torch.clamp(variance - q, min=0.0) + noise)
     if world > 1:
+        from .dist import all_gather
         parts = [torch.empty_like(part) for _ in range(world)]
-        dist.all_gather(parts, part, group=group)
+        all_gather(parts, part, group=group)
         full = torch.cat([parts[r][:, :max(0, min(per, M - r * per))] for r in range(world)], dim=1)
     else:
         full = part[:, :M]
