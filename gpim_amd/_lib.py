@@ -78,8 +78,13 @@ _PROTOS = {
     "gpimhip_dist_begin": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64]),
     "gpimhip_dist_panel_factor": (ctypes.c_int, [ctypes.c_void_p, c_dp, ctypes.c_int64, ctypes.c_int32,
                                                  ctypes.c_int32, c_dp, c_dp]),
-    "gpimhip_dist_trailing_update": (ctypes.c_int, [ctypes.c_void_p, c_dp, ctypes.c_int64, ctypes.c_int32, c_dp,
-                                                    ctypes.c_int64, ctypes.c_int32, ctypes.c_int32]),
+    "gpimhip_dist_setup": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32]),
+    "gpimhip_dist_panel_pack": (ctypes.c_int, [ctypes.c_void_p, c_dp, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
+                                               c_dp, ctypes.c_int64]),
+    "gpimhip_dist_update": (ctypes.c_int, [ctypes.c_void_p, c_dp, ctypes.c_int64, ctypes.c_int32, c_dp, ctypes.c_int64,
+                                           ctypes.c_int32, ctypes.c_int32]),
+    "gpimhip_dist_solve_update": (ctypes.c_int, [ctypes.c_void_p, c_dp, ctypes.c_int64, ctypes.c_int32, c_dp,
+                                                 ctypes.c_int64, ctypes.c_int64, c_dp, ctypes.c_int64, c_dp]),
     "gpimhip_set_precision": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32]),
     "gpimhip_acquire_exact": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ModelStruct), c_dp, c_dp, ctypes.c_int64,
                                              c_dp, c_dp, ctypes.c_int64, c_dp, ctypes.c_int64, ctypes.c_int32,
@@ -136,11 +141,11 @@ def check(rc):
 class Handle:
     """Owns one gpimhip_handle bound to torch's current stream on the current device."""
 
-    def __init__(self, precision="double"):
+    def __init__(self, precision="double", stream=None):
         self.device = require_gpu()
         lib = load()
         h = ctypes.c_void_p()
-        stream = torch.cuda.current_stream(self.device).cuda_stream
+        stream = (stream or torch.cuda.current_stream(self.device)).cuda_stream
         check(lib.gpimhip_create(ctypes.byref(h), self.device.index, ctypes.c_void_p(stream)))
         self._h = h
         self.lib = lib

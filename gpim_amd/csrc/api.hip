@@ -111,9 +111,6 @@ static void ws_release_matrix(gpimhip_ctx* h) {
     dev_free(h, &h->adam_m, B * MAXP);
     dev_free(h, &h->adam_v, B * MAXP);
     dev_free(h, &h->iter, B);
-    // the trailing-update tile lists of the distributed factorisation cover block rows up to nb - 1
-    for (auto& d : h->dist_lists) dev_free(h, &d.tiles, d.n);
-    h->dist_lists.clear();
     h->np = 0;
     h->ws_batch = 0;
 }
@@ -143,7 +140,7 @@ static int ws_ensure_b(gpimhip_ctx* h, int64_t N, int B, int padded, bool matric
                       (rc = dev_alloc(h, &h->B, mat_doubles(h, B * np * ld))) ||
                       (rc = dev_alloc(h, &h->Tm, mat_doubles(h, B * np * ld))))) ||
         (rc = dev_alloc(h, &h->dinv, mat_doubles(h, B * nb * NB * NB))) ||
-        (matrices && !h->fp32 && (rc = dev_alloc(h, &h->dinvB, B * nb * NB * NB))) ||
+        (!h->fp32 && (rc = dev_alloc(h, &h->dinvB, B * nb * NB * NB))) ||
         (rc = dev_alloc(h, &h->ypad, B * np)) || (rc = dev_alloc(h, &h->z, B * np)) ||
         (rc = dev_alloc(h, &h->alpha, B * np)) || (rc = dev_alloc(h, &h->logdet_part, B * nb)) ||
         (rc = dev_alloc(h, &h->grad_part, B * nb * (nb + 1) / 2 * 8)) || (rc = dev_alloc(h, &h->theta, (int64_t)B)) ||
@@ -161,9 +158,12 @@ static int ws_ensure_b(gpimhip_ctx* h, int64_t N, int B, int padded, bool matric
         }
         h->refine_cap = 10 * (int64_t)B * np;
     }
-    GP_TRY(plan_ensure(h, (int)nb));
-    // (the step schedule's plan too: building it synchronises the stream, which a graph capture does not allow)
-    if (h->dinvB) GP_TRY(step_plan_ensure(h, (int)nb));
+    // launch plans of the single-GPU path (built here: building one synchronises the stream, which a graph
+    // capture does not allow); the distributed factorisation has its own (gpimhip_dist_setup)
+    if (matrices) {
+        GP_TRY(plan_ensure(h, (int)nb));
+        if (h->dinvB) GP_TRY(step_plan_ensure(h, (int)nb));
+    }
     return GPIMHIP_OK;
 }
 int ws_ensure(gpimhip_ctx* h, int64_t N) { return ws_ensure_b(h, N, h->nbatch, 0); }
@@ -769,6 +769,7 @@ struct RunAhead {
 int vfe_finish_and_check(gpimhip_ctx* h) { return finish_and_check(h); }
 void vfe_release(gpimhip_ctx* h);
 void kron_release(gpimhip_ctx* h);
+static void dist_plan_release(gpimhip_ctx* h);
 
 // ------------------------------------------------------------------------------------------
 // C ABI
@@ -823,6 +824,7 @@ int gpimhip_destroy(gpimhip_handle h) {
     dev_free(h, &h->info, 4);
     if (h->plan.d_tiles) (void)hipFree(h->plan.d_tiles);
     step_plan_release(h);
+    dist_plan_release(h);
     for (auto e : h->ev_pool) (void)hipEventDestroy(e);
     for (auto e : h->ra_ev)
         if (e) (void)hipEventDestroy(e);
@@ -1163,68 +1165,190 @@ int gpimhip_topk(gpimhip_handle h, const double* acq, int64_t M, int32_t k, int3
     return launch_topk(h, acq, M, k, keep_nan, vals_out, idx_out, count_out);
 }
 
-// ---- distributed (block-column-cyclic) factorisation: building blocks (see include/gpimhip.h) ----
-int gpimhip_dist_begin(gpimhip_handle h, int64_t n) {
+// ---- distributed (block-column-cyclic, 1 x P) exact GP: building blocks (see include/gpimhip.h) ----
+static void dist_plan_release(gpimhip_ctx* h) {
+    DistPlan& D = h->dplan;
+    if (D.d_tiles) (void)hipFree(D.d_tiles);
+    if (D.d_rect) (void)hipFree(D.d_rect);
+    D = DistPlan();
+}
+
+static int upload_tiles(gpimhip_ctx* h, const std::vector<TileDesc>& tl, TileDesc** out) {
+    void* q = nullptr;
+    HIP_TRY(hipMalloc(&q, std::max<size_t>(tl.size(), 1) * sizeof(TileDesc)));
+    *out = (TileDesc*)q;
+    HIP_TRY(hipMemcpyAsync(q, tl.data(), tl.size() * sizeof(TileDesc), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return GPIMHIP_OK;
+}
+
+int gpimhip_dist_setup(gpimhip_handle h, int64_t n, int32_t world, int32_t rank) {
     FP64_ONLY(h);
-    if (!h || n < 1) return GPIMHIP_E_BADARG;
+    if (!h || n < 1 || world < 1 || rank < 0 || rank >= world) return GPIMHIP_E_BADARG;
     HIP_TRY(hipSetDevice(h->device));
     h->nbatch = 1;
     GP_TRY(ws_ensure_b(h, n, 1, 0, false));
     HIP_TRY(hipMemsetAsync(h->info, 0, sizeof(int32_t), h->stream));
+    const int nb = (int)(h->np / NB);
+    DistPlan& D = h->dplan;
+    if (D.nb == nb && D.world == world && D.rank == rank) return GPIMHIP_OK;
+    dist_plan_release(h);
+    std::vector<TileDesc> tl;
+    auto mark = [&](size_t start) { return PlanRange{(int64_t)start, (int32_t)(tl.size() - start)}; };
+    D.colfill.assign(nb, {0, 0});
+    const int npanel = (nb + OUTER_W - 1) / OUTER_W;
+    D.upd_panel.assign(npanel, {0, 0});
+    for (int j = 0; j < nb; ++j) {
+        const int p0 = (j / OUTER_W) * OUTER_W;
+        size_t s0 = tl.size();
+        if (j > p0)
+            for (int i = j + 1; i < nb; ++i) tl.push_back({i, j, p0, j});
+        D.colfill[j] = mark(s0);
+    }
+    // trailing-update tiles of the owned panels, ascending: a round updates a contiguous range of them.  kb0 carries
+    // the LOCAL block column of the output (GemmArgs::cmap), the k-range comes from kfix.
+    int slot = 0;
+    for (int c = 0; c < npanel; ++c) {
+        if (c % world != rank) continue;
+        size_t s0 = tl.size();
+        const int j0 = c * OUTER_W, j1 = std::min(j0 + OUTER_W, nb);
+        for (int ig = j0 / 8; ig <= (nb - 1) / 8; ++ig)
+            for (int i = std::max(j0, ig * 8); i < std::min(nb, ig * 8 + 8); ++i)
+                for (int j = j0; j < std::min(j1, i + 1); ++j) tl.push_back({i, j, slot * OUTER_W + (j - j0), 0});
+        D.upd_panel[c] = mark(s0);
+        ++slot;
+    }
+    D.n_tiles = (int64_t)tl.size();
+    GP_TRY(upload_tiles(h, tl, &D.d_tiles));
+    D.nb = nb; D.world = world; D.rank = rank;
     return GPIMHIP_OK;
 }
+
+int gpimhip_dist_begin(gpimhip_handle h, int64_t n) { return gpimhip_dist_setup(h, n, 1, 0); }
 
 int gpimhip_dist_panel_factor(gpimhip_handle h, double* Aloc, int64_t ldloc, int32_t loc_blk0, int32_t glob_blk0,
                               double* logdet_out, int32_t* info) {
     FP64_ONLY(h);
-    if (!h || !Aloc || !info || loc_blk0 < 0 || glob_blk0 < 0 || !h->np) return GPIMHIP_E_BADARG;
+    if (!h || !Aloc || !info || loc_blk0 < 0 || glob_blk0 < 0 || !h->np || !h->dplan.nb) return GPIMHIP_E_BADARG;
     HIP_TRY(hipSetDevice(h->device));
     const int nb = (int)(h->np / NB);
-    if (glob_blk0 >= nb || ldloc < (int64_t)(loc_blk0 + std::min(OUTER_W, nb - glob_blk0)) * NB) return GPIMHIP_E_BADARG;
+    if (glob_blk0 >= nb || glob_blk0 % OUTER_W || ldloc < (int64_t)(loc_blk0 + std::min(OUTER_W, nb - glob_blk0)) * NB)
+        return GPIMHIP_E_BADARG;
     h->nbatch = 1;
-    GP_TRY(plan_ensure(h, nb));
     // the panel's columns live at local block offset loc_blk0: shift the base so that GLOBAL column indices
-    // address them (the panel steps only touch columns of this panel)
+    // address them (the chain only touches columns of this panel)
     double* As = Aloc - (int64_t)(glob_blk0 - loc_blk0) * NB;
     const int p1 = std::min(glob_blk0 + OUTER_W, nb);
-    GP_TRY(panel_steps(h, As, ldloc, info, glob_blk0, p1));
+    GP_TRY(launch_panel_chain(h, As, ldloc, glob_blk0, p1, nb, h->dplan.d_tiles, h->dplan.colfill.data() + glob_blk0, info));
     if (logdet_out)
         HIP_TRY(hipMemcpyAsync(logdet_out, h->logdet_part + glob_blk0, (size_t)(p1 - glob_blk0) * sizeof(double),
                                hipMemcpyDeviceToDevice, h->stream));
     return GPIMHIP_OK;
 }
 
-int gpimhip_dist_trailing_update(gpimhip_handle h, const double* panel, int64_t ldp, int32_t panel_glob_blk0,
-                                 double* Aloc, int64_t ldloc, int32_t loc_blk0, int32_t glob_blk0) {
+int gpimhip_dist_panel_pack(gpimhip_handle h, const double* Aloc, int64_t ldloc, int32_t loc_blk0, int32_t glob_blk0,
+                            double* buf, int64_t ldbuf) {
     FP64_ONLY(h);
-    if (!h || !panel || !Aloc || !h->np || panel_glob_blk0 < 0 || glob_blk0 <= panel_glob_blk0) return GPIMHIP_E_BADARG;
+    if (!h || !Aloc || !buf || !h->np || !h->dplan.nb || glob_blk0 < 0 || loc_blk0 < 0 || ldbuf < OUTER_W * NB)
+        return GPIMHIP_E_BADARG;
     HIP_TRY(hipSetDevice(h->device));
     const int nb = (int)(h->np / NB);
-    if (glob_blk0 >= nb) return GPIMHIP_E_BADARG;
+    if (glob_blk0 >= nb || glob_blk0 % OUTER_W) return GPIMHIP_E_BADARG;
+    const int nblk = std::min(OUTER_W, nb - glob_blk0);
+    return launch_dist_pack(h, Aloc + (int64_t)loc_blk0 * NB, ldloc, (int64_t)glob_blk0 * NB, h->np, nblk * NB,
+                            h->dinv + (int64_t)glob_blk0 * NB * NB, nblk, buf, ldbuf);
+}
+
+int gpimhip_dist_update(gpimhip_handle h, const double* buf, int64_t ldbuf, int32_t panel_glob_blk0, double* Aloc,
+                        int64_t ldloc, int32_t panel_first, int32_t panel_last) {
+    FP64_ONLY(h);
+    if (!h || !buf || !Aloc || !h->np || !h->dplan.nb || panel_glob_blk0 < 0 || panel_glob_blk0 % OUTER_W)
+        return GPIMHIP_E_BADARG;
+    HIP_TRY(hipSetDevice(h->device));
+    const DistPlan& D = h->dplan;
+    const int nb = D.nb, npanel = (int)D.upd_panel.size();
+    if (panel_glob_blk0 >= nb || panel_first <= panel_glob_blk0 / OUTER_W) return GPIMHIP_E_BADARG;
     h->nbatch = 1;
-    const int ncol = std::min(OUTER_W, nb - glob_blk0), kblk = std::min(OUTER_W, nb - panel_glob_blk0);
-    gpimhip_ctx::DistList* dl = nullptr;
-    for (auto& d : h->dist_lists)
-        if (d.gblk0 == glob_blk0 && d.ncol == ncol) dl = &d;
-    if (!dl) {
-        std::vector<TileDesc> tl;
-        for (int i = glob_blk0; i < nb; ++i)
-            for (int j = glob_blk0; j < std::min(glob_blk0 + ncol, i + 1); ++j) tl.push_back({i, j, 0, 0});
-        gpimhip_ctx::DistList d{glob_blk0, ncol, nullptr, (int64_t)tl.size()};
-        GP_TRY(dev_alloc(h, &d.tiles, d.n));
-        HIP_TRY(hipMemcpyAsync(d.tiles, tl.data(), tl.size() * sizeof(TileDesc), hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(hipStreamSynchronize(h->stream));
-        h->dist_lists.push_back(d);
-        dl = &h->dist_lists.back();
+    panel_last = std::min<int32_t>(panel_last, npanel);
+    int64_t off = -1, cnt = 0;
+    for (int c = panel_first; c < panel_last; ++c) {
+        if (!D.upd_panel[c].n) continue;
+        if (off < 0) off = D.upd_panel[c].off;
+        cnt += D.upd_panel[c].n;                     // owned panels are stored back to back, ascending
     }
-    // operands: the broadcast panel holds columns [panel_glob_blk0, +kblk) of L for ALL rows; shifted bases
-    // again let the tile engine use global block indices
-    const double* Ps = panel - (int64_t)panel_glob_blk0 * NB;
-    double* Cs = Aloc - (int64_t)(glob_blk0 - loc_blk0) * NB;
-    GemmArgs g = gemm_args(Ps, ldp, Ps, ldp, Cs, ldloc, -1.0, 1.0, dl->tiles, (int)dl->n, h->np);
+    if (cnt == 0) return GPIMHIP_OK;
+    // operands: the broadcast buffer holds columns [panel_glob_blk0, +kblk) of L for all rows; the shifted base lets
+    // the tile engine use global block indices for them
+    const int kblk = std::min(OUTER_W, nb - panel_glob_blk0);
+    const double* Ps = buf - (int64_t)panel_glob_blk0 * NB;
+    GemmArgs g = gemm_args(Ps, ldbuf, Ps, ldbuf, Aloc, ldloc, -1.0, 1.0, D.d_tiles + off, (int)cnt, h->np);
     g.kfix0 = panel_glob_blk0;
     g.kfix1 = panel_glob_blk0 + kblk;
+    g.cmap = 1;
     return launch_gemm(h, false, false, EPI_STORE, g);
+}
+
+static int dist_rect_ensure(gpimhip_ctx* h, int cols) {
+    DistPlan& D = h->dplan;
+    if (D.rect_cols == cols && D.d_rect) return GPIMHIP_OK;
+    if (D.d_rect) { (void)hipFree(D.d_rect); D.d_rect = nullptr; }
+    std::vector<TileDesc> tl;
+    tl.reserve((size_t)D.nb * cols);
+    for (int r = 0; r < D.nb; ++r)
+        for (int c = 0; c < cols; ++c) tl.push_back({r, c, 0, 1});
+    D.n_rect = (int64_t)tl.size();
+    GP_TRY(upload_tiles(h, tl, &D.d_rect));
+    D.rect_cols = cols;
+    return GPIMHIP_OK;
+}
+
+// One panel step of the forward substitution  W = L^-1 B  for this rank's right-hand sides B (np x mpad, row-major,
+// destroyed), against the broadcast buffer of panel p (gpimhip_dist_panel_pack):
+//   for b = 0..3:  W_b = Dinv_b B[4p+b]   ->  Wt rows [128 b, +128)
+//                  B[4p+b+1 .. 4p+3] -= L[., 4p+b] W_b                       (rows inside the panel)
+//   B[4p+4 ..] -= L[., panel p] Wt                                           (k-depth 512)
+//   q[j] += sum over the panel's rows of W[r][j]^2
+int gpimhip_dist_solve_update(gpimhip_handle h, const double* buf, int64_t ldbuf, int32_t panel_glob_blk0, double* Bm,
+                              int64_t ldb, int64_t mpad, double* Wt, int64_t ldw, double* q) {
+    FP64_ONLY(h);
+    if (!h || !buf || !Bm || !Wt || !h->np || !h->dplan.nb || panel_glob_blk0 < 0 || panel_glob_blk0 % OUTER_W ||
+        mpad < NB || mpad % NB || ldb < mpad || ldw < mpad)
+        return GPIMHIP_E_BADARG;
+    HIP_TRY(hipSetDevice(h->device));
+    const DistPlan& D = h->dplan;
+    const int nb = D.nb, g0 = panel_glob_blk0;
+    if (g0 >= nb) return GPIMHIP_E_BADARG;
+    h->nbatch = 1;
+    const int cols = (int)(mpad / NB), nblk = std::min(OUTER_W, nb - g0);
+    GP_TRY(dist_rect_ensure(h, cols));
+    const double* dinv = buf + h->np * ldbuf;               // 128 x (128 nblk): the panel's diagonal-block inverses
+    const double* Ps = buf - (int64_t)g0 * NB;              // global k-block index -> buffer column
+    for (int b = 0; b < nblk; ++b) {
+        // W_b = Dinv_b * B[g0 + b]   (NN: A = Dinv_b k-contiguous, B = right-hand sides m-contiguous)
+        GemmArgs g = gemm_args(dinv + (int64_t)b * NB, ldbuf, Bm + (int64_t)(g0 + b) * NB * ldb, ldb,
+                               Wt + (int64_t)b * NB * ldw, ldw, 1.0, 0.0, D.d_rect, cols, h->np);
+        g.kfix0 = 0; g.kfix1 = 1;
+        GP_TRY(launch_gemm(h, false, true, EPI_STORE, g));
+        const int rows_in = nblk - 1 - b;
+        if (rows_in > 0) {
+            // B[g0+b+1 .. g0+nblk-1] -= L[., g0+b] * W_b
+            GemmArgs u = gemm_args(Ps, ldbuf, Wt + (int64_t)b * NB * ldw, ldw, Bm, ldb, -1.0, 1.0, D.d_rect,
+                                   rows_in * cols, h->np);
+            u.a_roff = g0 + b + 1; u.a_coff = g0 + b; u.c_roff = g0 + b + 1;
+            u.kfix0 = 0; u.kfix1 = 1;
+            GP_TRY(launch_gemm(h, false, true, EPI_STORE, u));
+        }
+    }
+    const int rows_below = nb - g0 - nblk;
+    if (rows_below > 0) {
+        GemmArgs u = gemm_args(Ps, ldbuf, Wt, ldw, Bm, ldb, -1.0, 1.0, D.d_rect, rows_below * cols, h->np);
+        u.a_roff = g0 + nblk; u.a_coff = g0; u.c_roff = g0 + nblk;
+        u.kfix0 = 0; u.kfix1 = nblk;
+        u.chunk = deal_chunk(u.ntiles);
+        GP_TRY(launch_gemm(h, false, true, EPI_STORE, u));
+    }
+    if (q) GP_TRY(launch_colsumsq_acc(h, Wt, ldw, nblk * NB, mpad, q));
+    return GPIMHIP_OK;
 }
 
 int gpimhip_thin_batch(gpimhip_handle h, const double* vals, const int64_t* flat_idx, int32_t n, int32_t d,

@@ -284,3 +284,35 @@ int launch_potrf_steps(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_
     }
     return GPIMHIP_OK;
 }
+
+// The chain of one outer panel [p0, p1) whose columns have already received every update from the panels left of
+// it (distributed factorisation: right-looking across panels, gpimhip_dist_panel_factor).  Same launches as above
+// with the left-looking window restricted to the panel: colfill[j - p0] = tiles (i, j), i > j, k-blocks [p0, j).
+// A is addressed with GLOBAL block indices (the caller shifts the base of a local column panel accordingly).
+int launch_panel_chain(gpimhip_ctx* h, double* A, int64_t ld, int p0, int p1, int nb, const TileDesc* tiles,
+                       const PlanRange* colfill, int32_t* info) {
+    const int B = h->nbatch;
+    for (int j = p0; j < p1; ++j) {
+        StepArgs a;
+        a.A = A; a.ld = ld; a.kblk = j; a.nb = nb;
+        a.dinv_all = h->dinv; a.dinvB_all = h->dinvB; a.logdet = h->logdet_part; a.info = info;
+        const PlanRange f = colfill[j - p0];
+        a.g = nt_update(A, ld, tiles + f.off, f.n, h->np);
+        a.g.chunk = 1;
+        if (f.n <= 128)
+            hipLaunchKernelGGL((chol_step_kernel<64, 64>), dim3(f.n ? 8 + 4 * f.n : 1, B), dim3(NTH), 0, h->stream, a);
+        else
+            hipLaunchKernelGGL((chol_step_kernel<128, 64>), dim3(8 + 2 * f.n, B), dim3(NTH), 0, h->stream, a);
+        HIP_TRY(hipGetLastError());
+        if (j + 1 < nb) {
+            hipLaunchKernelGGL(panel_solve_kernel, dim3(4 * (nb - j - 1), B), dim3(256), 0, h->stream, A, ld, j, nb,
+                               (const double*)h->dinvB);
+            HIP_TRY(hipGetLastError());
+        }
+        if (j + 1 < p1) {
+            hipLaunchKernelGGL(diag_update_kernel, dim3(10 * (p1 - j - 1), B), dim3(256), 0, h->stream, A, ld, j, nb);
+            HIP_TRY(hipGetLastError());
+        }
+    }
+    return GPIMHIP_OK;
+}

@@ -83,6 +83,18 @@ struct StepPlan {
     std::vector<PlanRange> fill, diag, bulk_rest;
 };
 
+// Launch plans of the distributed (block-column-cyclic, 1 x P) factorisation for one rank (api.hip: gpimhip_dist_*)
+struct DistPlan {
+    int nb = 0, world = 0, rank = 0;
+    TileDesc* d_tiles = nullptr;
+    int64_t n_tiles = 0;
+    std::vector<PlanRange> colfill;     // per global block column j: the in-panel left-looking column update
+    std::vector<PlanRange> upd_panel;   // per global panel c: the tiles of its trailing update (empty when not owned)
+    int rect_cols = 0;                  // column-tile count the rectangle list below was built for
+    TileDesc* d_rect = nullptr;         // tiles (r, c), r = 0 .. nb-1, c = 0 .. rect_cols-1, row-major
+    int64_t n_rect = 0;
+};
+
 struct gpimhip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -124,6 +136,7 @@ struct gpimhip_ctx {
     int64_t bytes = 0;
     LinalgPlan plan;
     StepPlan splan;
+    DistPlan dplan;
     // optional stage timing (bench.py): HIP event pairs on the handle's stream
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[4];
@@ -141,9 +154,6 @@ struct gpimhip_ctx {
     int fit_completed = 0;
     int32_t* pinned_info = nullptr;
     hipEvent_t ra_ev[2] = {nullptr, nullptr};
-    // distributed factorisation: per global column panel the tile list of its trailing update
-    struct DistList { int gblk0; int ncol; TileDesc* tiles; int64_t n; };
-    std::vector<DistList> dist_lists;
     // sparse (VFE) workspace, owned by vfe.hip (VfeWs*); released by vfe_release()
     void* vfe = nullptr;
     // structured (Kronecker) workspace, owned by kron.hip (KronWs*); released by kron_release()
@@ -171,6 +181,12 @@ int plan_ensure(gpimhip_ctx* h, int nb);
 int launch_potrf_steps(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_t* info);
 void step_plan_release(gpimhip_ctx* h);
 int step_plan_ensure(gpimhip_ctx* h, int nb);
+int launch_panel_chain(gpimhip_ctx* h, double* A, int64_t ld, int p0, int p1, int nb, const TileDesc* tiles,
+                       const PlanRange* colfill, int32_t* info);
+// distops.hip
+int launch_dist_pack(gpimhip_ctx* h, const double* P, int64_t ldp, int64_t r0, int64_t np, int w, const double* dinv,
+                     int nblk, double* buf, int64_t ldb);
+int launch_colsumsq_acc(gpimhip_ctx* h, const double* W, int64_t ldw, int rows, int64_t m, double* q);
 int launch_theta(gpimhip_ctx* h, const gpimhip_model_t* m, const double* u);
 // predict.hip
 bool fused_predict_fits(int64_t np);
@@ -189,6 +205,8 @@ struct GemmArgs {
     double* C; int64_t ldc; int c_roff, c_coff;
     double alpha, beta;
     const TileDesc* tiles; int ntiles;
+    int cmap;                              // C's block column is the tile's kb0 field (operand columns stay cj): output
+                                           // stored at local columns (distributed layouts); needs kfix0 / kfix1
     int chunk;                             // XCD dealing: 0 = contiguous slices, >0 = round-robin chunks
     int inplace;                           // C aliases an operand tile (panel solve): one workgroup must own the whole tile
     int krev;                              // walk each tile's k-range from its end (ranges sharing their upper end)

@@ -161,6 +161,7 @@ __device__ __forceinline__ void gemm_tile_body(GemmArgs g, const int bx, const i
         }
     }
     TileDesc t = g.tiles[p];
+    const int ccb = g.cmap ? t.kb0 : t.cj;          // block column of the output (see GemmArgs::cmap)
     if (g.kfix1 > g.kfix0) { t.kb0 = g.kfix0; t.kb1 = g.kfix1; }
     const int nsteps = (t.kb1 - t.kb0) * (NB / GEMM_BK);
     const int qi = (quad / QN) * TSM, qj = (quad % QN) * TSN;
@@ -287,7 +288,7 @@ __device__ __forceinline__ void gemm_tile_body(GemmArgs g, const int bx, const i
 
     if (EPI == EPI_STORE) {
         const int64_t crow0 = (int64_t)(t.ci + g.c_roff) * NB + qi + wm * WROWS + (lane >> 4);
-        const int64_t ccol0 = (int64_t)(t.cj + g.c_coff) * NB + qj + wn * WCOLS + (lane & 15);
+        const int64_t ccol0 = (int64_t)(ccb + g.c_coff) * NB + qj + wn * WCOLS + (lane & 15);
         const double alpha = g.alpha, beta = g.beta;
         if (beta != 0.0) {
             // accumulate into C: fetch one 16-row band of the wave's sub-tile (NTL x 4 values per lane)

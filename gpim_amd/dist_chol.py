@@ -15,21 +15,26 @@ only data-path collective.  Round p:
     each     : trailing update of every owned panel right of p with the broadcast copy
                                                      (gpimhip_dist_trailing_update -- the fp64 MFMA tile engine)
 
-The owner of panel p+1 updates that panel FIRST, so its factorisation and broadcast can start while the
-other ranks are still updating (look-ahead by ordering; RCCL runs the broadcast on its own stream).
+Look-ahead: the owner of panel p+1 updates that panel FIRST, then factors it, packs it and starts its
+broadcast on a high-priority SIDE stream while the main stream goes on with the rest of round p's updates (all of a
+rank's panels in ONE launch of the tile engine); the broadcast is asynchronous (``async_op=True``) and the main
+stream only waits for it at the top of round p+1.  The broadcast buffer carries the panel's rows and, in 128 extra
+rows, the inverses of its diagonal blocks (the forward substitutions of the other ranks multiply by them).
 Per-rank memory: N^2 / P doubles + two panel buffers.  Communication per rank: N^2 / 2 doubles received in
 total, about the time of the 1/P share of the N^3 / 3 flop at N = 65536, P = 8.
 
 What the distributed model offers: the factor, log det K, the negative log marginal likelihood at given
 hyper-parameters and the posterior mean and standard deviation (two distributed triangular solves for
 alpha, O(N^2); K*^T alpha sharded over test points; for the variance the factor is streamed through every
-rank once more while each rank forward-substitutes its own test columns).  Training gradients (the
-distributed K^-1) are not built: hyper-parameters come from a single-GPU fit on a sub-sample.
+rank once more while each rank forward-substitutes its own test columns on the MFMA tile engine:
+gpimhip_dist_solve_update).  Training gradients (the distributed K^-1) are not built: hyper-parameters come
+from a single-GPU fit on a sub-sample.
 
 The tile arithmetic is behind a small engine interface so that the ownership / broadcast schedule can be
 tested on CPU ranks (gloo) with a stub (tests/test_dist_gloo.py); ``HipTileEngine`` is the product engine and
 needs the GPU -- there is no CPU fallback in the product path.
 """
+import contextlib
 import ctypes
 import math
 
@@ -75,8 +80,17 @@ class Layout:
         return max(1, len(self.owned)) * PW
 
 
+class _Ready:
+    """Stands in for the Work handle of an asynchronous broadcast when there is nothing to wait for."""
+
+    def wait(self):
+        return True
+
+
 class HipTileEngine:
-    """The product engine: hand-written HIP behind the C ABI (include/gpimhip.h, gpimhip_dist_*)."""
+    """The product engine: hand-written HIP behind the C ABI (include/gpimhip.h, gpimhip_dist_*).  Two library
+    handles: one on the caller's (main) stream for the updates and solves, one on a high-priority side stream
+    for the panel chain, so that factoring panel p+1 overlaps the rest of round p's updates."""
 
     def __init__(self, layout, handle=None):
         from . import _lib
@@ -84,24 +98,62 @@ class HipTileEngine:
         self.H = handle or _lib.Handle()
         self.layout = layout
         self.device = self.H.device
-        _lib.check(self.H.lib.gpimhip_dist_begin(self.H.h, layout.n))
+        self.main = torch.cuda.current_stream(self.device)
+        self.side = torch.cuda.Stream(device=self.device, priority=-1)
+        self.Hs = _lib.Handle(stream=self.side)
+        _lib.check(self.H.lib.gpimhip_dist_setup(self.H.h, layout.n, layout.world, layout.rank))
+        _lib.check(self.H.lib.gpimhip_dist_setup(self.Hs.h, layout.n, layout.world, layout.rank))
         self.info = torch.zeros((4,), dtype=torch.int32, device=self.device)
         self.logdet = torch.zeros((layout.npanel, PANEL), dtype=torch.float64, device=self.device)
+        self._ev = torch.cuda.Event()
 
     def empty(self, rows, cols):
         return torch.zeros((rows, cols), dtype=torch.float64, device=self.device)
 
+    # ---- the panel chain (side stream)
+    def side_stream(self):
+        """Context in which panel_factor / pack / the broadcast of the packed panel are issued: the side stream,
+        after everything the main stream has been given so far."""
+        self._ev.record(self.main)
+        self.side.wait_event(self._ev)
+        return torch.cuda.stream(self.side)
+
+    def side_done(self):
+        """Something with .wait(): makes the stream current at that time wait for the side stream (P = 1: no
+        broadcast whose Work handle would do that)."""
+        ev = torch.cuda.Event()
+        ev.record(self.side)
+
+        class _W:
+            def wait(_self):
+                torch.cuda.current_stream(self.device).wait_event(ev)
+                return True
+        return _W()
+
     def panel_factor(self, Aloc, p):
-        L, lib = self.layout, self.H.lib
+        L, lib = self.layout, self.Hs.lib
         self._lib.check(lib.gpimhip_dist_panel_factor(
-            self.H.h, self._lib.ptr(Aloc), Aloc.stride(0), L.local_col0(p) // NB, p * PANEL,
+            self.Hs.h, self._lib.ptr(Aloc), Aloc.stride(0), L.local_col0(p) // NB, p * PANEL,
             ctypes.c_void_p(self.logdet[p].data_ptr()), self._lib.ptr(self.info)))
 
-    def trailing_update(self, panel, p, Aloc, c):
-        L, lib = self.layout, self.H.lib
-        self._lib.check(lib.gpimhip_dist_trailing_update(
-            self.H.h, self._lib.ptr(panel), panel.stride(0), p * PANEL, self._lib.ptr(Aloc), Aloc.stride(0),
-            L.local_col0(c) // NB, c * PANEL))
+    def pack(self, Aloc, p, buf):
+        L, lib = self.layout, self.Hs.lib
+        self._lib.check(lib.gpimhip_dist_panel_pack(
+            self.Hs.h, self._lib.ptr(Aloc), Aloc.stride(0), L.local_col0(p) // NB, p * PANEL, self._lib.ptr(buf),
+            buf.stride(0)))
+
+    # ---- main stream
+    def update(self, buf, p, Aloc, first, last):
+        """Trailing update of the owned panels c, first <= c < last, with the packed panel p: one launch."""
+        lib = self.H.lib
+        self._lib.check(lib.gpimhip_dist_update(self.H.h, self._lib.ptr(buf), buf.stride(0), p * PANEL,
+                                                self._lib.ptr(Aloc), Aloc.stride(0), first, last))
+
+    def solve_update(self, buf, p, B, Wt, q):
+        lib = self.H.lib
+        self._lib.check(lib.gpimhip_dist_solve_update(self.H.h, self._lib.ptr(buf), buf.stride(0), p * PANEL,
+                                                      self._lib.ptr(B), B.stride(0), B.shape[1], self._lib.ptr(Wt),
+                                                      Wt.stride(0), self._lib.ptr(q)))
 
     def failed_column(self):
         return int(self.info[0].item())
@@ -117,7 +169,8 @@ class DistributedCholesky:
         self.engine = engine_factory(self.layout)
         self.group = group
         self.local = self.engine.empty(self.layout.np, self.layout.local_cols)
-        self._panel = [self.engine.empty(self.layout.np, PW) for _ in range(2)]
+        # broadcast buffers: the panel's rows + 128 rows of diagonal-block inverses
+        self._panel = [self.engine.empty(self.layout.np + NB, PW) for _ in range(2)]
 
     # ------------------------------------------------------------------ filling the local share
     def set_from_function(self, cols_fn):
@@ -133,22 +186,45 @@ class DistributedCholesky:
         return self
 
     # ------------------------------------------------------------------ factorisation
+    def _factor_and_send(self, p):
+        """Owner of panel p: factor, pack and start the broadcast -- on the engine's side stream.  Others: post the
+        receive.  Returns something with .wait() that orders the caller's stream behind the arrival of the panel."""
+        L, eng = self.layout, self.engine
+        buf = self._panel[p & 1]
+        if L.owner(p) == L.rank:
+            with self._side():
+                eng.panel_factor(self.local, p)
+                eng.pack(self.local, p, buf)
+                if L.world > 1:
+                    return dist.broadcast(buf, src=L.rank, group=self.group, async_op=True)
+            return self._side_done()
+        return dist.broadcast(buf, src=L.owner(p), group=self.group, async_op=True)
+
+    def _side(self):
+        eng = self.engine
+        return eng.side_stream() if hasattr(eng, "side_stream") else contextlib.nullcontext()
+
+    def _side_done(self):
+        eng = self.engine
+        return eng.side_done() if hasattr(eng, "side_done") else _Ready()
+
     def factor(self):
         L, eng = self.layout, self.engine
+        work = self._factor_and_send(0)
         for p in range(L.npanel):
             buf = self._panel[p & 1]
-            w = L.width(p)
-            if L.owner(p) == L.rank:
-                eng.panel_factor(self.local, p)
-                l0 = L.local_col0(p)
-                buf[p * PW:, :w] = self.local[p * PW:, l0:l0 + w]
-            if L.world > 1:
-                dist.broadcast(buf, src=L.owner(p), group=self.group)
-            # the next panel first: its owner can then factor and broadcast while the others still update
-            todo = [c for c in L.owned if c > p]
-            todo.sort(key=lambda c: (c != p + 1, c))
-            for c in todo:
-                eng.trailing_update(buf, p, self.local, c)
+            work.wait()                                  # the main stream waits for panel p
+            nxt = p + 1
+            rest = nxt
+            if nxt < L.npanel:
+                if L.owner(nxt) == L.rank:
+                    # look-ahead: bring panel p+1 up to date first; its chain and broadcast then run on the side
+                    # stream beside the remaining updates of this round
+                    eng.update(buf, p, self.local, nxt, nxt + 1)
+                    rest = nxt + 1
+                work = self._factor_and_send(nxt)
+            if rest < L.npanel:
+                eng.update(buf, p, self.local, rest, L.npanel)
         bad = torch.tensor([eng.failed_column()], dtype=torch.int64)
         if L.world > 1:
             bad = bad.to(self.local.device if self.local.is_cuda else "cpu")
@@ -219,27 +295,33 @@ class DistributedCholesky:
     def solve_colsumsq(self, B):
         """q_j = |L^-1 B[:, j]|^2 for this rank's own right-hand sides B (np x m, rows beyond n zero; destroyed):
         the quadratic form of the posterior variance.  L is distributed by columns, the right-hand sides by
-        rank, so the factor is streamed once more -- every owner re-broadcasts its panels in order -- and each
-        rank forward-substitutes its columns: a 512-row triangular solve and a plain (np - r) x 512 x m GEMM
-        per panel (rocBLAS through torch: ordinary library GEMMs, N^2 m flop per rank).  Collective: every
-        rank must call it the same number of times."""
-        L = self.layout
-        q = torch.zeros((B.shape[1],), dtype=torch.float64, device=B.device)
+        rank, so the factor is streamed once more -- every owner re-broadcasts its packed panels in order -- and
+        each rank forward-substitutes its columns panel by panel on the MFMA tile engine
+        (gpimhip_dist_solve_update: block solves with the diagonal-block inverses, a k-depth-512 update of the
+        rows below, column sums of squares; N^2 m flop per rank).  Collective: every rank must call it the same
+        number of times.  The engine works on column counts that are multiples of 128: B is padded if needed."""
+        L, eng = self.layout, self.engine
+        m = B.shape[1]
+        mpad = max(NB, (m + NB - 1) // NB * NB)
+        if B.shape[1] != mpad or not B.is_contiguous():
+            Bp = eng.empty(L.np, mpad)
+            Bp[:, :m] = B
+            B = Bp
+        Wt = eng.empty(PW, mpad)
+        q = torch.zeros((mpad,), dtype=torch.float64, device=B.device)
         for p in range(L.npanel):
             buf = self._panel[p & 1]
-            w, r0 = L.width(p), p * PW
             if L.owner(p) == L.rank:
-                l0 = L.local_col0(p)
-                buf[r0:, :w] = self.local[r0:, l0:l0 + w]
+                # pack() belongs to the engine's side handle: order it behind the main stream's earlier reads of
+                # `buf` and in front of the broadcast / the solve that follow on the main stream
+                with self._side():
+                    eng.pack(self.local, p, buf)
+                self._side_done().wait()
             if L.world > 1:
                 dist.broadcast(buf, src=L.owner(p), group=self.group)
-            if B.shape[1] == 0:
-                continue
-            Wp = torch.linalg.solve_triangular(torch.tril(buf[r0:r0 + w, :w]), B[r0:r0 + w], upper=False)
-            q += (Wp * Wp).sum(0)
-            if r0 + w < L.np:
-                B[r0 + w:].addmm_(buf[r0 + w:, :w], Wp, alpha=-1.0)
-        return q
+            if m:
+                eng.solve_update(buf, p, B, Wt, q)
+        return q[:m]
 
     def nll(self, y):
         """1/2 y^T K^-1 y + 1/2 log det K + N/2 log 2 pi (no prior constant)."""
@@ -310,12 +392,13 @@ def exact_gp_posterior(X, y, Xtest, kernel="Matern52", lengthscale=None, varianc
     part = torch.full((2, per), float("nan"), dtype=torch.float64, device=dev)
     for ci in range(nchunk):
         s0, s1 = min(hi, lo + ci * step), min(hi, lo + (ci + 1) * step)
-        Ks = torch.zeros((npd, s1 - s0), dtype=torch.float64, device=dev)
+        wpad = max(NB, (s1 - s0 + NB - 1) // NB * NB)      # the tile engine works on multiples of 128 columns
+        Ks = torch.zeros((npd, wpad), dtype=torch.float64, device=dev)
         if s1 > s0:
             kmat(Xt[s0:s1].to(dev).contiguous(), Ks)
-            part[0, s0 - lo:s1 - lo] = Ks[:N].T @ alpha
+            part[0, s0 - lo:s1 - lo] = (Ks[:N, :s1 - s0].T @ alpha)
         if with_sd:
-            q = chol.solve_colsumsq(Ks)
+            q = chol.solve_colsumsq(Ks)[:s1 - s0]
             part[1, s0 - lo:s1 - lo] = torch.sqrt(torch.clamp(variance - q, min=0.0) + noise)
     if world > 1:
         from .dist import all_gather

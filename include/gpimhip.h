@@ -250,24 +250,40 @@ int gpimhip_topk(gpimhip_handle h, const double* acq, int64_t M, int32_t k, int3
  * layout); each rank keeps its panels, all rows, side by side in ONE caller-owned row-major array
  *     Aloc : np x (512 * owned panels), leading dimension ldloc,   np = N padded to 128.
  * The host driver (gpim_amd/dist_chol.py, torch.distributed / RCCL) runs, for p = 0, 1, ...:
- *     owner(p):  gpimhip_dist_panel_factor   -> L(:, panel p) in place
- *     all     :  broadcast of the factored panel (np x 512 doubles, src = owner)
- *     each    :  gpimhip_dist_trailing_update for every owned panel right of p
- * With P = 1 the sequence of tile operations is the one gpimhip_potrf performs (same bits).
- *   gpimhip_dist_begin            per-handle set-up for order n (diagonal-block workspace and launch plans
- *                                 only -- none of the n x n buffers of the single-GPU path)
+ *     owner(p):  gpimhip_dist_panel_factor   -> L(:, panel p) in place   (on a side stream: look-ahead)
+ *                gpimhip_dist_panel_pack     -> broadcast buffer: rows of the panel + its diagonal-block inverses
+ *     all     :  broadcast of the buffer ((np + 128) x 512 doubles, src = owner)
+ *     each    :  gpimhip_dist_update for its owned panels right of p (panel p+1 first, the rest in one launch)
+ *   gpimhip_dist_setup            per-handle set-up for order n on rank `rank` of `world`: diagonal-block workspace
+ *                                 and the launch plans of this rank's share -- none of the n x n buffers of the
+ *                                 single-GPU path.  gpimhip_dist_begin(h, n) = gpimhip_dist_setup(h, n, 1, 0).
  *   gpimhip_dist_panel_factor     loc_blk0: block column (128-wide) where the panel starts inside Aloc;
- *                                 glob_blk0: its global block index; logdet_out: up to 4 doubles (device), the
- *                                 sums of log L_ii of the panel's 128-blocks, or NULL; info as gpimhip_potrf
- *   gpimhip_dist_trailing_update  panel: the broadcast copy (np rows x 512, leading dimension ldp) of the
- *                                 factored panel with global block index panel_glob_blk0; updates the owned
- *                                 panel (loc_blk0 / glob_blk0) in Aloc:  C -= P_rows P_cols^T on tiles i >= j */
+ *                                 glob_blk0: its global block index (a multiple of 4); logdet_out: up to 4 doubles
+ *                                 (device), the sums of log L_ii of the panel's 128-blocks, or NULL; info as
+ *                                 gpimhip_potrf.  The step kernels of the single-GPU factorisation (cholstep.hip)
+ *                                 with the left-looking window restricted to the panel.
+ *   gpimhip_dist_panel_pack       buf (ldbuf >= 512, np + 128 rows): rows [128 glob_blk0, np) <- the panel, rows
+ *                                 [np, np + 128) <- the inverses of its diagonal blocks side by side
+ *   gpimhip_dist_update           buf: a packed panel with global block index panel_glob_blk0; updates the OWNED
+ *                                 panels c with panel_first <= c < panel_last (global panel indices) in Aloc
+ *                                 (this rank's panels side by side):  C -= P_rows P_cols^T on tiles i >= j.
+ *                                 One launch whatever the number of panels.
+ *   gpimhip_dist_solve_update     one panel step of the forward substitution W = L^-1 B for this rank's own
+ *                                 right-hand sides B (np x mpad row-major, mpad a multiple of 128, destroyed):
+ *                                 W rows of the panel -> Wt (512 x mpad), B rows below -= L W, and
+ *                                 q[j] += sum_r W[r][j]^2 (q may be NULL).  Replaces the solve_triangular /
+ *                                 GEMM pair of `conditional` (gpim/gpreg/gpr.py:247-248) for a factor that is
+ *                                 streamed through the ranks panel by panel. */
+int gpimhip_dist_setup(gpimhip_handle h, int64_t n, int32_t world, int32_t rank);
 int gpimhip_dist_begin(gpimhip_handle h, int64_t n);
 int gpimhip_dist_panel_factor(gpimhip_handle h, double* Aloc, int64_t ldloc, int32_t loc_blk0,
                               int32_t glob_blk0, double* logdet_out, int32_t* info);
-int gpimhip_dist_trailing_update(gpimhip_handle h, const double* panel, int64_t ldp,
-                                 int32_t panel_glob_blk0, double* Aloc, int64_t ldloc,
-                                 int32_t loc_blk0, int32_t glob_blk0);
+int gpimhip_dist_panel_pack(gpimhip_handle h, const double* Aloc, int64_t ldloc, int32_t loc_blk0,
+                            int32_t glob_blk0, double* buf, int64_t ldbuf);
+int gpimhip_dist_update(gpimhip_handle h, const double* buf, int64_t ldbuf, int32_t panel_glob_blk0,
+                        double* Aloc, int64_t ldloc, int32_t panel_first, int32_t panel_last);
+int gpimhip_dist_solve_update(gpimhip_handle h, const double* buf, int64_t ldbuf, int32_t panel_glob_blk0,
+                              double* B, int64_t ldb, int64_t mpad, double* Wt, int64_t ldw, double* q);
 
 /* Batch thinning of boptimizer.update_points (gpim/gpbayes/boptim.py:326-376): among n <= 1024 ranked
  * candidates (vals, flat grid indices into a d-dimensional grid of the given shape) repeatedly keep the

@@ -99,8 +99,9 @@ def test_single_process_paths():
 # block-column-cyclic Cholesky: ownership / broadcast schedule with a stubbed tile engine
 # ------------------------------------------------------------------------------------------------
 class NumpyTileEngine:
-    """Test stub of gpim_amd.dist_chol.HipTileEngine (the product engine needs the GPU): the same two tile
-    operations in plain torch-CPU arithmetic, so that world-size-2 gloo ranks can run the real schedule."""
+    """Test stub of gpim_amd.dist_chol.HipTileEngine (the product engine needs the GPU): the same tile operations
+    in plain torch-CPU arithmetic, so that world-size-2 gloo ranks can run the real schedule (no side stream: the
+    driver falls back to in-order calls)."""
 
     def __init__(self, layout):
         self.layout = layout
@@ -122,11 +123,29 @@ class NumpyTileEngine:
         if r0 + w < L.np:
             Aloc[r0 + w:, l0:l0 + w] = torch.linalg.solve_triangular(Lpp, Aloc[r0 + w:, l0:l0 + w].T, upper=False).T
 
-    def trailing_update(self, panel, p, Aloc, c):
+    def pack(self, Aloc, p, buf):
         from gpim_amd.dist_chol import PW
         L = self.layout
-        wp, wc, c0, l0 = L.width(p), L.width(c), c * PW, L.local_col0(c)
-        Aloc[c0:, l0:l0 + wc] -= panel[c0:, :wp] @ panel[c0:c0 + wc, :wp].T
+        w, r0, l0 = L.width(p), p * PW, L.local_col0(p)
+        buf[r0:L.np, :w] = Aloc[r0:, l0:l0 + w]
+
+    def update(self, panel, p, Aloc, first, last):
+        from gpim_amd.dist_chol import PW
+        L = self.layout
+        wp = L.width(p)
+        for c in L.owned:
+            if first <= c < last:
+                wc, c0, l0 = L.width(c), c * PW, L.local_col0(c)
+                Aloc[c0:, l0:l0 + wc] -= panel[c0:L.np, :wp] @ panel[c0:c0 + wc, :wp].T
+
+    def solve_update(self, buf, p, B, Wt, q):
+        from gpim_amd.dist_chol import PW
+        L = self.layout
+        w, r0 = L.width(p), p * PW
+        Wp = torch.linalg.solve_triangular(torch.tril(buf[r0:r0 + w, :w]), B[r0:r0 + w], upper=False)
+        q += (Wp * Wp).sum(0)
+        if r0 + w < L.np:
+            B[r0 + w:].addmm_(buf[r0 + w:L.np, :w], Wp, alpha=-1.0)
 
     def failed_column(self):
         return self.bad
