@@ -1218,6 +1218,28 @@ int gpimhip_dist_setup(gpimhip_handle h, int64_t n, int32_t world, int32_t rank)
         D.upd_panel[c] = mark(s0);
         ++slot;
     }
+    // training: K^-1 = X^T X row panel by row panel (X = L^-1, broadcast panel c) against the owned columns, and the
+    // owned lower tiles of K^-1 for the gradient contraction.  Local block lb <-> global block gblk[lb].
+    std::vector<int> gblk;
+    for (int c = 0; c < npanel; ++c)
+        if (c % world == rank)
+            for (int j = c * OUTER_W; j < std::min(c * OUTER_W + OUTER_W, nb); ++j) gblk.push_back(j);
+    // (a rank's last owned panel may be the ragged one: its local blocks still sit at slot * 4 + offset)
+    auto local_of = [&](int lbidx) { return (gblk[lbidx] / OUTER_W / world) * OUTER_W + gblk[lbidx] % OUTER_W; };
+    D.kinv_panel.assign(npanel, {0, 0});
+    for (int c = 0; c < npanel; ++c) {
+        size_t s0 = tl.size();
+        for (int ci = c * OUTER_W; ci < std::min(c * OUTER_W + OUTER_W, nb); ++ci)
+            for (size_t q = 0; q < gblk.size(); ++q)
+                if (gblk[q] <= ci) tl.push_back({ci, local_of((int)q), ci, nb});
+        D.kinv_panel[c] = mark(s0);
+    }
+    {
+        size_t s0 = tl.size();
+        for (size_t q = 0; q < gblk.size(); ++q)
+            for (int ci = gblk[q]; ci < nb; ++ci) tl.push_back({ci, gblk[q], local_of((int)q), 0});
+        D.grad_tiles = mark(s0);
+    }
     D.n_tiles = (int64_t)tl.size();
     GP_TRY(upload_tiles(h, tl, &D.d_tiles));
     D.nb = nb; D.world = world; D.rank = rank;
@@ -1309,7 +1331,7 @@ static int dist_rect_ensure(gpimhip_ctx* h, int cols) {
 //   B[4p+4 ..] -= L[., panel p] Wt                                           (k-depth 512)
 //   q[j] += sum over the panel's rows of W[r][j]^2
 int gpimhip_dist_solve_update(gpimhip_handle h, const double* buf, int64_t ldbuf, int32_t panel_glob_blk0, double* Bm,
-                              int64_t ldb, int64_t mpad, double* Wt, int64_t ldw, double* q) {
+                              int64_t ldb, int64_t mpad, double* Wt, int64_t ldw, double* q, int32_t col_tiles) {
     FP64_ONLY(h);
     if (!h || !buf || !Bm || !Wt || !h->np || !h->dplan.nb || panel_glob_blk0 < 0 || panel_glob_blk0 % OUTER_W ||
         mpad < NB || mpad % NB || ldb < mpad || ldw < mpad)
@@ -1328,6 +1350,7 @@ int gpimhip_dist_solve_update(gpimhip_handle h, const double* buf, int64_t ldbuf
         GemmArgs g = gemm_args(dinv + (int64_t)b * NB, ldbuf, Bm + (int64_t)(g0 + b) * NB * ldb, ldb,
                                Wt + (int64_t)b * NB * ldw, ldw, 1.0, 0.0, D.d_rect, cols, h->np);
         g.kfix0 = 0; g.kfix1 = 1;
+        g.cj_max = col_tiles;
         GP_TRY(launch_gemm(h, false, true, EPI_STORE, g));
         const int rows_in = nblk - 1 - b;
         if (rows_in > 0) {
@@ -1336,6 +1359,7 @@ int gpimhip_dist_solve_update(gpimhip_handle h, const double* buf, int64_t ldbuf
                                    rows_in * cols, h->np);
             u.a_roff = g0 + b + 1; u.a_coff = g0 + b; u.c_roff = g0 + b + 1;
             u.kfix0 = 0; u.kfix1 = 1;
+            u.cj_max = col_tiles;
             GP_TRY(launch_gemm(h, false, true, EPI_STORE, u));
         }
     }
@@ -1345,10 +1369,81 @@ int gpimhip_dist_solve_update(gpimhip_handle h, const double* buf, int64_t ldbuf
         u.a_roff = g0 + nblk; u.a_coff = g0; u.c_roff = g0 + nblk;
         u.kfix0 = 0; u.kfix1 = nblk;
         u.chunk = deal_chunk(u.ntiles);
+        u.cj_max = col_tiles;
         GP_TRY(launch_gemm(h, false, true, EPI_STORE, u));
     }
     if (q) GP_TRY(launch_colsumsq_acc(h, Wt, ldw, nblk * NB, mpad, q));
     return GPIMHIP_OK;
+}
+
+// ---- distributed training: covariance columns at u, K^-1 rows, gradient sums, finalize ----
+int gpimhip_dist_kmat_cols(gpimhip_handle h, const gpimhip_model_t* m, const double* X, int64_t N, const double* u,
+                           int64_t col0, int64_t ncols_pad, double* out, int64_t ld) {
+    FP64_ONLY(h);
+    if (!h || !X || !u || !out || N < 1 || col0 < 0 || ncols_pad < NB || ncols_pad % NB || ld < ncols_pad || !h->np)
+        return GPIMHIP_E_BADARG;
+    GP_TRY(check_model(m));
+    HIP_TRY(hipSetDevice(h->device));
+    h->nbatch = 1;
+    GP_TRY(launch_theta(h, m, u));
+    const int64_t M = std::max<int64_t>(0, std::min(ncols_pad, N - col0));
+    GP_TRY(launch_kmat(h, m, X, N, X + std::min(col0, N - 1) * m->dim, M, h->theta, 0.0, 0, out, ld, h->np, ncols_pad, 0, 0, 0,
+                       0, 0));
+    return launch_add_diag_theta(h, out, ld, col0, M, std::min(ncols_pad, h->np - col0));
+}
+
+int gpimhip_dist_kinv_update(gpimhip_handle h, const double* xbuf, int64_t ldx, int32_t panel_glob_blk0,
+                             const double* Xloc, int64_t ldloc, double* Kinv, int64_t ldk) {
+    FP64_ONLY(h);
+    if (!h || !xbuf || !Xloc || !Kinv || !h->np || !h->dplan.nb || panel_glob_blk0 < 0 || panel_glob_blk0 % OUTER_W ||
+        panel_glob_blk0 >= h->dplan.nb)
+        return GPIMHIP_E_BADARG;
+    HIP_TRY(hipSetDevice(h->device));
+    h->nbatch = 1;
+    const DistPlan& D = h->dplan;
+    const PlanRange r = D.kinv_panel[panel_glob_blk0 / OUTER_W];
+    if (!r.n) return GPIMHIP_OK;
+    // K^-1[ci, cj] = sum_{kb >= ci} X[kb, ci]^T X[kb, cj]: A = the broadcast column panel of X (block column
+    // ci - panel_glob_blk0 of xbuf), B = the owned columns
+    GemmArgs g = gemm_args(xbuf, ldx, Xloc, ldloc, Kinv, ldk, 1.0, 0.0, D.d_tiles + r.off, r.n, h->np);
+    g.a_coff = -panel_glob_blk0;
+    g.krev = 1;
+    g.chunk = deal_chunk(g.ntiles);
+    return launch_gemm(h, true, true, EPI_STORE, g);
+}
+
+int gpimhip_dist_grad_sums(gpimhip_handle h, const gpimhip_model_t* m, const double* X, int64_t N, const double* u,
+                           const double* Kinv, int64_t ldk, const double* alpha, double* S_out) {
+    FP64_ONLY(h);
+    if (!h || !X || !u || !Kinv || !alpha || !S_out || !h->np || !h->dplan.nb) return GPIMHIP_E_BADARG;
+    GP_TRY(check_model(m));
+    HIP_TRY(hipSetDevice(h->device));
+    h->nbatch = 1;
+    const DistPlan& D = h->dplan;
+    GP_TRY(launch_theta(h, m, u));
+    if (D.grad_tiles.n)
+        GP_TRY(launch_grad_reduce_tiles(h, m, Kinv, ldk, X, N, h->np, alpha, D.d_tiles + D.grad_tiles.off, D.grad_tiles.n,
+                                        h->grad_part));
+    return launch_sum7(h, h->grad_part, D.grad_tiles.n, S_out);
+}
+
+int gpimhip_dist_finalize(gpimhip_handle h, const gpimhip_model_t* m, int64_t N, double* u, const double* S, double quad,
+                          double half_logdet, double lr, int32_t t, double* loss_out, double* grad_out, double* hist_row) {
+    FP64_ONLY(h);
+    if (!h || !u || !S || N < 1 || t < 0 || !h->np) return GPIMHIP_E_BADARG;
+    GP_TRY(check_model(m));
+    HIP_TRY(hipSetDevice(h->device));
+    h->nbatch = 1;
+    GP_TRY(launch_theta(h, m, u));
+    AdamStep st;
+    st.beta1 = 0.9; st.beta2 = 0.999; st.eps = 1e-8;
+    st.lr_over_bc1 = t > 0 ? lr / (1.0 - pow(0.9, (double)t)) : 0.0;
+    st.bc2_sqrt = t > 0 ? sqrt(1.0 - pow(0.999, (double)t)) : 1.0;
+    if (t == 1) {
+        HIP_TRY(hipMemsetAsync(h->adam_m, 0, MAXP * sizeof(double), h->stream));
+        HIP_TRY(hipMemsetAsync(h->adam_v, 0, MAXP * sizeof(double), h->stream));
+    }
+    return launch_dist_finalize(h, m, N, S, quad, half_logdet, u, t > 0 ? 1 : 0, st, loss_out, grad_out, hist_row);
 }
 
 int gpimhip_thin_batch(gpimhip_handle h, const double* vals, const int64_t* flat_idx, int32_t n, int32_t d,

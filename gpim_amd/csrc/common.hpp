@@ -90,6 +90,8 @@ struct DistPlan {
     int64_t n_tiles = 0;
     std::vector<PlanRange> colfill;     // per global block column j: the in-panel left-looking column update
     std::vector<PlanRange> upd_panel;   // per global panel c: the tiles of its trailing update (empty when not owned)
+    std::vector<PlanRange> kinv_panel;  // per global panel c: tiles of K^-1 rows of panel c x owned columns (training)
+    PlanRange grad_tiles{0, 0};         // the owned lower tiles of K^-1 for the gradient contraction
     int rect_cols = 0;                  // column-tile count the rectangle list below was built for
     TileDesc* d_rect = nullptr;         // tiles (r, c), r = 0 .. nb-1, c = 0 .. rect_cols-1, row-major
     int64_t n_rect = 0;
@@ -187,6 +189,13 @@ int launch_panel_chain(gpimhip_ctx* h, double* A, int64_t ld, int p0, int p1, in
 int launch_dist_pack(gpimhip_ctx* h, const double* P, int64_t ldp, int64_t r0, int64_t np, int w, const double* dinv,
                      int nblk, double* buf, int64_t ldb);
 int launch_colsumsq_acc(gpimhip_ctx* h, const double* W, int64_t ldw, int rows, int64_t m, double* q);
+// engine.hip (distributed training)
+int launch_grad_reduce_tiles(gpimhip_ctx* h, const gpimhip_model_t* m, const double* Kinv, int64_t ld, const double* X,
+                             int64_t N, int64_t np, const double* alpha, const TileDesc* tiles, int ntile, double* part);
+int launch_sum7(gpimhip_ctx* h, const double* part, int ntile, double* S);
+int launch_dist_finalize(gpimhip_ctx* h, const gpimhip_model_t* m, int64_t N, const double* S, double q2, double lg,
+                         double* u, int do_adam, AdamStep st, double* loss_out, double* grad_out, double* hist_row);
+int launch_add_diag_theta(gpimhip_ctx* h, double* out, int64_t ld, int64_t row0, int64_t n, int64_t npad);
 int launch_theta(gpimhip_ctx* h, const gpimhip_model_t* m, const double* u);
 // predict.hip
 bool fused_predict_fits(int64_t np);
@@ -205,6 +214,7 @@ struct GemmArgs {
     double* C; int64_t ldc; int c_roff, c_coff;
     double alpha, beta;
     const TileDesc* tiles; int ntiles;
+    int cj_max;                            // > 0: tiles with cj >= cj_max are skipped (structurally zero columns)
     int cmap;                              // C's block column is the tile's kb0 field (operand columns stay cj): output
                                            // stored at local columns (distributed layouts); needs kfix0 / kfix1
     int chunk;                             // XCD dealing: 0 = contiguous slices, >0 = round-robin chunks

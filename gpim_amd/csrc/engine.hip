@@ -452,7 +452,8 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const R* __restrict__ 
                                                           const double* __restrict__ X, int64_t N, int d,
                                                           const double* __restrict__ alpha,
                                                           const ThetaDev* __restrict__ th,
-                                                          double* __restrict__ part, int64_t x_bs, int64_t np) {
+                                                          double* __restrict__ part, int64_t x_bs, int64_t np,
+                                                          const TileDesc* __restrict__ tiles) {
     __shared__ double xa[128][5];
     __shared__ double xz[128][5];
     __shared__ double al_r[128], al_c[128];
@@ -463,8 +464,17 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const R* __restrict__ 
     alpha += blockIdx.y * np;
     th += blockIdx.y;
     part += (int64_t)blockIdx.y * gridDim.x * 8;
+    // tiles == nullptr: workgroup q is lower tile q of a full np x np matrix.  Otherwise (distributed layouts:
+    // a rank holds some block columns side by side) tile (ci, cj) of the matrix lives at block column kb0 of Kinv.
     int ci, cj;
-    lower_tile_from_linear(blockIdx.x, ci, cj);
+    int64_t ccol;
+    if (tiles) {
+        const TileDesc td = tiles[blockIdx.x];
+        ci = td.ci; cj = td.cj; ccol = (int64_t)td.kb0 * 128;
+    } else {
+        lower_tile_from_linear(blockIdx.x, ci, cj);
+        ccol = (int64_t)cj * 128;
+    }
     const ThetaDev t = *th;
     {
         const bool isrow = tid < 128;
@@ -491,7 +501,7 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const R* __restrict__ 
         const double ali = al_r[r];
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc) {
-            const typename Vec2<R>::T kv = *reinterpret_cast<const typename Vec2<R>::T*>(Kinv + gi * ld + (int64_t)cj * 128 + tx * 2 + 32 * cc);
+            const typename Vec2<R>::T kv = *reinterpret_cast<const typename Vec2<R>::T*>(Kinv + gi * ld + ccol + tx * 2 + 32 * cc);
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const int c = tx * 2 + 32 * cc + e;
@@ -538,10 +548,10 @@ int launch_grad_reduce(gpimhip_ctx* h, const gpimhip_model_t* m, const double* K
     do {                                                                                                  \
         if (h->fp32)                                                                                      \
             hipLaunchKernelGGL((grad_reduce_kernel<KIND, float>), grid, block, 0, h->stream, reinterpret_cast<const float*>(Kinv), \
-                               ld, X, N, m->dim, alpha, h->theta, h->grad_part, x_bs, (int64_t)nb * NB);  \
+                               ld, X, N, m->dim, alpha, h->theta, h->grad_part, x_bs, (int64_t)nb * NB, (const TileDesc*)nullptr);  \
         else                                                                                              \
             hipLaunchKernelGGL((grad_reduce_kernel<KIND, double>), grid, block, 0, h->stream, Kinv, ld, X, N, m->dim, alpha, \
-                               h->theta, h->grad_part, x_bs, (int64_t)nb * NB);                           \
+                               h->theta, h->grad_part, x_bs, (int64_t)nb * NB, (const TileDesc*)nullptr);  \
     } while (0)
     switch (m->kernel) {
         case GPIMHIP_KERNEL_RBF: GR_LAUNCH(GPIMHIP_KERNEL_RBF); break;
@@ -821,6 +831,82 @@ int launch_topk(gpimhip_ctx* h, const double* x, int64_t M, int k, int keep_nan,
     hipLaunchKernelGGL(topk_keys_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, h->stream, x, M, keep_nan,
                        h->keys);
     hipLaunchKernelGGL(topk_select_kernel, dim3(1), dim3(1024), 0, h->stream, x, h->keys, M, k, vals, idx, count);
+    HIP_TRY(hipGetLastError());
+    return GPIMHIP_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------
+// distributed training (api.hip: gpimhip_dist_grad_sums / gpimhip_dist_finalize): the gradient contraction over the
+// tiles of K^-1 a rank holds, reduced to the seven sums S[] in a fixed order; after the all-reduce of S across
+// the ranks the same finalize_step as the single-GPU path turns them into loss, gradient and Adam step.
+// ------------------------------------------------------------------------------------------
+int launch_grad_reduce_tiles(gpimhip_ctx* h, const gpimhip_model_t* m, const double* Kinv, int64_t ld, const double* X,
+                             int64_t N, int64_t np, const double* alpha, const TileDesc* tiles, int ntile, double* part) {
+    dim3 grid(ntile, 1), block(256);
+    switch (m->kernel) {
+        case GPIMHIP_KERNEL_RBF:
+            hipLaunchKernelGGL((grad_reduce_kernel<GPIMHIP_KERNEL_RBF, double>), grid, block, 0, h->stream, Kinv, ld, X, N, m->dim,
+                               alpha, h->theta, part, (int64_t)0, np, tiles);
+            break;
+        case GPIMHIP_KERNEL_MATERN52:
+            hipLaunchKernelGGL((grad_reduce_kernel<GPIMHIP_KERNEL_MATERN52, double>), grid, block, 0, h->stream, Kinv, ld, X, N,
+                               m->dim, alpha, h->theta, part, (int64_t)0, np, tiles);
+            break;
+        case GPIMHIP_KERNEL_RQ:
+            hipLaunchKernelGGL((grad_reduce_kernel<GPIMHIP_KERNEL_RQ, double>), grid, block, 0, h->stream, Kinv, ld, X, N, m->dim,
+                               alpha, h->theta, part, (int64_t)0, np, tiles);
+            break;
+        default: gpim_set_error("unknown kernel kind"); return GPIMHIP_E_BADARG;
+    }
+    HIP_TRY(hipGetLastError());
+    return GPIMHIP_OK;
+}
+
+__global__ __launch_bounds__(256) void sum7_kernel(const double* __restrict__ part, int ntile, double* __restrict__ S) {
+    __shared__ double red[256];
+    for (int k = 0; k < 7; ++k) {
+        double v = 0.0;
+        for (int q = threadIdx.x; q < ntile; q += 256) v += part[(int64_t)q * 8 + k];
+        v = block_sum_256(v, red);
+        if (threadIdx.x == 0) S[k] = v;
+    }
+    if (threadIdx.x == 0) S[7] = 0.0;
+}
+int launch_sum7(gpimhip_ctx* h, const double* part, int ntile, double* S) {
+    hipLaunchKernelGGL(sum7_kernel, dim3(1), dim3(256), 0, h->stream, part, ntile, S);
+    HIP_TRY(hipGetLastError());
+    return GPIMHIP_OK;
+}
+
+__global__ void dist_finalize_kernel(gpimhip_model_t m, int64_t N, const double* __restrict__ S, double q2, double lg,
+                                     const ThetaDev* __restrict__ th, double* __restrict__ u, double* __restrict__ adam_m,
+                                     double* __restrict__ adam_v, int do_adam, AdamStep st, double* __restrict__ loss_out,
+                                     double* __restrict__ grad_out, double* __restrict__ hist_row) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double Sl[8];
+    for (int k = 0; k < 8; ++k) Sl[k] = S[k];
+    finalize_step(m, N, Sl, q2, lg, *th, u, adam_m, adam_v, do_adam, st, loss_out, grad_out, hist_row, prior_constant(m));
+}
+int launch_dist_finalize(gpimhip_ctx* h, const gpimhip_model_t* m, int64_t N, const double* S, double q2, double lg,
+                         double* u, int do_adam, AdamStep st, double* loss_out, double* grad_out, double* hist_row) {
+    hipLaunchKernelGGL(dist_finalize_kernel, dim3(1), dim3(64), 0, h->stream, *m, N, S, q2, lg, h->theta, u, h->adam_m,
+                       h->adam_v, do_adam, st, loss_out, grad_out, hist_row);
+    HIP_TRY(hipGetLastError());
+    return GPIMHIP_OK;
+}
+
+// The diagonal of a column slab of the covariance (columns row0 .. row0 + npad - 1 of the padded matrix):
+// out[(row0 + j) * ld + j] += jitter + noise(theta) for the n valid columns, = 1 for the padding columns
+__global__ void add_diag_theta_kernel(double* __restrict__ out, int64_t ld, int64_t row0, int64_t n, int64_t npad,
+                                      const ThetaDev* __restrict__ th) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) out[(row0 + j) * ld + j] += th->diag_add;
+    else if (j < npad) out[(row0 + j) * ld + j] = 1.0;
+}
+int launch_add_diag_theta(gpimhip_ctx* h, double* out, int64_t ld, int64_t row0, int64_t n, int64_t npad) {
+    hipLaunchKernelGGL(add_diag_theta_kernel, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, h->stream, out, ld, row0, n,
+                       npad, h->theta);
     HIP_TRY(hipGetLastError());
     return GPIMHIP_OK;
 }

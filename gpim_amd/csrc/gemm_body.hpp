@@ -161,6 +161,7 @@ __device__ __forceinline__ void gemm_tile_body(GemmArgs g, const int bx, const i
         }
     }
     TileDesc t = g.tiles[p];
+    if (g.cj_max > 0 && t.cj >= g.cj_max) return;   // (the whole workgroup: t is uniform)
     const int ccb = g.cmap ? t.kb0 : t.cj;          // block column of the output (see GemmArgs::cmap)
     if (g.kfix1 > g.kfix0) { t.kb0 = g.kfix0; t.kb1 = g.kfix1; }
     const int nsteps = (t.kb1 - t.kb0) * (NB / GEMM_BK);

@@ -149,11 +149,17 @@ class HipTileEngine:
         self._lib.check(lib.gpimhip_dist_update(self.H.h, self._lib.ptr(buf), buf.stride(0), p * PANEL,
                                                 self._lib.ptr(Aloc), Aloc.stride(0), first, last))
 
-    def solve_update(self, buf, p, B, Wt, q):
+    def solve_update(self, buf, p, B, Wt, q, col_tiles=0):
         lib = self.H.lib
         self._lib.check(lib.gpimhip_dist_solve_update(self.H.h, self._lib.ptr(buf), buf.stride(0), p * PANEL,
                                                       self._lib.ptr(B), B.stride(0), B.shape[1], self._lib.ptr(Wt),
-                                                      Wt.stride(0), self._lib.ptr(q)))
+                                                      Wt.stride(0), self._lib.ptr(q), col_tiles))
+
+    def kinv_update(self, xbuf, c, Xloc, Kinv):
+        lib = self.H.lib
+        self._lib.check(lib.gpimhip_dist_kinv_update(self.H.h, self._lib.ptr(xbuf), xbuf.stride(0), c * PANEL,
+                                                     self._lib.ptr(Xloc), Xloc.stride(0), self._lib.ptr(Kinv),
+                                                     Kinv.stride(0)))
 
     def failed_column(self):
         return int(self.info[0].item())
@@ -323,6 +329,53 @@ class DistributedCholesky:
                 eng.solve_update(buf, p, B, Wt, q)
         return q[:m]
 
+    def _stream_panel(self, p):
+        """Pack (owner) and broadcast the factored panel p once more; returns the buffer."""
+        L, eng = self.layout, self.engine
+        buf = self._panel[p & 1]
+        if L.owner(p) == L.rank:
+            with self._side():
+                eng.pack(self.local, p, buf)
+            self._side_done().wait()
+        if L.world > 1:
+            dist.broadcast(buf, src=L.owner(p), group=self.group)
+        return buf
+
+    def inverse(self):
+        """X = L^-1, distributed like L: this rank's block columns (np x 512 * owned panels), lower triangular.
+        The factor is streamed through the ranks once more and every rank forward-substitutes the identity
+        columns it owns (gpimhip_dist_solve_update; block columns right of the current panel are still zero and
+        are skipped, so the work is that of a triangular inversion, N^3 / 3 flop over all ranks)."""
+        L, eng = self.layout, self.engine
+        Bw = eng.empty(L.np, L.local_cols)
+        for p in L.owned:
+            idx = torch.arange(L.width(p), device=Bw.device)
+            Bw[p * PW + idx, L.local_col0(p) + idx] = 1.0
+        Xl = eng.empty(L.np, L.local_cols)
+        for p in range(L.npanel):
+            buf = self._stream_panel(p)
+            nown = sum(1 for c in L.owned if c <= p)
+            if nown:
+                eng.solve_update(buf, p, Bw, Xl[p * PW:], None, nown * PANEL)
+        return Xl
+
+    def kinv(self, Xl):
+        """K^-1 = X^T X (lower tiles) for the owned block columns, np x 512 * owned panels: every owner broadcasts
+        its block columns of X in turn and each rank forms the rows of that panel against its own columns on the
+        MFMA tile engine (gpimhip_dist_kinv_update)."""
+        L, eng = self.layout, self.engine
+        Kl = eng.empty(L.np, L.local_cols)
+        for c in range(L.npanel):
+            buf = self._panel[c & 1]
+            w = L.width(c)
+            if L.owner(c) == L.rank:
+                l0 = L.local_col0(c)
+                buf[:L.np, :w] = Xl[:, l0:l0 + w]
+            if L.world > 1:
+                dist.broadcast(buf, src=L.owner(c), group=self.group)
+            eng.kinv_update(buf, c, Xl, Kl)
+        return Kl
+
     def nll(self, y):
         """1/2 y^T K^-1 y + 1/2 log det K + N/2 log 2 pi (no prior constant)."""
         alpha = self.solve(y)
@@ -415,3 +468,113 @@ def exact_gp_posterior_mean(X, y, Xtest, **kw):
     """(mean, nll) only -- see exact_gp_posterior."""
     mean, _, nll = exact_gp_posterior(X, y, Xtest, with_sd=False, **kw)
     return mean, nll
+
+
+def exact_gp_fit(X, y, kernel="RBF", lengthscale=None, learning_rate=5e-2, iterations=100, seed=0, jitter=1e-5,
+                 amplitude=None, group=None, verbose=0, u0=None):
+    """Trains ONE exact GP on all N points across the ranks of the process group: the training loop of
+    ``reconstructor.train`` (gpim/gpreg/gpr.py:170-217 -- MAP hyper-parameters under Uniform priors, Adam with the
+    reference's learning rate) for covariances too large for one device.  X (N, d), y (N,); ``lengthscale`` = the
+    prior bounds [[lo...], [hi...]] (or two scalars: isotropic) as in ``reconstructor``; every rank passes the same
+    arguments and ends with the same hyper-parameters (the initial draw comes from a private CPU generator seeded with
+    ``seed``; the gradient sums are all-reduced, everything after them is replicated arithmetic).
+
+    Per Adam iteration: every rank builds its own column panels of K(u) (gpimhip_dist_kmat_cols), the block-column-
+    cyclic factorisation (DistributedCholesky.factor), log det and alpha = K^-1 y (two distributed triangular
+    solves), X = L^-1 (``inverse``), K^-1 = X^T X for the owned columns (``kinv``), the rank's share of
+    sum_ij (K^-1 - alpha alpha^T)_ij dK_ij/dtheta (gpimhip_dist_grad_sums), ONE all-reduce of 8 doubles, and the
+    chain rule + Adam step of the single-GPU path (gpimhip_dist_finalize).
+
+    Returns (hyperparams, u): the dictionary ``reconstructor.hyperparams`` holds ("lengthscale", "variance", "noise"
+    histories as numpy arrays, plus "loss") and the final unconstrained parameter vector (device tensor) -- feed the last
+    history row to ``exact_gp_posterior``."""
+    from . import _lib
+    from .kernels import KernelSpec
+    rank, world = _world()
+    X = torch.as_tensor(X, dtype=torch.float64)
+    N, d = X.shape
+    if lengthscale is None:
+        lengthscale = [[0.0] * d, [float(X.max()) / 2] * d]
+    spec = KernelSpec(kernel, d, lengthscale, amplitude=amplitude, jitter=jitter)
+    m = spec.struct()
+    P = spec.n_params
+    chol = DistributedCholesky(N, group=group)
+    L, H = chol.layout, chol.engine.H
+    dev = H.device
+    lib = H.lib
+    Xd = X.to(dev).contiguous()
+    yd = torch.as_tensor(y, dtype=torch.float64).to(dev).contiguous()
+    u = (spec.draw_initial_u(torch.Generator().manual_seed(seed)) if u0 is None
+         else torch.as_tensor(u0, dtype=torch.float64).clone()).to(dev).contiguous()
+    T = int(iterations)
+    hist = torch.zeros((max(T, 1), P), dtype=torch.float64, device=dev)
+    loss = torch.zeros((max(T, 1),), dtype=torch.float64, device=dev)
+    S = torch.zeros((8,), dtype=torch.float64, device=dev)
+    alpha_pad = torch.zeros((L.np,), dtype=torch.float64, device=dev)
+    ld = chol.local.stride(0)
+    for t in range(1, T + 1):
+        for p in L.owned:
+            l0 = L.local_col0(p)
+            _lib.check(lib.gpimhip_dist_kmat_cols(H.h, ctypes.byref(m), _lib.ptr(Xd), N, _lib.ptr(u), p * PW, L.width(p),
+                                                  ctypes.c_void_p(chol.local.data_ptr() + 8 * l0), ld))
+        chol.factor()
+        half_logdet = 0.5 * chol.logdet()
+        alpha = chol.solve(yd)
+        quad = float((yd * alpha).sum().item())
+        alpha_pad[:N] = alpha
+        Xl = chol.inverse()
+        Kl = chol.kinv(Xl)
+        del Xl
+        _lib.check(lib.gpimhip_dist_grad_sums(H.h, ctypes.byref(m), _lib.ptr(Xd), N, _lib.ptr(u), _lib.ptr(Kl),
+                                              Kl.stride(0), _lib.ptr(alpha_pad), _lib.ptr(S)))
+        del Kl
+        if world > 1:
+            dist.all_reduce(S, group=group)
+        _lib.check(lib.gpimhip_dist_finalize(H.h, ctypes.byref(m), N, _lib.ptr(u), _lib.ptr(S), quad, half_logdet,
+                                             float(learning_rate), t, ctypes.c_void_p(loss[t - 1:].data_ptr()), None,
+                                             ctypes.c_void_p(hist[t - 1].data_ptr())))
+        if verbose and rank == 0 and (t == 1 or t % 10 == 0 or t == T):
+            print("iter: {} ... loss: {:.4f}".format(t - 1, float(loss[t - 1].item())))
+    hcpu = hist[:T].cpu().numpy()
+    hyper = {"variance": hcpu[:, 0], "lengthscale": hcpu[:, 1:1 + spec.n_ls], "noise": hcpu[:, 1 + spec.n_ls],
+             "loss": loss[:T].cpu().numpy()}
+    return hyper, u
+
+
+def exact_gp_nll_grad(X, y, u, kernel="RBF", lengthscale=None, jitter=1e-5, amplitude=None, group=None):
+    """Loss and d loss / du of the distributed model at the unconstrained parameters u (no Adam step): what
+    gpimhip_nll_grad returns on one GPU.  Returns (loss, grad) as a float and a numpy vector, the same on every rank."""
+    from . import _lib
+    from .kernels import KernelSpec
+    rank, world = _world()
+    X = torch.as_tensor(X, dtype=torch.float64)
+    N, d = X.shape
+    spec = KernelSpec(kernel, d, lengthscale, amplitude=amplitude, jitter=jitter)
+    m = spec.struct()
+    chol = DistributedCholesky(N, group=group)
+    L, H = chol.layout, chol.engine.H
+    dev, lib = H.device, H.lib
+    Xd = X.to(dev).contiguous()
+    yd = torch.as_tensor(y, dtype=torch.float64).to(dev).contiguous()
+    ud = torch.as_tensor(u, dtype=torch.float64).clone().to(dev).contiguous()
+    ld = chol.local.stride(0)
+    for p in L.owned:
+        _lib.check(lib.gpimhip_dist_kmat_cols(H.h, ctypes.byref(m), _lib.ptr(Xd), N, _lib.ptr(ud), p * PW, L.width(p),
+                                              ctypes.c_void_p(chol.local.data_ptr() + 8 * L.local_col0(p)), ld))
+    chol.factor()
+    half_logdet = 0.5 * chol.logdet()
+    alpha = chol.solve(yd)
+    quad = float((yd * alpha).sum().item())
+    alpha_pad = torch.zeros((L.np,), dtype=torch.float64, device=dev)
+    alpha_pad[:N] = alpha
+    Kl = chol.kinv(chol.inverse())
+    S = torch.zeros((8,), dtype=torch.float64, device=dev)
+    _lib.check(lib.gpimhip_dist_grad_sums(H.h, ctypes.byref(m), _lib.ptr(Xd), N, _lib.ptr(ud), _lib.ptr(Kl), Kl.stride(0),
+                                          _lib.ptr(alpha_pad), _lib.ptr(S)))
+    if world > 1:
+        dist.all_reduce(S, group=group)
+    out = torch.zeros((1 + spec.n_params,), dtype=torch.float64, device=dev)
+    _lib.check(lib.gpimhip_dist_finalize(H.h, ctypes.byref(m), N, _lib.ptr(ud), _lib.ptr(S), quad, half_logdet, 0.0, 0,
+                                         ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(out.data_ptr() + 8), None))
+    o = out.cpu().numpy()
+    return float(o[0]), o[1:]

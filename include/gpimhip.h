@@ -271,7 +271,9 @@ int gpimhip_topk(gpimhip_handle h, const double* acq, int64_t M, int32_t k, int3
  *   gpimhip_dist_solve_update     one panel step of the forward substitution W = L^-1 B for this rank's own
  *                                 right-hand sides B (np x mpad row-major, mpad a multiple of 128, destroyed):
  *                                 W rows of the panel -> Wt (512 x mpad), B rows below -= L W, and
- *                                 q[j] += sum_r W[r][j]^2 (q may be NULL).  Replaces the solve_triangular /
+ *                                 q[j] += sum_r W[r][j]^2 (q may be NULL).  col_tiles > 0: only the first col_tiles
+ *                                 128-column tiles of B take part (the others are known to be zero).  Replaces the
+ *                                 solve_triangular /
  *                                 GEMM pair of `conditional` (gpim/gpreg/gpr.py:247-248) for a factor that is
  *                                 streamed through the ranks panel by panel. */
 int gpimhip_dist_setup(gpimhip_handle h, int64_t n, int32_t world, int32_t rank);
@@ -283,7 +285,34 @@ int gpimhip_dist_panel_pack(gpimhip_handle h, const double* Aloc, int64_t ldloc,
 int gpimhip_dist_update(gpimhip_handle h, const double* buf, int64_t ldbuf, int32_t panel_glob_blk0,
                         double* Aloc, int64_t ldloc, int32_t panel_first, int32_t panel_last);
 int gpimhip_dist_solve_update(gpimhip_handle h, const double* buf, int64_t ldbuf, int32_t panel_glob_blk0,
-                              double* B, int64_t ldb, int64_t mpad, double* Wt, int64_t ldw, double* q);
+                              double* B, int64_t ldb, int64_t mpad, double* Wt, int64_t ldw, double* q,
+                              int32_t col_tiles);
+
+/* Distributed TRAINING of that one exact GP (gpim/gpreg/gpr.py:170-217 for a covariance that does not fit one
+ * device; driver: gpim_amd/dist_chol.py exact_gp_fit).  Per Adam iteration, at the unconstrained parameters u:
+ *   gpimhip_dist_kmat_cols    columns [col0, col0 + ncols_pad) of K(u) + (jitter + noise) I into out (np rows; identity
+ *                             on the padding diagonal) -- every rank builds its own panels
+ *   (factorisation as above, then X = L^-1 by streaming the factor once more through gpimhip_dist_solve_update with
+ *    B = this rank's identity columns, Wt = the panel's rows of the rank's X share, col_tiles = the block columns that
+ *    are not structurally zero yet)
+ *   gpimhip_dist_kinv_update  xbuf: the broadcast block-column panel of X with global block index panel_glob_blk0
+ *                             (all np rows x 512); rows of that panel of K^-1 = X^T X for the OWNED columns
+ *                             (tiles i >= j) -> Kinv (np x owned columns, like Aloc)
+ *   gpimhip_dist_grad_sums    the rank's share of  sum_ij (K^-1 - alpha alpha^T)_ij dK_ij/dtheta  reduced to 8
+ *                             doubles S_out (device); the ranks all-reduce (sum) them
+ *   gpimhip_dist_finalize     loss (given quad = y^T alpha and half_logdet = sum log L_ii), d loss / du, and -- for
+ *                             t >= 1, the 1-based Adam iteration -- torch.optim.Adam's step on u (state in the handle,
+ *                             reset at t = 1) and the constrained values of the stepped u in hist_row; t = 0:
+ *                             loss and gradient only.  Identical inputs on every rank -> identical u. */
+int gpimhip_dist_kmat_cols(gpimhip_handle h, const gpimhip_model_t* m, const double* X, int64_t N, const double* u,
+                           int64_t col0, int64_t ncols_pad, double* out, int64_t ld);
+int gpimhip_dist_kinv_update(gpimhip_handle h, const double* xbuf, int64_t ldx, int32_t panel_glob_blk0,
+                             const double* Xloc, int64_t ldloc, double* Kinv, int64_t ldk);
+int gpimhip_dist_grad_sums(gpimhip_handle h, const gpimhip_model_t* m, const double* X, int64_t N, const double* u,
+                           const double* Kinv, int64_t ldk, const double* alpha, double* S_out);
+int gpimhip_dist_finalize(gpimhip_handle h, const gpimhip_model_t* m, int64_t N, double* u, const double* S,
+                          double quad, double half_logdet, double lr, int32_t t, double* loss_out, double* grad_out,
+                          double* hist_row);
 
 /* Batch thinning of boptimizer.update_points (gpim/gpbayes/boptim.py:326-376): among n <= 1024 ranked
  * candidates (vals, flat grid indices into a d-dimensional grid of the given shape) repeatedly keep the

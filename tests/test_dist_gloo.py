@@ -138,14 +138,27 @@ class NumpyTileEngine:
                 wc, c0, l0 = L.width(c), c * PW, L.local_col0(c)
                 Aloc[c0:, l0:l0 + wc] -= panel[c0:L.np, :wp] @ panel[c0:c0 + wc, :wp].T
 
-    def solve_update(self, buf, p, B, Wt, q):
+    def solve_update(self, buf, p, B, Wt, q, col_tiles=0):
         from gpim_amd.dist_chol import PW
         L = self.layout
         w, r0 = L.width(p), p * PW
-        Wp = torch.linalg.solve_triangular(torch.tril(buf[r0:r0 + w, :w]), B[r0:r0 + w], upper=False)
-        q += (Wp * Wp).sum(0)
+        nc = col_tiles * 128 if col_tiles else B.shape[1]
+        Wp = torch.linalg.solve_triangular(torch.tril(buf[r0:r0 + w, :w]), B[r0:r0 + w, :nc], upper=False)
+        Wt[:w, :nc] = Wp
+        if q is not None:
+            q[:nc] += (Wp * Wp).sum(0)
         if r0 + w < L.np:
-            B[r0 + w:].addmm_(buf[r0 + w:L.np, :w], Wp, alpha=-1.0)
+            B[r0 + w:, :nc].addmm_(buf[r0 + w:L.np, :w], Wp, alpha=-1.0)
+
+    def kinv_update(self, xbuf, c, Xloc, Kinv):
+        from gpim_amd.dist_chol import PW
+        L = self.layout
+        w, r0 = L.width(c), c * PW
+        full = xbuf[:L.np, :w].T @ Xloc                         # rows of panel c of X^T X against the owned columns
+        for p in L.owned:
+            if p <= c:                                          # block columns left of / at the panel: tiles i >= j
+                l0 = L.local_col0(p)
+                Kinv[r0:r0 + w, l0:l0 + L.width(p)] = full[:, l0:l0 + L.width(p)]
 
     def failed_column(self):
         return self.bad
@@ -184,6 +197,16 @@ def _chol_worker(rank, world, port, ret):
         want = (torch.linalg.solve_triangular(Lref, Bm[:n].clone(), upper=False) ** 2).sum(0) if m_loc else torch.zeros(0)
         got = ch.solve_colsumsq(Bm)
         assert torch.allclose(got, want.to(torch.float64), rtol=1e-9, atol=1e-12)
+        # training passes: X = L^-1 and K^-1 = X^T X, both distributed like L (lower parts against torch)
+        Xl = ch.inverse()
+        Kl = ch.kinv(Xl)
+        Xref = torch.linalg.inv(Lref)
+        Kref = torch.linalg.inv(A)
+        for p in lay.owned:
+            c0, w, l0 = p * 512, min(512, n - p * 512), lay.local_col0(p)
+            assert torch.allclose(Xl[:n, l0:l0 + w], Xref[:, c0:c0 + w], rtol=1e-9, atol=1e-12)
+            mask = (torch.arange(n)[:, None] >= torch.arange(c0, c0 + w)[None, :])
+            assert torch.allclose(Kl[:n, l0:l0 + w][mask], Kref[:, c0:c0 + w][mask], rtol=1e-9, atol=1e-12)
     # a matrix that is not positive-definite is reported on every rank
     A = torch.eye(700, dtype=torch.float64)
     A[600, 600] = -1.0

@@ -74,3 +74,56 @@ def test_exact_gp_posterior_mean_vs_oracle(ensure_built):
     assert_allclose(mean, mref.numpy(), atol=1e-9)
     assert_allclose(sd, vref.sqrt().numpy(), atol=1e-9)
     assert_allclose(nll, (gp.loss() - kp.neg_log_prior()).item(), rtol=1e-11)
+
+
+def _train_problem(n=1300, seed=5):
+    rng = np.random.default_rng(seed)
+    pts = np.unique(rng.integers(0, 64, size=(6000, 2)), axis=0)
+    pts = pts[rng.permutation(len(pts))[:n]].astype(np.float64)
+    y = np.sin(pts[:, 0] / 6.0) * np.cos(pts[:, 1] / 8.0) + 0.05 * rng.standard_normal(len(pts))
+    return pts, y
+
+
+@pytest.mark.parametrize("kind", ["RBF", "Matern52"])
+def test_distributed_loss_and_gradient_vs_single_gpu(ensure_built, kind):
+    """Loss and d loss / du through the distributed passes (K columns, block-column-cyclic factor, streamed inverse,
+    K^-1 = X^T X, sharded gradient sums) at P = 1 against gpimhip_nll_grad (pinned to the oracle in test_gpu_ops.py)."""
+    from gpim_amd import _lib
+    from gpim_amd.dist_chol import exact_gp_nll_grad
+    from gpim_amd.kernels import KernelSpec
+    pts, y = _train_problem()
+    ls = [[1., 1.], [20., 20.]]
+    spec = KernelSpec(kind, 2, ls, jitter=1e-5)
+    u = spec.draw_initial_u(torch.Generator().manual_seed(3))
+    loss_d, grad_d = exact_gp_nll_grad(pts, y, u, kernel=kind, lengthscale=ls)
+    H = _lib.Handle()
+    m = spec.struct()
+    Xd, yd, ud = (torch.from_numpy(a).cuda() for a in (pts, y, u.numpy()))
+    out = torch.zeros(1 + spec.n_params, dtype=torch.float64, device="cuda")
+    _lib.check(H.lib.gpimhip_nll_grad(H.h, ctypes.byref(m), _lib.ptr(Xd), _lib.ptr(yd), len(y), _lib.ptr(ud),
+                                      ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(out.data_ptr() + 8)))
+    o = out.cpu().numpy()
+    assert_allclose(loss_d, o[0], rtol=1e-11)
+    assert_allclose(grad_d, o[1:], rtol=1e-8, atol=1e-9 * np.abs(o[1:]).max())
+    H.close()
+
+
+def test_distributed_training_vs_reconstructor(ensure_built):
+    """exact_gp_fit (P = 1) follows reconstructor.train: same seed -> same initial draw, same Adam trajectory."""
+    import gpim_amd
+    from gpim_amd.dist_chol import exact_gp_fit
+    rng = np.random.default_rng(11)
+    R = np.full((48, 48), np.nan)
+    idx = rng.permutation(48 * 48)[:900]
+    ii, jj = np.unravel_index(idx, R.shape)
+    R[ii, jj] = np.sin(ii / 5.0) * np.cos(jj / 7.0) + 0.05 * rng.standard_normal(len(idx))
+    X, Xf = gpim_amd.utils.get_sparse_grid(R), gpim_amd.utils.get_full_grid(R)
+    kw = dict(kernel="Matern52", lengthscale=[[1., 1.], [20., 20.]], learning_rate=0.1, iterations=8)
+    rec = gpim_amd.reconstructor(X, R, Xf, verbose=0, seed=0, **kw)
+    rec.train()
+    pts = rec.X.cpu().numpy()
+    yv = rec.y.cpu().numpy()
+    hyper, u = exact_gp_fit(pts, yv, seed=0, **kw)
+    assert_allclose(hyper["lengthscale"], np.asarray(rec.hyperparams["lengthscale"]), rtol=1e-8)
+    assert_allclose(hyper["variance"], np.asarray(rec.hyperparams["variance"]), rtol=1e-8)
+    assert_allclose(hyper["noise"], np.asarray(rec.hyperparams["noise"]), rtol=1e-8)

@@ -86,6 +86,36 @@ def main():
     check("posterior sd vs oracle", np.abs(sd - vref.sqrt().numpy()).max() < 1e-9)
     nref = (gp.loss() - kp.neg_log_prior()).item()
     check("NLL vs oracle", abs(nll - nref) <= 1e-11 * abs(nref), "%.3e" % (abs(nll - nref) / abs(nref)))
+    # 3b. distributed training: loss / gradient at P = world against the single-GPU entry point, and a short Adam run
+    from gpim_amd.dist_chol import exact_gp_fit, exact_gp_nll_grad
+    from gpim_amd.kernels import KernelSpec
+    import ctypes
+    lsb = [[1., 1.], [20., 20.]]
+    spec = KernelSpec("Matern52", 2, lsb, jitter=1e-5)
+    u0 = spec.draw_initial_u(torch.Generator().manual_seed(3))
+    loss_d, grad_d = exact_gp_nll_grad(pts, y, u0, kernel="Matern52", lengthscale=lsb)
+    H = _lib.Handle()
+    mm = spec.struct()
+    Xd, yd, ud = (torch.from_numpy(a).to(dev) for a in (pts, y, u0.numpy()))
+    out = torch.zeros(1 + spec.n_params, dtype=torch.float64, device=dev)
+    _lib.check(H.lib.gpimhip_nll_grad(H.h, ctypes.byref(mm), _lib.ptr(Xd), _lib.ptr(yd), len(y), _lib.ptr(ud),
+                                      ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(out.data_ptr() + 8)))
+    o = out.cpu().numpy()
+    check("distributed loss", abs(loss_d - o[0]) <= 1e-11 * abs(o[0]), "%.3e" % (abs(loss_d - o[0]) / abs(o[0])))
+    check("distributed gradient", np.abs(grad_d - o[1:]).max() <= 1e-8 * np.abs(o[1:]).max(),
+          "%.3e" % (np.abs(grad_d - o[1:]).max() / np.abs(o[1:]).max()))
+    hist = torch.zeros((6, spec.n_params), dtype=torch.float64, device=dev)
+    us = ud.clone()
+    _lib.check(H.lib.gpimhip_fit_exact(H.h, ctypes.byref(mm), _lib.ptr(Xd), _lib.ptr(yd), len(y), _lib.ptr(us), 0.1, 6,
+                                       _lib.ptr(hist), None))
+    hyper, uf = exact_gp_fit(pts, y, kernel="Matern52", lengthscale=lsb, learning_rate=0.1, iterations=6, u0=u0)
+    hs = hist.cpu().numpy()
+    got = np.concatenate([hyper["variance"][:, None], hyper["lengthscale"], hyper["noise"][:, None]], axis=1)
+    check("distributed Adam trajectory", np.abs(got / hs - 1).max() <= 1e-8, "%.3e" % np.abs(got / hs - 1).max())
+    ulist = [torch.empty_like(uf) for _ in range(world)]
+    gdist.all_gather(ulist, uf)
+    check("every rank holds the same parameters", all(torch.equal(ulist[0], t) for t in ulist))
+    H.close()
     # 4. independent slices dealt to the ranks, gathered to rank 0 (device tensors through gather_to_root)
     cube, _ = hyperspectral_cube(size=24, nspec=6)
     kw = dict(kernel="RBF", lengthscale=[[1., 1.], [10., 10.]], learning_rate=0.1, iterations=5)
