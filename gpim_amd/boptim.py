@@ -50,6 +50,12 @@ class _LazyMaps(list):
     def __iter__(self):
         return (self._mat(i) for i in range(len(self)))
 
+    def __reversed__(self):
+        return (self._mat(i) for i in range(len(self) - 1, -1, -1))
+
+    def copy(self):
+        return [self._mat(i) for i in range(len(self))]
+
     def __reduce__(self):                   # pickles (np.save of the results dict) as a plain list of arrays
         return (list, (list(iter(self)),))
 
@@ -161,11 +167,19 @@ class boptimizer:
         (holding on to them made every step pay fresh hipMallocs, ~10x the cost of the step itself)."""
         slot = self._maps_used % 16
         if slot == 0:
+            # the previous slab is full: its 16 steps' maps go to the host now and the slab is released, so the
+            # device holds at most one slab (16 x 2 x M values) however long the exploration runs
+            for i in range(len(self.gp_predictions)):
+                self.gp_predictions._mat(i)
+            self._map_slabs.clear()
             self._map_slabs.append(torch.empty((16, 2, mean_d.numel()), dtype=mean_d.dtype, device=mean_d.device))
         slab = self._map_slabs[-1]
         if slab.shape[2] != mean_d.numel():                      # grid changed size: start a new slab
+            for i in range(len(self.gp_predictions)):
+                self.gp_predictions._mat(i)
+            self._map_slabs.clear()
             self._map_slabs.append(torch.empty((16, 2, mean_d.numel()), dtype=mean_d.dtype, device=mean_d.device))
-            slab, slot, self._maps_used = self._map_slabs[-1], 0, 16 * (len(self._map_slabs) - 1)
+            slab, slot, self._maps_used = self._map_slabs[-1], 0, 0
         slab[slot, 0].copy_(mean_d)
         slab[slot, 1].copy_(sd_d)
         self._maps_used += 1
@@ -314,6 +328,11 @@ class boptimizer:
         vals = np.array(acqfunc_values, dtype=np.float64)[first:]
         pts = np.vstack(indices)[first:]
         n, d = pts.shape
+        if n > 1024 or d > _lib.MAX_DIM:
+            # beyond the device kernel's limits (gpimhip_thin_batch: <= 1024 candidates, d <= 4): the same greedy
+            # maximum-and-suppress loop on the host
+            kept_ids = self._thin_host(vals, pts, float(dscale), int(self.batch_out_max))
+            return self._pad_batch(vals, pts, kept_ids)
         handle = self.surrogate_model._handle
         dev = handle.device
         shape = pts.max(axis=0).astype(np.int64) + 1                  # any box containing the candidates
@@ -327,6 +346,23 @@ class boptimizer:
                                                  _lib.ptr(shape_d), float(dscale), int(self.batch_out_max),
                                                  _lib.ptr(keep_d), _lib.ptr(nkeep_d)))
         kept_ids = keep_d[:int(nkeep_d.item())].cpu().numpy().astype(np.int64)
+        return self._pad_batch(vals, pts, kept_ids)
+
+    @staticmethod
+    def _thin_host(vals, pts, dscale, max_out):
+        """boptim.py:352-365 of the reference without the k-d tree: keep the largest remaining value, drop every
+        candidate within Euclidean distance dscale of it (inclusive, as cKDTree.query_ball_point), repeat."""
+        alive = np.ones(len(vals), dtype=bool)
+        work = vals.astype(np.float64).copy()
+        P = pts.astype(np.float64)
+        kept = []
+        while alive.any() and len(kept) < max_out:
+            i = int(np.argmax(np.where(alive, work, -np.inf)))
+            kept.append(i)
+            alive &= np.linalg.norm(P - P[i], axis=1) > dscale
+        return np.asarray(kept, dtype=np.int64)
+
+    def _pad_batch(self, vals, pts, kept_ids):
         kept_vals = vals[kept_ids].tolist()
         out = pts[kept_ids].tolist()
         if len(out) < self.batch_out_max:

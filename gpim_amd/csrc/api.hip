@@ -479,10 +479,7 @@ static int panel_steps(gpimhip_ctx* h, double* A, int64_t ld, int32_t* info, int
 static bool use_step_schedule(const gpimhip_ctx* h, int64_t np) {
     static const bool off = getenv("GPIMHIP_OLD_POTRF") != nullptr;
     (void)np;
-    // (not for large batches: with dozens of problems per launch the chip is saturated anyway, and the hosted
-    // tiles -- one workgroup per CU next to the 134 KB factorisation role -- run slower than in their own launches:
-    // C3, 64 problems of N = 1207, 1.21 vs 1.15 s)
-    return !off && !h->fp32 && h->dinvB != nullptr && h->nbatch <= 4;
+    return !off && !h->fp32 && h->dinvB != nullptr;
 }
 
 int launch_potrf(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_t* info) {

@@ -250,6 +250,7 @@ int launch_potrf_steps(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_
     static const int quad_max = getenv("GPIMHIP_FILL_QUAD_MAX") ? atoi(getenv("GPIMHIP_FILL_QUAD_MAX")) : 128;
     static const int half_max = getenv("GPIMHIP_FILL_HALF_MAX") ? atoi(getenv("GPIMHIP_FILL_HALF_MAX")) : 512;
     static const bool old_diag = getenv("GPIMHIP_OLD_DIAG") != nullptr;
+    static const int host_max_batch = getenv("GPIMHIP_HOST_MAX_BATCH") ? atoi(getenv("GPIMHIP_HOST_MAX_BATCH")) : 4;
     for (int j = 0; j < nb; ++j) {
         if (j % W == 0 && P.bulk_rest[j / W].n) {
             GemmArgs g = nt_update(A, ld, P.d_tiles + P.bulk_rest[j / W].off, P.bulk_rest[j / W].n, h->np);
@@ -262,7 +263,13 @@ int launch_potrf_steps(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_
         const int nf = P.fill[j].n;
         // mixed k-ranges (column updates are up to 2W-1 blocks deep, bulk tiles W): deal the list to the XCDs in chunks
         a.g.chunk = std::max(1, std::min(64, nf / 512));
-        if ((int64_t)nf * B <= quad_max)
+        if (B > host_max_batch) {
+            // large batches saturate the chip by themselves: the pending tiles run as their own launch (two to four
+            // workgroups per CU) in front of a factorisation-only step launch.  Same tile operations in the same
+            // order per output element as the hosted form, hence the same bits as a stand-alone problem.
+            if (nf) GP_TRY(launch_gemm(h, false, false, EPI_STORE, a.g));
+            hipLaunchKernelGGL((chol_step_kernel<64, 64>), dim3(1, B), dim3(NTH), 0, h->stream, a);
+        } else if ((int64_t)nf * B <= quad_max)
             hipLaunchKernelGGL((chol_step_kernel<64, 64>), dim3(nf ? 8 + 4 * nf : 1, B), dim3(NTH), 0, h->stream, a);
         else if ((int64_t)nf * B <= half_max)
             hipLaunchKernelGGL((chol_step_kernel<128, 64>), dim3(8 + 2 * nf, B), dim3(NTH), 0, h->stream, a);

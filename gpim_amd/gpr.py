@@ -115,7 +115,8 @@ class reconstructor:
         kernel (str): 'RBF', 'Matern52' or 'RationalQuadratic'
         lengthscale: ``[lo, hi]`` (one shared lengthscale) or ``[[lo...], [hi...]]`` bounds;
             default ``[[0]*d, [mean(y.shape)/2]*d]``
-        sparse, indpoints: inducing-point GP (not implemented yet)
+        sparse (bool), indpoints (int): sparse variational GP (VFE) with trainable inducing inputs, initialised as
+            X[::len(X) // indpoints] like the reference (csrc/vfe.hip)
         learning_rate (float), iterations (int): Adam settings
         use_gpu: ignored (always on the GPU)
         verbose (int): 0, 1 or 2

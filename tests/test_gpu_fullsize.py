@@ -17,7 +17,7 @@ from numpy.testing import assert_allclose
 pytestmark = pytest.mark.gpu
 
 from oracle import gpim_oracle as O
-from problems import hyperspectral_cube, lattice_image, spiral_image
+from problems import hyperspectral_cube, lattice_image, spiral_image, spiral_pfm_image
 
 
 @pytest.fixture(scope="module")
@@ -36,6 +36,24 @@ def test_c1_full_size_vs_oracle(gpim):
     torch.set_num_threads(1)
     assert_allclose(hyper["lengthscale"], ho["lengthscale"], rtol=1e-9)
     assert_allclose(hyper["noise"], ho["noise"], rtol=1e-9)
+    assert np.sqrt(np.mean((mean - mo) ** 2)) < 1e-9
+    assert np.sqrt(np.mean((sd - so) ** 2)) < 1e-9
+
+
+def test_c1_reference_data_vs_oracle(gpim):
+    """Config C1 on the reference's own data (expdata/spiral_s_00010_2019.npy, committed as a fixture; masked as the
+    notebook does: N = 4212): three Adam iterations + predict against the oracle."""
+    R = spiral_pfm_image()
+    assert int(np.isfinite(R).sum()) == 4212 and R.shape == (128, 128)
+    X, Xf = gpim.utils.get_sparse_grid(R), gpim.utils.get_full_grid(R)
+    kw = dict(kernel="RBF", lengthscale=[[1., 1.], [4., 4.]], learning_rate=0.1, iterations=3, verbose=0)
+    mean, sd, hyper = gpim.reconstructor(X, R, Xf, **kw).run()
+    torch.set_num_threads(min(32, torch.get_num_threads() * 32))
+    mo, so, ho = O.reconstructor(X, R, Xf, **kw).run()
+    torch.set_num_threads(1)
+    assert_allclose(hyper["lengthscale"], ho["lengthscale"], rtol=1e-9)
+    assert_allclose(hyper["noise"], ho["noise"], rtol=1e-9)
+    assert_allclose(hyper["variance"], ho["variance"], rtol=1e-9)
     assert np.sqrt(np.mean((mean - mo) ** 2)) < 1e-9
     assert np.sqrt(np.mean((sd - so) ** 2)) < 1e-9
 

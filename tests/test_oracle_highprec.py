@@ -63,3 +63,36 @@ def test_sparse_vfe_vs_high_precision(golden_dir):
         mean, var = gp.predict(torch.from_numpy(c["Xs"]))
         assert_allclose(mean.numpy(), c["vfe_mean"], rtol=0, atol=1e-10)
         assert_allclose(var.numpy(), c["vfe_var"], rtol=0, atol=1e-10)
+
+
+def load_cases2(golden_dir):
+    """tests/golden/gp_highprec2.npz (tests/tools/make_highprec_fixtures2.py): a d = 4 Matern52 GP and two GPs with
+    an ISOTROPIC lengthscale (d = 3), exact models only."""
+    z = np.load(os.path.join(golden_dir, "gp_highprec2.npz"))
+    for ci in range(int(z["n_cases"])):
+        t = "c%d_" % ci
+        yield {k[len(t):]: z[k] for k in z.files if k.startswith(t)}
+
+
+def test_isotropic_and_4d_vs_high_precision(golden_dir):
+    cases = list(load_cases2(golden_dir))
+    assert any(bool(c["iso"]) for c in cases) and any(c["X"].shape[1] == 4 for c in cases)
+    for c in cases:
+        kind, d, iso = str(c["kind"]), c["X"].shape[1], bool(c["iso"])
+        ls = [float(c["ls"][0]), float(c["ls"][1])] if iso else [c["ls"][0].tolist(), c["ls"][1].tolist()]
+        kp = O.KernelParams(kind, d, ls)
+        u = torch.from_numpy(c["u"])
+        nl = 1 if iso else d
+        with torch.no_grad():
+            kp.u_var.copy_(u[0])
+            kp.u_ls.copy_(u[1:1 + nl].reshape(kp.u_ls.shape))
+            kp.u_noise.copy_(u[1 + nl])
+            if kp.u_alpha is not None:
+                kp.u_alpha.copy_(u[2 + nl])
+        gp = O.ExactGP(torch.from_numpy(c["X"]), torch.from_numpy(c["y"]), kp, float(c["jitter"]))
+        loss, g = gp.loss_and_grad()
+        assert_allclose(loss.item(), float(c["loss"]), rtol=1e-13)
+        assert_allclose(g.numpy(), c["grad"], rtol=1e-10, atol=1e-12)
+        mean, var = gp.predict(torch.from_numpy(c["Xs"]))
+        assert_allclose(mean.numpy(), c["mean"], rtol=0, atol=1e-12)
+        assert_allclose(var.numpy(), c["var"], rtol=0, atol=1e-12)
