@@ -35,6 +35,7 @@ _PROTOS = {
     "gpimhip_destroy": (ctypes.c_int, [ctypes.c_void_p]),
     "gpimhip_last_error": (ctypes.c_char_p, []),
     "gpimhip_version": (ctypes.c_int, []),
+    "gpimhip_shutdown": (ctypes.c_int, []),
     "gpimhip_workspace_bytes": (ctypes.c_int64, [ctypes.c_void_p]),
     "gpimhip_sync": (ctypes.c_int, [ctypes.c_void_p]),
     "gpimhip_fit_completed": (ctypes.c_int, [ctypes.c_void_p]),
@@ -122,7 +123,30 @@ def load():
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
     _lib = lib
+    import atexit
+    atexit.register(_shutdown)
     return lib
+
+
+_live = None
+
+
+def _shutdown():
+    """Interpreter exit: close the handles that are still alive, then release the library's helper streams while the
+    HIP runtime is still up (see gpimhip_shutdown)."""
+    import gc
+    gc.collect()
+    for h in list(_live or ()):
+        try:
+            h.close()
+        except Exception:
+            pass
+    try:
+        if torch.cuda.is_available() and torch.cuda.is_initialized():
+            torch.cuda.synchronize()
+            _lib.gpimhip_shutdown()
+    except Exception:
+        pass
 
 
 def require_gpu():
@@ -159,6 +183,11 @@ class Handle:
         check(lib.gpimhip_create(ctypes.byref(h), self.device.index, ctypes.c_void_p(stream)))
         self._h = h
         self.lib = lib
+        global _live
+        if _live is None:
+            import weakref
+            _live = weakref.WeakSet()
+        _live.add(self)
         self.precision = precision
         if precision == "single":       # N x N matrices and the O(N^3) products in float (gpimhip_set_precision)
             check(lib.gpimhip_set_precision(h, 32))

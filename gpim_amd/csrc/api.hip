@@ -774,6 +774,20 @@ static void dist_plan_release(gpimhip_ctx* h);
 extern "C" {
 
 const char* gpimhip_last_error(void) { return g_err.c_str(); }
+
+// Destroys the process-wide side streams (ensure_lookahead_streams / ensure_capture_stream).  Called by the Python
+// binding at interpreter exit, while the HIP runtime is still up: a priority / CU-masked stream that is alive when
+// the process tears down makes rocprofv3's exit handler crash (segmentation fault after the CSVs are written).
+int gpimhip_shutdown(void) {
+    std::lock_guard<std::mutex> lock(g_side_mutex);
+    for (auto& S : g_side) {
+        if (S.panel) (void)hipStreamDestroy(S.panel);
+        if (S.bulk) (void)hipStreamDestroy(S.bulk);
+        if (S.capture) (void)hipStreamDestroy(S.capture);
+        S = SideStreams();
+    }
+    return GPIMHIP_OK;
+}
 int gpimhip_version(void) { return 100; }
 
 int gpimhip_create(gpimhip_handle* out, int device, void* hip_stream) {

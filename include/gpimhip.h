@@ -340,6 +340,11 @@ int gpimhip_timing_read(gpimhip_handle h, int stage, double* total_ms, int64_t* 
  * u_inout and the first gpimhip_fit_completed() rows of hist_out / loss_out are valid after the error. */
 int gpimhip_fit_completed(gpimhip_handle h);
 
+/* Releases the process-wide helper streams of the library (created on first use, shared by all handles).  Call once,
+ * after the last handle has been destroyed and before the process exits; the Python binding registers it with
+ * atexit.  Handles created afterwards recreate what they need. */
+int gpimhip_shutdown(void);
+
 /* Block until everything enqueued on the handle's stream has finished. */
 int gpimhip_sync(gpimhip_handle h);
 

@@ -44,3 +44,4 @@ if os.environ.get("PROF_STAGES"):
         print("  stage %-6s %.3f ms per call (%d calls)" % (nm, ms.value / max(cnt.value, 1), cnt.value))
     lib.gpimhip_timing_enable(H.h, 0)
 print("workspace GiB", lib.gpimhip_workspace_bytes(H.h) / 2**30)
+H.close(); del H; torch.cuda.synchronize()

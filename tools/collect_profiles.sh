@@ -5,17 +5,24 @@
 # tools/summarize_profiles.py regenerates the derived tables).
 cd /tmp; export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r02}
+TAG=${1:-r03}
 O=$R/gpurun_out/prof_$TAG
 rm -rf $O; mkdir -p $O
 # 1. kernel stats of the bench command itself (+ the JSON lines with and without the profiler)
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_stats -- python $R/bench.py > $O/bench_line_profiled.json 2> $O/bench_profiled.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_stats -- python $R/bench.py --no-cpu-baseline > $O/bench_line_profiled.json 2> $O/bench_profiled.err
 python $R/bench.py > $O/bench_line.json 2> $O/bench.err
+# 1b. the configs north_star names as targets: C1 (128x128 spiral scan) and C3 (64 slices of 64x64), kernel stats + lines
+for wl in c1 c3; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/${wl}_stats -- python $R/bench.py --workload $wl --no-cpu-baseline > $O/${wl}_line_profiled.json 2> $O/${wl}_profiled.err
+  python $R/bench.py --workload $wl > $O/${wl}_line.json 2> $O/${wl}.err
+done
 # 2. PMC passes on two training iterations at the bench size (separate runs, kernel trace only)
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE"; do
   tag=$(echo $set | cut -d' ' -f1)
   rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/pmc_$tag -- python $R/tests/tools/prof_fit.py 16384 2 0 Matern52 > /dev/null 2>&1
 done
+# kernel traces of the bench runs are tens of MB each (gpurun copies back at most 64 MiB): the stats CSVs are what is kept
+find $O/bench_stats $O/c1_stats $O/c3_stats -name "*_kernel_trace.csv" -delete
 # the profiled bench also traces its child process (the extras): keep the PARENT's stats (lowest pid)
 ls $O/bench_stats/*/*_kernel_stats.csv | sort -t/ -k1 -V | head -3
 find $O -name "*.csv" | head -30
