@@ -170,6 +170,12 @@ static void lower_patches(std::vector<TileDesc>& out, int lo, int hi, int kb0, i
                     if (j <= i) out.push_back({i, j, kb0, kb1});
 }
 
+static bool pair_mode(int nb) {
+    static const int v = getenv("GPIMHIP_PAIR") ? atoi(getenv("GPIMHIP_PAIR")) : -1;
+    if (v >= 0) return v != 0;
+    return nb >= 112;     // N = 16384: 32.2 -> 31.4 ms, 20480: 57.9 -> 57.3; no gain at 8192 / 12288
+}
+
 // Share of the previous panel's bulk update hosted by one step launch: at most this many tiles; what is left runs
 // as a plain tile-engine launch before the panel's first step.  Hosted tiles run one workgroup per CU (the 134 KB
 // factorisation role sets the launch's LDS size), 7 % slower than in their own launch (two per CU): up to
@@ -179,6 +185,7 @@ static void lower_patches(std::vector<TileDesc>& out, int lo, int hi, int kb0, i
 static int fill_cap(int nb) {
     static const int v = getenv("GPIMHIP_FILL_CAP") ? atoi(getenv("GPIMHIP_FILL_CAP")) : -1;
     if (v >= 0) return v;
+    if (pair_mode(nb)) return 0;       // hosted k-depth-1024 tiles would outlast the factorisation role by far
     return nb < 64 ? (1 << 30) : 32;
 }
 
@@ -195,9 +202,27 @@ int step_plan_ensure(gpimhip_ctx* h, int nb) {
     P.bulk_rest.assign(npanel, {0, 0});
     for (int p = 0; p < npanel; ++p) {
         const int p0 = p * W, p1 = std::min(p0 + W, nb), ncol = p1 - p0;
-        // bulk(p-1): columns >= p0 + W, k-blocks = the columns of panel p-1
+        // bulk(p-1): columns >= p0 + W, k-blocks = the columns of panel p-1.
+        // Pair mode (large matrices): panels are applied two at a time to everything at least two panels to their
+        // right -- k-depth 1024, half the passes over the trailing matrix -- and an even panel alone only to the one
+        // destination panel that needs it before its partner is factored:
+        //   start of an odd panel p  (p-1 even): panel p-1 -> destination panel p+1 only           (k-depth 512)
+        //   start of an even panel p (p-1 odd) : panels p-2, p-1 -> every column >= p0 + W          (k-depth 1024)
+        // Each destination panel Q still receives every source panel S <= Q-2 exactly once here and S >= Q-1 through
+        // the left-looking column updates / diagonal updates below.
         std::vector<TileDesc> bulk;
-        if (p > 0 && p0 + W < nb) lower_patches(bulk, p0 + W, nb, p0 - W, p0);
+        if (p > 0 && p0 + W < nb) {
+            if (!pair_mode(nb)) {
+                lower_patches(bulk, p0 + W, nb, p0 - W, p0);
+            } else if ((p - 1) % 2 == 0) {
+                const int c0 = p0 + W, c1 = std::min(p0 + 2 * W, nb);
+                for (int ig = c0 / 8; ig <= (nb - 1) / 8; ++ig)
+                    for (int i = std::max(c0, ig * 8); i < std::min(nb, ig * 8 + 8); ++i)
+                        for (int j = c0; j < std::min(c1, i + 1); ++j) bulk.push_back({i, j, p0 - W, p0});
+            } else {
+                lower_patches(bulk, p0 + W, nb, p0 - 2 * W, p0);
+            }
+        }
         const int per = std::min<int>(fill_cap(nb), (int)((bulk.size() + ncol - 1) / ncol));
         size_t taken = 0;
         for (int j = p0; j < p1; ++j) {

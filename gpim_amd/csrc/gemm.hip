@@ -36,7 +36,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_tiles_kernel(GemmArgs g) {
 // Up to this many tiles the 8-wave shape is launched with 24 KB of unused dynamic LDS on top of its 74 KB of
 // staging buffers, so that every tile has a CU to itself (K^-1 product at N = 4206: 0.71 -> 0.56 ms).
 static int mid_tiles() {
-    static const int v = getenv("GPIMHIP_MID_TILES") ? atoi(getenv("GPIMHIP_MID_TILES")) : 2048;
+    static const int v = getenv("GPIMHIP_MID_TILES") ? atoi(getenv("GPIMHIP_MID_TILES")) : 1100;   // (2048-tile levels of the inverse at N = 16384: 4-wave, two per CU, is 0.25 ms faster)
     return v;
 }
 
