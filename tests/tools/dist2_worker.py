@@ -38,11 +38,14 @@ def main():
     for n in (700, 1500, 2600):
         rng = np.random.default_rng(n)
         Bm = rng.standard_normal((n, n // 3))
-        A = torch.from_numpy(Bm @ Bm.T + n * np.eye(n)).to(dev)
+        Ah = torch.from_numpy(Bm @ Bm.T + n * np.eye(n))
+        A = Ah.to(dev)
         ch = DistributedCholesky(n)
         ch.set_from_function(lambda c0, c1: A[:, c0:c1]).factor()
         Ld = ch.gather_lower()
-        ref = torch.linalg.cholesky(A)
+        # reference on the host (torch.linalg.cholesky on the device goes through the vendor solver library, which
+        # returned a wrong factor once while the other rank was busy on the same GPU)
+        ref = torch.linalg.cholesky(Ah).to(dev)
         scale = ref.abs().max().item()
         check("factor n=%d vs torch" % n, (Ld - ref).abs().max().item() <= 1e-11 * scale,
               "%.2e" % ((Ld - ref).abs().max().item() / scale))
