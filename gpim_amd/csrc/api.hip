@@ -482,8 +482,38 @@ static bool use_step_schedule(const gpimhip_ctx* h, int64_t np) {
     return !off && !h->fp32 && h->dinvB != nullptr;
 }
 
+// Hybrid schedule (OFF by default, GPIMHIP_TAIL_BLOCKS > 0 switches it on): the two-stream look-ahead below for the
+// head of a large factorisation, where the bulk update of a round outlasts the panel chain, and the single-stream step
+// schedule for the last tail_blocks() block columns, which the head leaves fully updated.  Measured, potrf alone at
+// N = 16384 / 20480: 31.4 / 56.7 ms without it, 32.9 / 59.6 with a 48-block tail, 33.9 / 60.1 with 72, 34.6 / 61.2 with
+// 96 -- the look-ahead head (bulk on 240 CUs, k-depth 512, chain kernels competing for the rest) is slower than the
+// step schedule's in-order head with k-depth-1024 pair updates on all 256 CUs.
+static int tail_blocks() {
+    static const int v = getenv("GPIMHIP_TAIL_BLOCKS") ? atoi(getenv("GPIMHIP_TAIL_BLOCKS")) : 0;
+    return v;
+}
+static int launch_potrf_lookahead(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_t* info, int stop_panel);
+
 int launch_potrf(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_t* info) {
-    if (use_step_schedule(h, np)) return launch_potrf_steps(h, A, np, ld, info);
+    const int nb_all = (int)(np / NB), npanel_all = (nb_all + OUTER_W - 1) / OUTER_W;
+    if (use_step_schedule(h, np)) {
+        const int tail = tail_blocks() / OUTER_W * OUTER_W;
+        if (h->nbatch == 1 && tail > 0 && nb_all - tail >= 4 * OUTER_W) {
+            ensure_lookahead_streams(h);
+            if (h->panel_stream && h->bulk_stream) {
+                const int head_panels = (nb_all - tail) / OUTER_W;
+                GP_TRY(plan_ensure(h, nb_all));
+                GP_TRY(launch_potrf_lookahead(h, A, np, ld, info, head_panels));
+                return launch_potrf_steps(h, A, np, ld, info, head_panels * OUTER_W);
+            }
+        }
+        return launch_potrf_steps(h, A, np, ld, info);
+    }
+    return launch_potrf_lookahead(h, A, np, ld, info, npanel_all);
+}
+
+// Factors the panels [0, stop_panel) and applies their updates to everything right of them.
+static int launch_potrf_lookahead(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_t* info, int stop_panel) {
     const int nb = (int)(np / NB);
     GP_TRY(plan_ensure(h, nb));
     const LinalgPlan& P = h->plan;
@@ -493,6 +523,7 @@ int launch_potrf(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_t* inf
     // behind them (measured: 9.4 vs 9.5 ms at N = 6144, 15.5 vs 16.2 at 8192, 25.8 vs 27.5 at 10240)
     if (npanel >= LOOKAHEAD_MIN_PANELS) ensure_lookahead_streams(h);
     const bool ahead = (h->panel_stream != nullptr) && npanel >= LOOKAHEAD_MIN_PANELS;
+    const int last = std::min(stop_panel, npanel) - 1;          // last panel this routine factors
     while ((int)h->ev_pool.size() < 2 * npanel + 2) {
         hipEvent_t e;
         HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -504,7 +535,8 @@ int launch_potrf(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_t* inf
     int rc = GPIMHIP_OK;
     // panel 0 has nothing to overlap with
     GP_TRY(panel_steps(h, A, ld, info, 0, std::min(OUTER_W, nb)));
-    for (int p = 0; p + 1 < npanel; ++p) {
+    for (int p = 0; p <= last && p + 1 < npanel; ++p) {
+        const bool factor_next = p + 1 <= last;
         const int klast = std::min((p + 1) * OUTER_W, nb) - 1;      // last column of panel p
         const int q0 = (p + 1) * OUTER_W, q1 = std::min(q0 + OUTER_W, nb);
         GemmArgs gn = gemm_args(A, ld, A, ld, A, ld, -1.0, 1.0, P.d_tiles + P.trail_next[klast].off,
@@ -514,7 +546,7 @@ int launch_potrf(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_t* inf
             // in-order schedule (small / mid N, or no side streams)
             if (gn.ntiles) GP_TRY(launch_gemm(h, false, false, EPI_STORE, gn));
             if (gb.ntiles) GP_TRY(launch_gemm(h, false, false, EPI_STORE, gb));
-            GP_TRY(panel_steps(h, A, ld, info, q0, q1));
+            if (factor_next) GP_TRY(panel_steps(h, A, ld, info, q0, q1));
             continue;
         }
         // Panel p is final (ev0 / evF(p-1)).  Two chains, ordered by events between the two side
@@ -536,7 +568,7 @@ int launch_potrf(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_t* inf
         }
         h->stream = h->panel_stream;
         rc = gn.ntiles ? launch_gemm(h, false, false, EPI_STORE, gn) : GPIMHIP_OK;
-        if (rc == GPIMHIP_OK) rc = panel_steps(h, A, ld, info, q0, q1);
+        if (rc == GPIMHIP_OK && factor_next) rc = panel_steps(h, A, ld, info, q0, q1);
         h->stream = main_s;
         GP_TRY(rc);
         HIP_TRY(hipEventRecord(evF(p), h->panel_stream));
@@ -545,7 +577,7 @@ int launch_potrf(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_t* inf
         h->stream = main_s;
         GP_TRY(rc);
         HIP_TRY(hipEventRecord(evB(p), bs));
-        if (p + 2 == npanel) {
+        if (p + 2 == npanel || p == last) {
             HIP_TRY(hipStreamWaitEvent(main_s, evF(p), 0));
             HIP_TRY(hipStreamWaitEvent(main_s, evB(p), 0));
         }

@@ -30,6 +30,7 @@
 struct StepArgs {
     double* A; int64_t ld; int kblk; int nb;
     double* dinv_all; double* dinvB_all; double* logdet; int32_t* info;
+    int col_off;                // global index of the sub-matrix's first column (non-PD reporting)
     GemmArgs g;                 // filler tiles (NT, alpha = -1, beta = 1)
 };
 
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(NTH, 1) void chol_step_kernel(StepArgs a) {
         return;
     }
     if (b != 0) return;
-    potf2_body<double>(smem, (int)blockIdx.y, a.A, a.ld, a.kblk, a.dinv_all, a.dinvB_all, a.logdet, a.info, a.nb);
+    potf2_body<double>(smem, (int)blockIdx.y, a.A, a.ld, a.kblk, a.dinv_all, a.dinvB_all, a.logdet, a.info, a.nb, a.col_off);
 }
 
 // Panel solve, one workgroup (4 waves) per 32-row strip of the block column below the diagonal block:
@@ -189,8 +190,7 @@ static int fill_cap(int nb) {
     return nb < 64 ? (1 << 30) : 32;
 }
 
-int step_plan_ensure(gpimhip_ctx* h, int nb) {
-    StepPlan& P = h->splan;
+static int step_plan_build(gpimhip_ctx* h, int nb, StepPlan& P) {
     if (P.nb == nb) return GPIMHIP_OK;
     if (P.d_tiles) { (void)hipFree(P.d_tiles); P.d_tiles = nullptr; }
     const int W = STEP_W;
@@ -250,10 +250,15 @@ int step_plan_ensure(gpimhip_ctx* h, int nb) {
     return GPIMHIP_OK;
 }
 
+int step_plan_ensure(gpimhip_ctx* h, int nb) { return step_plan_build(h, nb, h->splan); }
+int step_plan_ensure_tail(gpimhip_ctx* h, int nb) { return step_plan_build(h, nb, h->splan_tail); }
+
 void step_plan_release(gpimhip_ctx* h) {
-    if (h->splan.d_tiles) (void)hipFree(h->splan.d_tiles);
-    h->splan.d_tiles = nullptr;
-    h->splan.nb = 0;
+    for (StepPlan* P : {&h->splan, &h->splan_tail}) {
+        if (P->d_tiles) (void)hipFree(P->d_tiles);
+        P->d_tiles = nullptr;
+        P->nb = 0;
+    }
 }
 
 static GemmArgs nt_update(double* A, int64_t ld, const TileDesc* tiles, int n, int64_t rows) {
@@ -267,10 +272,17 @@ static GemmArgs nt_update(double* A, int64_t ld, const TileDesc* tiles, int n, i
 
 // lower Cholesky of the np x np matrix A (np = nb * 128), in place, on h->stream; h->dinv / h->dinvB / h->logdet_part
 // receive the inverses of the diagonal blocks and the log-determinant partials like the in-order driver of api.hip.
-int launch_potrf_steps(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_t* info) {
-    const int nb = (int)(np / NB), W = STEP_W;
-    GP_TRY(step_plan_ensure(h, nb));
-    const StepPlan& P = h->splan;
+// blk_off > 0: the trailing sub-matrix that starts at block (blk_off, blk_off) -- a Schur complement the caller has
+// brought up to date with every column left of it (hybrid schedule of api.hip: look-ahead head, step-schedule tail).
+int launch_potrf_steps(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_t* info, int blk_off) {
+    const int nb = (int)(np / NB) - blk_off, W = STEP_W;
+    if (blk_off) GP_TRY(step_plan_ensure_tail(h, nb));
+    else GP_TRY(step_plan_ensure(h, nb));
+    const StepPlan& P = blk_off ? h->splan_tail : h->splan;
+    A += (int64_t)blk_off * NB * (ld + 1);
+    double* const dinv = h->dinv + (int64_t)blk_off * NB * NB;
+    double* const dinvB = h->dinvB + (int64_t)blk_off * NB * NB;
+    double* const logdet = h->logdet_part + blk_off;
     const int B = h->nbatch;
     static const int quad_max = getenv("GPIMHIP_FILL_QUAD_MAX") ? atoi(getenv("GPIMHIP_FILL_QUAD_MAX")) : 128;
     static const int half_max = getenv("GPIMHIP_FILL_HALF_MAX") ? atoi(getenv("GPIMHIP_FILL_HALF_MAX")) : 512;
@@ -283,7 +295,8 @@ int launch_potrf_steps(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_
         }
         StepArgs a;
         a.A = A; a.ld = ld; a.kblk = j; a.nb = nb;
-        a.dinv_all = h->dinv; a.dinvB_all = h->dinvB; a.logdet = h->logdet_part; a.info = info;
+        a.dinv_all = dinv; a.dinvB_all = dinvB; a.logdet = logdet; a.info = info;
+        a.col_off = blk_off * NB;
         a.g = nt_update(A, ld, P.d_tiles + P.fill[j].off, P.fill[j].n, h->np);
         const int nf = P.fill[j].n;
         // mixed k-ranges (column updates are up to 2W-1 blocks deep, bulk tiles W): deal the list to the XCDs in chunks
@@ -303,7 +316,7 @@ int launch_potrf_steps(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_
         HIP_TRY(hipGetLastError());
         if (j + 1 < nb) {
             hipLaunchKernelGGL(panel_solve_kernel, dim3(4 * (nb - j - 1), B), dim3(256), 0, h->stream, A, ld, j, nb,
-                               (const double*)h->dinvB);
+                               (const double*)dinvB);
             HIP_TRY(hipGetLastError());
             if (old_diag) {
                 GemmArgs g = nt_update(A, ld, P.d_tiles + P.diag[j].off, P.diag[j].n, h->np);
@@ -328,6 +341,7 @@ int launch_panel_chain(gpimhip_ctx* h, double* A, int64_t ld, int p0, int p1, in
         StepArgs a;
         a.A = A; a.ld = ld; a.kblk = j; a.nb = nb;
         a.dinv_all = h->dinv; a.dinvB_all = h->dinvB; a.logdet = h->logdet_part; a.info = info;
+        a.col_off = 0;
         const PlanRange f = colfill[j - p0];
         a.g = nt_update(A, ld, tiles + f.off, f.n, h->np);
         a.g.chunk = 1;

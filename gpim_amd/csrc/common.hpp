@@ -137,7 +137,7 @@ struct gpimhip_ctx {
     int64_t pred_ntiles = 0;
     int64_t bytes = 0;
     LinalgPlan plan;
-    StepPlan splan;
+    StepPlan splan, splan_tail;     // whole matrix / the trailing sub-matrix of the hybrid schedule
     DistPlan dplan;
     // optional stage timing (bench.py): HIP event pairs on the handle's stream
     bool timing = false;
@@ -180,7 +180,8 @@ int ws_ensure(gpimhip_ctx* h, int64_t N);
 int ws_ensure_predict(gpimhip_ctx* h, int64_t np, int64_t mc);
 int plan_ensure(gpimhip_ctx* h, int nb);
 // cholstep.hip
-int launch_potrf_steps(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_t* info);
+int launch_potrf_steps(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_t* info, int blk_off = 0);
+int step_plan_ensure_tail(gpimhip_ctx* h, int nb);
 void step_plan_release(gpimhip_ctx* h);
 int step_plan_ensure(gpimhip_ctx* h, int nb);
 int launch_panel_chain(gpimhip_ctx* h, double* A, int64_t ld, int p0, int p1, int nb, const TileDesc* tiles,

@@ -22,7 +22,8 @@
 template <typename R>
 __device__ __forceinline__ void potf2_body(double* __restrict__ smem, const int by, R* __restrict__ A, int64_t ld, int kblk,
                                            R* __restrict__ dinv_all, double* __restrict__ dinvB_all,
-                                           double* __restrict__ logdet_out, int32_t* __restrict__ info, int nb PROF_ARG) {
+                                           double* __restrict__ logdet_out, int32_t* __restrict__ info, int nb PROF_ARG,
+                                           int col_off = 0) {
     double* D = smem;
     double* invd = D + NB * LDD;
     double* Xs = invd + NB;
@@ -60,7 +61,7 @@ __device__ __forceinline__ void potf2_body(double* __restrict__ smem, const int 
     __syncthreads();
     if (tid == 0) {
         logdet_out[kblk] = red[0] + red[1];
-        if (s_bad != 0 && *info == 0) *info = kblk * NB + s_bad;
+        if (s_bad != 0 && *info == 0) *info = col_off + kblk * NB + s_bad;
     }
     STAMP(3);
     STAMP(4);
