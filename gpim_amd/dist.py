@@ -149,7 +149,7 @@ def run_units(units, unit_fn, out_shape, device=None, concurrency=1):
 
 
 def reconstruct_slices(cube, axis=-1, batch=16, return_hyperparams=False, handle=None, sparse_concurrency=4,
-                       **recon_kwargs):
+                       batch_concurrency=1, **recon_kwargs):
     """Independent GP reconstruction of every slice of a 3D / 4D cube along `axis` (configs C3 and
     C5 of SURVEY 8(d)).  Slices are sharded over the ranks; on each GPU the owned slices with the same
     number of observations advance in lock-step, `batch` at a time, through the batched engine
@@ -157,6 +157,7 @@ def reconstruct_slices(cube, axis=-1, batch=16, return_hyperparams=False, handle
     Per-slice results are those of ``reconstructor(X_slice, R_slice, X_full, **recon_kwargs).run()``.
     handle: an existing ``_lib.Handle`` for the batched fits (its workspace is reused between calls).
     sparse_concurrency: how many sparse (inducing-point) slices are fitted at the same time on one GPU.
+    batch_concurrency: how many lock-step batches of exact GPs run at the same time on one GPU (own streams).
     Returns (mean, sd) cubes on rank 0 (None elsewhere)."""
     from . import gprutils
     from .batch import fit_predict_batch
@@ -202,14 +203,33 @@ def reconstruct_slices(cube, axis=-1, batch=16, return_hyperparams=False, handle
     by_n = {}
     for i in owned:
         by_n.setdefault(int(np.count_nonzero(~np.isnan(cube[i]))), []).append(i)
+    groups = []
     for n_obs, idxs in sorted(by_n.items()):
         for s in range(0, len(idxs), batch):
-            grp = idxs[s:s + batch]
-            Xs = [grid_of(cube[i]) for i in grp]
+            groups.append(idxs[s:s + batch])
+
+    def one_group(grp, own_stream):
+        Xs = [grid_of(cube[i]) for i in grp]
+        if own_stream:
+            with torch.cuda.device(dev), torch.cuda.stream(torch.cuda.Stream(device=dev)):
+                mean, sd, hist = fit_predict_batch(Xs, [cube[i] for i in grp], Xf, **recon_kwargs)
+                torch.cuda.current_stream().synchronize()
+        else:
             mean, sd, hist = fit_predict_batch(Xs, [cube[i] for i in grp], Xf, handle=handle, **recon_kwargs)
-            for k, i in enumerate(grp):
-                mine[i] = torch.stack([mean[k], sd[k]])
-                hyper[i] = hist[k].cpu().numpy()
+        return grp, mean, sd, hist
+
+    # several lock-step batches at a time (each on its own host thread / HIP stream / handle): the latency-bound
+    # launches of one batch (diagonal-block factorisations, panel solves) overlap the tile products of another
+    if batch_concurrency > 1 and len(groups) > 1 and handle is None:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(int(batch_concurrency), len(groups))) as pool:
+            done = list(pool.map(lambda g: one_group(g, True), groups))
+    else:
+        done = [one_group(g, False) for g in groups]
+    for grp, mean, sd, hist in done:
+        for k, i in enumerate(grp):
+            mine[i] = torch.stack([mean[k], sd[k]])
+            hyper[i] = hist[k].cpu().numpy()
     full = gather_to_root(mine, nunits, (2,) + tuple(cube.shape[1:]), device=dev)
     if full is None:
         return None

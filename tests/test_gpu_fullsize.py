@@ -120,3 +120,18 @@ def test_c3_batched_equals_single_on_samples(gpim):
                                        **kw).run()
         np.testing.assert_array_equal(mean[..., k], m1)
         np.testing.assert_array_equal(sd[..., k], s1)
+
+
+def test_concurrent_batches_and_sparse_slices_equal_sequential(gpim):
+    """reconstruct_slices with several lock-step batches (exact GPs) or several sparse slices in flight at a time --
+    host threads, one HIP stream and library handle each -- returns the bits of the sequential run."""
+    from gpim_amd import dist as gd
+    cube, _ = hyperspectral_cube(size=32, nspec=8)
+    kw = dict(kernel="RBF", lengthscale=[[1., 1.], [10., 10.]], learning_rate=0.1, iterations=12)
+    m1, s1 = gd.reconstruct_slices(cube, axis=-1, batch=8, **kw)
+    m2, s2 = gd.reconstruct_slices(cube, axis=-1, batch=2, batch_concurrency=4, **kw)
+    assert np.array_equal(m1, m2) and np.array_equal(s1, s2)
+    kws = dict(kw, sparse=True, indpoints=40)
+    m3, s3 = gd.reconstruct_slices(cube[..., :4], axis=-1, sparse_concurrency=1, **kws)
+    m4, s4 = gd.reconstruct_slices(cube[..., :4], axis=-1, sparse_concurrency=4, **kws)
+    assert np.array_equal(m3, m4) and np.array_equal(s3, s4)
