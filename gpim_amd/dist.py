@@ -158,6 +158,7 @@ def reconstruct_slices(cube, axis=-1, batch=16, return_hyperparams=False, handle
     handle: an existing ``_lib.Handle`` for the batched fits (its workspace is reused between calls).
     sparse_concurrency: how many sparse (inducing-point) slices are fitted at the same time on one GPU.
     batch_concurrency: how many lock-step batches of exact GPs run at the same time on one GPU (own streams).
+    batch="auto" picks both from the number of slices this rank owns.
     Returns (mean, sd) cubes on rank 0 (None elsewhere)."""
     from . import gprutils
     from .batch import fit_predict_batch
@@ -203,6 +204,11 @@ def reconstruct_slices(cube, axis=-1, batch=16, return_hyperparams=False, handle
     by_n = {}
     for i in owned:
         by_n.setdefault(int(np.count_nonzero(~np.isnan(cube[i]))), []).append(i)
+    if batch == "auto":
+        # measured on one MI355X (N = 1207 per slice, tools/r3_c3c.py): 8 slices 4 x 2 concurrent 0.27 s (one batch of
+        # 8: 0.32), 16 slices 4 x 4 0.35 (0.45), 32 slices 16 x 2 0.64 (0.68), 64 slices 16 x 4 0.99 (1.11)
+        batch = 4 if len(owned) <= 16 else 16
+        batch_concurrency = min(4, max(1, (len(owned) + batch - 1) // batch))
     groups = []
     for n_obs, idxs in sorted(by_n.items()):
         for s in range(0, len(idxs), batch):
