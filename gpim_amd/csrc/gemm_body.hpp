@@ -6,6 +6,13 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
 
 #define LD_MK (GEMM_BK + 2)
+// doubles between two 8-row groups of a directly staged k-contiguous tile.  128 = the groups back to back: rows m and
+// m + 8 of a fragment read then share their banks (2-way conflict on every read); 130 shifts the second group of a
+// 16-row fragment by 16 bytes, onto the banks the first one leaves free (within a group the XOR swizzle uses the
+// chunks of one parity of k >> 1 per row parity) -- conflict-free, and 16 x 130 <= 18 x 128 still fits a stage.
+#ifndef MK_GROUP
+#define MK_GROUP 130
+#endif
 
 // TS = tile side handled by one workgroup (128 or 64); NT = threads.  One staged operand tile is
 // TS x 16 doubles = 8*TS 16-byte chunks whatever its orientation.
@@ -76,12 +83,12 @@ __device__ __forceinline__ void stage_direct_mk(const double* __restrict__ base,
         const int q = wave * GROUPS + i;
         __builtin_amdgcn_global_load_lds(
             (const __attribute__((address_space(1))) void*)(base + (mrow0 + q * 8 + r8) * ld + kcol0 + c8 * 2),
-            (__attribute__((address_space(3))) void*)(lds + q * 128), 16, 0, 0);
+            (__attribute__((address_space(3))) void*)(lds + q * MK_GROUP), 16, 0, 0);
     }
 }
 __device__ __forceinline__ double frag_mk_swz(const double* lds, int m0, int kk, int lane) {
     const int m = m0 + (lane & 15), k = kk * 4 + (lane >> 4);
-    return lds[(m >> 3) * 128 + ((m & 7) * 8 + ((k >> 1) ^ (m & 7))) * 2 + (k & 1)];
+    return lds[(m >> 3) * MK_GROUP + ((m & 7) * 8 + ((k >> 1) ^ (m & 7))) * 2 + (k & 1)];
 }
 
 template <bool KM, int NW, int TS>
