@@ -65,9 +65,20 @@ __device__ __forceinline__ double pick4(double v0, double v1, double v2, double 
 // A[l&15][4g + (l>>4)], so register g *is* the 16x4 column panel g in f64 16x16x4 operand layout.
 // Per panel: the 4x4 diagonal block is factored and inverted in wave-uniform scalars (10 readlanes),
 // one MFMA forms the panel  L_p^T = W A_p^T  (W = L4^-1) and one MFMA applies  A -= L_p L_p^T.
-__device__ __forceinline__ int chol16(double* D, double* invd_out, int lane) {
+//
+// xinv (optional): the inverse X = L16^-1 as a by-product, in accumulator layout X[(lane>>4) + 4g][lane & 15] (what
+// trinv16_regs returns).  The same block elimination applied to the identity: with Y = I, per 4-column panel
+// X[rows of the panel] = W Y[rows of the panel] and Y -= L_p X[rows of the panel] -- two more MFMAs per panel that are
+// independent of the factorisation's own dependency chain (they issue in the shadow of the next panel's scalar work).
+__device__ __forceinline__ int chol16(double* D, double* invd_out, int lane, d4* xinv = nullptr) {
     const int r = lane & 15, kq = lane >> 4, p = r & 3;
     d4 acc, Lf;
+    d4 yacc, Xf;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        yacc[g] = ((kq + 4 * g) == r) ? 1.0 : 0.0;
+        Xf[g] = 0.0;
+    }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const int c = kq + 4 * g;
@@ -107,7 +118,11 @@ __device__ __forceinline__ int chol16(double* D, double* invd_out, int lane) {
         // operand A of the panel MFMA: rows m = r < 4 of W, column k = kq
         const double wsel = pick4(pick4(i0, w10, w20, w30, p), pick4(0.0, i1, w21, w31, p),
                                   pick4(0.0, 0.0, i2, w32, p), (p == 3) ? i3 : 0.0, kq);
-        const d4 res = __builtin_amdgcn_mfma_f64_16x16x4f64((r < 4) ? wsel : 0.0, P, (d4){0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
+        const double wop = (r < 4) ? wsel : 0.0;
+        const d4 res = __builtin_amdgcn_mfma_f64_16x16x4f64(wop, P, (d4){0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
+        // (issued next to `res`, which it does not depend on: both are in flight while the panel is assembled)
+        d4 xr = (d4){0.0, 0.0, 0.0, 0.0};
+        if (xinv) xr = __builtin_amdgcn_mfma_f64_16x16x4f64(wop, yacc[jb], (d4){0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
         // rows of the diagonal block take the scalar factor itself; rows above it are zero
         const double lsel = pick4(pick4(l00, l10, l20, l30, p), pick4(0.0, l11, l21, l31, p),
                                   pick4(0.0, 0.0, l22, l32, p), (p == 3) ? l33 : 0.0, kq);
@@ -116,6 +131,10 @@ __device__ __forceinline__ int chol16(double* D, double* invd_out, int lane) {
         Lp = ((r >> 2) < jb) ? 0.0 : Lp;
         Lf[jb] = Lp;
         if (jb < 3) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Lp, Lp, acc, 0, 0, 0);
+        if (xinv) {
+            Xf[jb] = xr[0];
+            if (jb < 3) yacc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Lp, xr[0], yacc, 0, 0, 0);
+        }
         if (lane == 0) {
             invd_out[b0] = i0;
             invd_out[b0 + 1] = i1;
@@ -128,7 +147,15 @@ __device__ __forceinline__ int chol16(double* D, double* invd_out, int lane) {
         const int c = 4 * jb + kq;
         if (c <= r) D[r * LDD + c] = Lf[jb];
     }
+    if (xinv) *xinv = Xf;
     return bad;
+}
+
+// row-major copy of a 16x16 tile held in accumulator layout (scratch tile of lds_factor_inv: the layout converter
+// between "accumulator" and "operand" order)
+__device__ __forceinline__ void xs_write(double* Xs, d4 x, int lane) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) Xs[((lane >> 4) + 4 * g) * 18 + (lane & 15)] = x[g];
 }
 
 // Inverse of a 16x16 lower-triangular block by one full wave: X = L^-1 written as a full tile
@@ -231,7 +258,7 @@ __device__ __forceinline__ void tile_write(double* C, d4 v, int lane) {
 // double either way).
 template <typename R>
 __device__ __forceinline__ void load_block_chol0(double* D, double* invd, int* s_bad,
-                                                 const R* __restrict__ Ablk, int64_t ld, int tid) {
+                                                 const R* __restrict__ Ablk, int64_t ld, int tid, double* Xs) {
     typedef R RV2 __attribute__((ext_vector_type(2)));
     d2 r[16];
 #pragma unroll
@@ -247,7 +274,9 @@ __device__ __forceinline__ void load_block_chol0(double* D, double* invd, int* s
     }
     __syncthreads();
     if (tid < 64) {
-        const int bad = chol16(D, invd, tid);
+        d4 x0;
+        const int bad = chol16(D, invd, tid, &x0);
+        xs_write(Xs, x0, tid);
         if (tid == 0 && bad && *s_bad == 0) *s_bad = bad;
     }
 #pragma unroll
@@ -261,90 +290,101 @@ __device__ __forceinline__ void load_block_chol0(double* D, double* invd, int* s
 
 // Cholesky AND inverse of the leading npan*16 rows/cols of the block in D, in place: on return D holds
 // X = L^-1 (lower; the diagonal 16x16 tiles with zeros above the diagonal), invd[j] = 1/L_jj.
-// Right-looking factorisation in 16-column panels: the 16x16 register Cholesky of the next diagonal
-// tile is the serial part and is overlapped with the trailing update (wave 0 updates tile (p+1,p+1)
-// first and goes straight on to factor it while the other waves update the rest); substitution
-// panel solve, one thread per row.  The inverse is built block row by block row in the shadow of
-// the factorisation instead of afterwards:
+// Right-looking factorisation in 16-column panels.  The serial part is wave 0: own tile update -> 16x16 register
+// Cholesky of the next diagonal tile (chol16, which also yields that tile's INVERSE) -- overlapped with the trailing
+// update by the other waves.  The panel solve of the rows below a diagonal tile is a product with that inverse, one
+// 16x16 tile per wave on MFMA (4 dependent MFMAs: ~0.6K cycles; the substitution it replaces, one thread per row, was
+// 2.5K cycles of wave 0's 8.8K per panel).  The inverse of the whole block is built block row by block row in the
+// shadow of the factorisation instead of afterwards:
 //   X(i,i) = L(i,i)^-1,   X(i,j) = -X(i,i) * sum_{k=j}^{i-1} L(i,k) X(k,j)      (j < i)
 // Block row i of L is final once step i-1 is over.  During step i
-//   panel-solve phase : wave 4 inverts L(i,i) (registers + the Xs scratch tile); the five worker waves first
-//                       store block row i-1 of X (held in registers since the previous step) over
-//                       L(i-1,.), then sink(i, t) lets them export block row i of L;
+//   panel-solve phase : every wave but wave 4 solves one tile below the diagonal tile; wave 4 stores X(i-1,i-1)
+//                       (from the scratch tile) over L(i-1,i-1); the five worker waves store block row i-1 of
+//                       X (held in registers since the previous step) over L(i-1,.); sink(i, t) lets all
+//                       512 threads export block row i of L;
 //   update phase      : next to their trailing tiles, the workers form T(i,j) = sum_k L(i,k) X(k,j) on
 //                       MFMA and multiply by -X(i,i) (T is already in B-operand layout); the results
 //                       stay in registers until the next step so that no wave overwrites an L(i,k)
 //                       another one still reads.  The row-inverse work grows as the trailing
 //                       update shrinks, and both hide behind wave 0's 16x16 factorisation.
-// Waves 0/1 (panel solve, next diagonal factorisation = the critical path) are not touched.
+// Xs: TWO scratch tiles (2 x 16 x XS_LD doubles): the inverse of diagonal tile i lives in Xs + (i & 1) * 16 * XS_LD,
+// row-major, from the end of step i-1 to the panel-solve phase of step i+1.
+#ifdef POTF2_PROFILE
+__device__ long long g_fprof[128];       // tools/potf2_prof.hip: wave 0's clock at the marks below, 8 per 16-column step
+#define FSTAMP(i) do { if (threadIdx.x == 0) g_fprof[i] = clock64(); } while (0)
+#else
+#define FSTAMP(i) do { } while (0)
+#endif
 #define XS_LD 18
-#define SINK_THREADS 320      // sink(i, t) is called by the five worker waves: t = 0..319
+#define SINK_THREADS 512      // sink(i, t) is called by every thread of the workgroup: t = 0..511
 // FIRST_DONE: the caller has already factored the first diagonal tile (load_block_chol0).
 template <typename Sink, bool FIRST_DONE = false>
 __device__ __forceinline__ void lds_factor_inv(double* D, double* invd, double* Xs, int npan, int* s_bad, int tid,
                                                Sink sink) {
     const int lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, kq = lane >> 4;
-    const int ns = npan * 16;
     const d4 zero = (d4){0.0, 0.0, 0.0, 0.0};
-    // row-inverse workers: waves 2, 3, 5, 6, 7; the diagonal inverses go to wave 4, which shares its
-    // SIMD with wave 0 -- busy there only while wave 0 runs the (MFMA-free) panel solve
+    // row-inverse workers: waves 2, 3, 5, 6, 7; wave 4 moves finished diagonal inverses into D
     const int widx = (wave >= 5) ? wave - 3 : wave - 2;      // 0..4 for the workers
     const bool worker = wave >= 2 && wave != 4;
+    const int slot = (wave < 4) ? wave : wave - 1;           // panel-solve tile of this wave (wave 4 has none)
+    const int widx7 = worker ? widx : 5 + wave;             // last step: waves 2,3,5,6,7,0,1 -> 0..6
     if (!FIRST_DONE) {
         if (wave == 0) {
-            const int bad = chol16(D, invd, lane);
+            d4 x0;
+            const int bad = chol16(D, invd, lane, &x0);
+            xs_write(Xs, x0, lane);
             if (lane == 0 && bad && *s_bad == 0) *s_bad = bad;
         }
         __syncthreads();
     }
-    d4 xd = zero, keep[2] = {zero, zero};       // block row p-1 of X, carried into step p
+    d4 keep[2] = {zero, zero};       // block row p-1 of X, carried into step p
     for (int p = 0; p <= npan; ++p) {
         const int c0 = p * 16;
-        if (wave < 2) {
-            // panel solve, one thread per row below the diagonal tile: x L16^T = a
-            const int row = c0 + 16 + tid;
-            if (row < ns) {
-                double x[16];
-                double* px = D + row * LDD + c0;
+        const double* Xp = Xs + (p & 1) * 16 * XS_LD;       // inverse of diagonal tile p
+        FSTAMP(8 * p + 0);
+        if (wave != 4) {
+            // panel solve of tile (p + 1 + slot, p):  S = A X_p^T
+            const int t = p + 1 + slot;
+            if (p < npan && t < npan) {
+                double* C = D + t * 16 * LDD + c0;
+                d4 acc = zero;
 #pragma unroll
-                for (int c = 0; c < 16; c += 2) {
-                    const d2 v = *reinterpret_cast<const d2*>(px + c);
-                    x[c] = v[0];
-                    x[c + 1] = v[1];
-                }
-                const double* Lp = D + c0 * LDD + c0;
-#pragma unroll
-                for (int c = 0; c < 16; ++c) {
-                    double sacc = x[c];
-#pragma unroll
-                    for (int k = 0; k < c; ++k) sacc = fma(-x[k], Lp[c * LDD + k], sacc);
-                    x[c] = sacc * invd[c0 + c];
-                }
-#pragma unroll
-                for (int c = 0; c < 16; c += 2) *reinterpret_cast<d2*>(px + c) = (d2){x[c], x[c + 1]};
+                for (int sft = 0; sft < 16; sft += 4)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(C[r * LDD + sft + kq], Xp[r * XS_LD + sft + kq], acc, 0, 0, 0);
+                tile_write(C, acc, lane);
             }
-        } else if (wave == 4) {
-            if (p > 0) tile_write(D + (c0 - 16) * LDD + (c0 - 16), xd, lane);
-            if (p < npan) {
-                xd = trinv16_regs(D + c0 * LDD + c0, LDD, invd + c0, lane);
+            // block row p-1 of X, held in registers since the previous step (by seven waves if that was the last one)
+            if ((p == npan) ? true : worker) {
+                const int hw = (p == npan) ? widx7 : widx, hs = (p == npan) ? 7 : 5;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) Xs[(kq + 4 * g) * XS_LD + r] = xd[g];
+                for (int cnt = 0; cnt < 2; ++cnt) {
+                    const int j = hw + hs * cnt;
+                    if (j < p - 1) tile_write(D + (c0 - 16) * LDD + j * 16, keep[cnt], lane);
+                }
             }
         } else {
+            if (p > 0) {
+                const double* Xq = Xs + ((p - 1) & 1) * 16 * XS_LD;
+                d4 xd;
 #pragma unroll
-            for (int cnt = 0; cnt < 2; ++cnt) {
-                const int j = widx + 5 * cnt;
-                if (j < p - 1) tile_write(D + (c0 - 16) * LDD + j * 16, keep[cnt], lane);
+                for (int g = 0; g < 4; ++g) xd[g] = Xq[(kq + 4 * g) * XS_LD + r];
+                tile_write(D + (c0 - 16) * LDD + (c0 - 16), xd, lane);
             }
-            if (p < npan) sink(p, widx * 64 + lane);
         }
+        if (p < npan) sink(p, tid);
+        FSTAMP(8 * p + 1);
         __syncthreads();
+        FSTAMP(8 * p + 2);
         if (p == npan) break;
-        if (worker) {
+        // row p of the inverse: the five workers, two tiles each -- or, in the LAST step (no 16x16 factorisation left
+        // to hide behind), seven waves with one tile each
+        const bool lastp = (p == npan - 1);
+        if (lastp ? (wave != 4) : worker) {
+            const int ww = lastp ? widx7 : widx, ws = lastp ? 7 : 5;
 #pragma unroll
             for (int cnt = 0; cnt < 2; ++cnt) {
-                const int j = widx + 5 * cnt;
+                const int j = ww + ws * cnt;
                 if (j >= p) continue;
                 d4 t = zero;
                 for (int k = j; k < p; ++k)
@@ -357,7 +397,7 @@ __device__ __forceinline__ void lds_factor_inv(double* D, double* invd, double* 
                 d4 x = zero;
 #pragma unroll
                 for (int sft = 0; sft < 4; ++sft)
-                    x = __builtin_amdgcn_mfma_f64_16x16x4f64(-Xs[r * XS_LD + 4 * sft + kq], t[sft], x, 0, 0, 0);
+                    x = __builtin_amdgcn_mfma_f64_16x16x4f64(-Xp[r * XS_LD + 4 * sft + kq], t[sft], x, 0, 0, 0);
                 keep[cnt] = x;
             }
         }
@@ -365,7 +405,18 @@ __device__ __forceinline__ void lds_factor_inv(double* D, double* invd, double* 
         const int m = npan - 1 - p;
         const int ntile = m * (m + 1) / 2;
         const int nworkers = NTH / 64 - 1;
-        for (int q = (wave == 0) ? 0 : wave; q < ntile; q += (wave == 0) ? ntile : nworkers) {
+        if (wave == 0 && ntile > 0) {
+            // the tile the next 16x16 factorisation waits for: two accumulation chains instead of four dependent MFMAs
+            double* C = D + (c0 + 16) * LDD + c0 + 16;
+            d4 acc = tile_read(C, lane), acc2 = zero;
+            const double* Pr = D + (c0 + 16 + r) * LDD + c0 + kq;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Pr[0], Pr[0], acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-Pr[4], Pr[4], acc2, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Pr[8], Pr[8], acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-Pr[12], Pr[12], acc2, 0, 0, 0);
+            tile_write(C, acc + acc2, lane);
+        }
+        for (int q = (wave == 0) ? ntile : wave; q < ntile; q += nworkers) {
             int i = (int)((sqrtf(8.0f * q + 1.0f) - 1.0f) * 0.5f);
             while (i * (i + 1) / 2 > q) --i;
             while ((i + 1) * (i + 2) / 2 <= q) ++i;
@@ -381,11 +432,16 @@ __device__ __forceinline__ void lds_factor_inv(double* D, double* invd, double* 
             }
             tile_write(C, acc, lane);
         }
+        FSTAMP(8 * p + 3);
         if (wave == 0 && p + 1 < npan) {
             const int c1 = c0 + 16;
-            const int bad = chol16(D + c1 * LDD + c1, invd + c1, lane);
+            d4 xn;
+            const int bad = chol16(D + c1 * LDD + c1, invd + c1, lane, &xn);
+            xs_write(Xs + ((p + 1) & 1) * 16 * XS_LD, xn, lane);
             if (lane == 0 && bad && *s_bad == 0) *s_bad = c1 + bad;
         }
+        FSTAMP(8 * p + 4);
         __syncthreads();
+        FSTAMP(8 * p + 5);
     }
 }

@@ -18,7 +18,7 @@
 // S = P * Dinv^T of the panel solve (cholstep.hip): dinvB[t][s2][lane][e] = Dinv[16 t + (lane & 15)][8 s2 + 4 e + (lane >> 4)],
 // so that a wave fetches the fragments of two k-steps of one 16-column tile with ONE coalesced 16-byte load per lane.
 // smem: POTF2_SMEM_DOUBLES doubles of LDS.
-#define POTF2_SMEM_DOUBLES (NB * LDD + NB + 16 * XS_LD + 4)
+#define POTF2_SMEM_DOUBLES (NB * LDD + NB + 32 * XS_LD + 4)
 template <typename R>
 __device__ __forceinline__ void potf2_body(double* __restrict__ smem, const int by, R* __restrict__ A, int64_t ld, int kblk,
                                            R* __restrict__ dinv_all, double* __restrict__ dinvB_all,
@@ -27,7 +27,7 @@ __device__ __forceinline__ void potf2_body(double* __restrict__ smem, const int 
     double* D = smem;
     double* invd = D + NB * LDD;
     double* Xs = invd + NB;
-    double* red = Xs + 16 * XS_LD;
+    double* red = Xs + 32 * XS_LD;
     int& s_bad = *reinterpret_cast<int*>(red + 2);
     A += (int64_t)by * nb * NB * ld;
     dinv_all += (int64_t)by * nb * NB * NB;
@@ -38,7 +38,7 @@ __device__ __forceinline__ void potf2_body(double* __restrict__ smem, const int 
     if (tid == 0) s_bad = 0;
     __syncthreads();
     STAMP(0);
-    load_block_chol0(D, invd, &s_bad, Ablk, ld, tid);
+    load_block_chol0(D, invd, &s_bad, Ablk, ld, tid, Xs);
     STAMP(1);
     // factor and invert in one sweep; block row i of L goes back to HBM (zeros above the diagonal)
     // during step i, just before the inverse overwrites it in LDS

@@ -8,7 +8,7 @@
 __global__ __launch_bounds__(NTH, 1) void k(const double* A, double* Lout, double* Xout, int npan, long long* cyc) {
     __shared__ __attribute__((aligned(16))) double D[NB * LDD];
     __shared__ double invd[NB];
-    __shared__ double Xs[16 * XS_LD];
+    __shared__ double Xs[32 * XS_LD];
     __shared__ int s_bad;
     const int tid = threadIdx.x;
     const int ns = npan * 16;

@@ -23,6 +23,14 @@ int main() {
         printf("rep %d: %.1f us total; cycles: load %lld | factor %lld | write L + logdet %lld | inverse %lld | write inverse %lld | all %lld\n",
                rep, ms * 1e3, hp[1] - hp[0], hp[2] - hp[1], hp[3] - hp[2], hp[4] - hp[3], hp[5] - hp[4], hp[5] - hp[0]);
     }
+    {
+        long long fp[128];
+        hipMemcpyFromSymbol(fp, HIP_SYMBOL(g_fprof), sizeof(fp));
+        printf("wave 0 inside lds_factor_inv, cycles per 16-column step: [panel solve | wait | own tile update | chol16 of the next tile | wait]\n");
+        for (int p = 0; p < 8; ++p)
+            printf("  step %d: %5lld | %5lld | %5lld | %5lld | %5lld   (step total %lld)\n", p, fp[8 * p + 1] - fp[8 * p], fp[8 * p + 2] - fp[8 * p + 1],
+                   fp[8 * p + 3] - fp[8 * p + 2], fp[8 * p + 4] - fp[8 * p + 3], fp[8 * p + 5] - fp[8 * p + 4], fp[8 * p + 5] - fp[8 * p]);
+    }
     std::vector<double> L(n * n);
     hipMemcpy(L.data(), dA, n * n * 8, hipMemcpyDeviceToHost);
     // residual check L L^T - A
