@@ -69,7 +69,9 @@ __device__ __forceinline__ double pick4(double v0, double v1, double v2, double 
 // xinv (optional): the inverse X = L16^-1 as a by-product, in accumulator layout X[(lane>>4) + 4g][lane & 15] (what
 // trinv16_regs returns).  The same block elimination applied to the identity: with Y = I, per 4-column panel
 // X[rows of the panel] = W Y[rows of the panel] and Y -= L_p X[rows of the panel] -- two more MFMAs per panel that are
-// independent of the factorisation's own dependency chain (they issue in the shadow of the next panel's scalar work).
+// independent of the factorisation's own dependency chain.  Cost, one wave alone (tools/chol16_var.hip): 4.43K cycles
+// without, 5.23K with the inverse (fp64 MFMAs and the wave's fp64 scalar chains share the SIMD's fp64 unit); handing
+// the two operands per panel to a helper wave through LDS behind a flag instead measured 5.60K -- not kept.
 __device__ __forceinline__ int chol16(double* D, double* invd_out, int lane, d4* xinv = nullptr) {
     const int r = lane & 15, kq = lane >> 4, p = r & 3;
     d4 acc, Lf;
@@ -416,7 +418,9 @@ __device__ __forceinline__ void lds_factor_inv(double* D, double* invd, double* 
             acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-Pr[12], Pr[12], acc2, 0, 0, 0);
             tile_write(C, acc + acc2, lane);
         }
-        for (int q = (wave == 0) ? ntile : wave; q < ntile; q += nworkers) {
+        // (wave 4 shares its SIMD with wave 0, whose 16x16 factorisation is the critical path: it takes no tiles)
+        const int widx6 = (wave < 4) ? wave - 1 : wave - 2;
+        for (int q = (wave == 0 || wave == 4) ? ntile : 1 + widx6; q < ntile; q += nworkers - 1) {
             int i = (int)((sqrtf(8.0f * q + 1.0f) - 1.0f) * 0.5f);
             while (i * (i + 1) / 2 > q) --i;
             while ((i + 1) * (i + 2) / 2 <= q) ++i;
