@@ -227,12 +227,10 @@ int launch_predict_fused(gpimhip_ctx* h, const gpimhip_model_t* m, const double*
     const dim3 grid((unsigned)((M + PF_CT - 1) / PF_CT), h->nbatch);
 #define PF_LAUNCH(KIND)                                                                                            \
     do {                                                                                                           \
-        static bool attr_set = false;                                                                              \
-        if (!attr_set) {                                                                                           \
-            HIP_TRY(hipFuncSetAttribute((const void*)predict_fused_kernel<KIND>,                                   \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                  \
-            attr_set = true;                                                                                       \
-        }                                                                                                          \
+        /* once per process and kernel; several host threads may predict at the same time (dist.reconstruct_slices) */ \
+        static const hipError_t attr_rc = hipFuncSetAttribute((const void*)predict_fused_kernel<KIND>,             \
+                                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        HIP_TRY(attr_rc);                                                                                          \
         hipLaunchKernelGGL(predict_fused_kernel<KIND>, grid, dim3(256), lds, h->stream, a);                        \
     } while (0)
     if (m->kernel == GPIMHIP_KERNEL_RBF) PF_LAUNCH(GPIMHIP_KERNEL_RBF);
