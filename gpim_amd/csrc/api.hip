@@ -5,6 +5,7 @@
 #include <string.h>
 #include <stdlib.h>
 #include <algorithm>
+#include <chrono>
 #include <mutex>
 #include "common.hpp"
 
@@ -398,7 +399,7 @@ static GemmArgs gemm_args(const double* A, int64_t lda, const double* B, int64_t
 // cross-stream dependency is an event of the handle that recorded it).  Handles that only ever run the fused
 // small-N trainer use none.
 struct SideStreams {
-    hipStream_t panel = nullptr, bulk = nullptr, capture = nullptr;
+    hipStream_t panel = nullptr, bulk = nullptr, capture = nullptr, chain = nullptr;
     bool lookahead_tried = false, capture_tried = false;
 };
 static std::mutex g_side_mutex;
@@ -414,6 +415,19 @@ static void ensure_lookahead_streams(gpimhip_ctx* h) {
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // hi = numerically lowest = highest priority
         if (hipStreamCreateWithPriority(&S.panel, hipStreamNonBlocking, hi) != hipSuccess) S.panel = nullptr;
+        // The stream that DRIVES the large-N factorisation and triangular inverse (factor_at_u hops onto it and back).
+        // These two stages are chains of hundreds of short dependent launches, and how fast the runtime lets such a
+        // chain run on the CALLER's stream depends on the stream population of the whole process: after a mid-size fit
+        // and the first use of a few more streams (torch's pool; dist.reconstruct_slices' concurrent batches), every
+        // launch boundary on the default stream and on torch's normal-priority streams cost ~14 us instead of ~1 us
+        // for the rest of the process (N = 16384: Cholesky 29.0 -> 44.9 ms, iteration 74.6 -> 92.4 ms; float engine
+        // 43.5 -> 57.0 ms), also after those streams were destroyed, also on a stream with a queue of its own
+        // (CU mask), not with GPU_MAX_HW_QUEUES = 8 as long as the process stays below that many streams (which in
+        // turn slows the concurrent batches of config C3 by 23 %).  A HIGH-PRIORITY driving stream was unaffected in
+        // every situation measured (tools/r3_single_ctx.py: 75.0 - 75.2 / 44.1 - 44.2 ms in all of them; DESIGN
+        // section 6).  The mechanism inside the runtime is not known to us: this is an empirical remedy, and
+        // GPIMHIP_NO_CHAIN_STREAM=1 switches it off.
+        if (hipStreamCreateWithPriority(&S.chain, hipStreamNonBlocking, hi) != hipSuccess) S.chain = nullptr;
         // The bulk trailing updates run on a stream whose CU mask leaves RESERVED_CUS compute units
         // free (the mask is interleaved over the XCDs: 16 reserved = 2 per XCD, tools/cumask_probe.hip):
         // potf2 needs ~135 KB of LDS, i.e. a whole CU, and would otherwise wait until the bulk kernel
@@ -430,6 +444,7 @@ static void ensure_lookahead_streams(gpimhip_ctx* h) {
     }
     h->panel_stream = S.panel;                       // null: fall back to the in-order schedule
     h->bulk_stream = S.bulk;
+    h->chain_stream = S.chain;                       // null: the caller's stream drives every stage
 }
 // The capture stream is shared by every handle of a device: two threads fitting at the same time must not
 // interleave their Begin..EndCapture sections on it (the second BeginCapture would fail and that fit would
@@ -676,8 +691,37 @@ static int factor_at_u(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X
     const int64_t np = h->np, ld = h->ld;
     GP_TRY(launch_theta(h, m, u));
     GP_TRY(launch_kmat(h, m, X, N, nullptr, N, h->theta, 0.0, 1, h->A, ld, np, np, 1, 1, x_bs, x_bs, np * ld));
-    { StageTimer t(h, 0); GP_TRY(launch_potrf(h, h->A, np, ld, h->info)); }
-    { StageTimer t(h, 1); GP_TRY(launch_trtri(h, h->A, h->Tm, np, ld)); }
+    // Large N, eager launches: the two launch-chain stages run on the engine's high-priority chain stream (see
+    // ensure_lookahead_streams), two event hops per call; everything else stays on the caller's stream, below the
+    // priority of the side branch that hides the mat-vecs behind the K^-1 product.
+    hipStream_t caller_s = h->stream;
+    bool hop = false;
+    if (!h->capturing && (int)((np / NB + OUTER_W - 1) / OUTER_W) >= LOOKAHEAD_MIN_PANELS &&
+        !getenv("GPIMHIP_NO_CHAIN_STREAM")) {
+        ensure_lookahead_streams(h);
+        if (h->chain_stream) {
+            for (auto& e : h->ev_chain)
+                if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            hop = true;
+        }
+    }
+    if (hop) {
+        HIP_TRY(hipEventRecord(h->ev_chain[0], caller_s));
+        HIP_TRY(hipStreamWaitEvent(h->chain_stream, h->ev_chain[0], 0));
+        h->stream = h->chain_stream;
+    }
+    int rc = GPIMHIP_OK;
+    { StageTimer t(h, 0); rc = launch_potrf(h, h->A, np, ld, h->info); }
+    if (rc == GPIMHIP_OK) { StageTimer t(h, 1); rc = launch_trtri(h, h->A, h->Tm, np, ld); }
+    if (hop) {
+        // joined on every path: after a failed launch the caller's stream (the one a handle synchronises before it
+        // frees anything) must still be behind whatever the chain stream was given
+        h->stream = caller_s;
+        hipError_t je = hipEventRecord(h->ev_chain[1], h->chain_stream);
+        if (je == hipSuccess) je = hipStreamWaitEvent(caller_s, h->ev_chain[1], 0);
+        if (rc == GPIMHIP_OK) HIP_TRY(je);
+    }
+    GP_TRY(rc);
     if (!defer_vectors) GP_TRY(solve_vectors(h, m, X, x_bs, N));
     return GPIMHIP_OK;
 }
@@ -690,27 +734,35 @@ static int loss_grad_at_u(gpimhip_ctx* h, const gpimhip_model_t* m, const double
     const int64_t np = h->np;
     // In the look-ahead regime the panel stream exists and is idle after the factorisation: the two
     // HBM-bound mat-vecs over L^-1 run there, next to the MFMA-bound K^-1 product (both only read L^-1).
+    // While an iteration is being CAPTURED (fit_impl, large N) the branch goes to the handle's own fork stream: the
+    // panel stream is shared by every handle of the device and may be running another handle's eager work, which a
+    // capture on it would swallow.  fit_impl creates the fork stream and the events before the capture begins.
     bool side = (int)((np / NB + OUTER_W - 1) / OUTER_W) >= LOOKAHEAD_MIN_PANELS;
-    if (side) {
+    hipStream_t side_s = nullptr;
+    if (side && h->capturing) {
+        side_s = h->fork_stream;
+        side = side_s != nullptr && h->ev_pool.size() >= 2;
+    } else if (side) {
         ensure_lookahead_streams(h);
         while (h->ev_pool.size() < 2) {
             hipEvent_t e;
             HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             h->ev_pool.push_back(e);
         }
-        side = h->panel_stream != nullptr;
+        side_s = h->panel_stream;
+        side = side_s != nullptr;
     }
     GP_TRY(factor_at_u(h, m, X, x_bs, N, u, side));
     if (side) {
         hipStream_t main_s = h->stream;
         hipEvent_t ev_in = h->ev_pool[0], ev_out = h->ev_pool[1];    // free again once launch_potrf has joined
         HIP_TRY(hipEventRecord(ev_in, main_s));
-        HIP_TRY(hipStreamWaitEvent(h->panel_stream, ev_in, 0));
-        h->stream = h->panel_stream;
+        HIP_TRY(hipStreamWaitEvent(side_s, ev_in, 0));
+        h->stream = side_s;
         const int rc = solve_vectors(h, m, X, x_bs, N);
         h->stream = main_s;
         GP_TRY(rc);
-        HIP_TRY(hipEventRecord(ev_out, h->panel_stream));
+        HIP_TRY(hipEventRecord(ev_out, side_s));
         { StageTimer t(h, 2); GP_TRY(launch_lauum(h, h->A, h->B, np, h->ld)); }
         HIP_TRY(hipStreamWaitEvent(main_s, ev_out, 0));
     } else {
@@ -816,6 +868,7 @@ int gpimhip_shutdown(void) {
         if (S.panel) (void)hipStreamDestroy(S.panel);
         if (S.bulk) (void)hipStreamDestroy(S.bulk);
         if (S.capture) (void)hipStreamDestroy(S.capture);
+        if (S.chain) (void)hipStreamDestroy(S.chain);
         S = SideStreams();
     }
     return GPIMHIP_OK;
@@ -872,7 +925,10 @@ int gpimhip_destroy(gpimhip_handle h) {
     for (auto e : h->ra_ev)
         if (e) (void)hipEventDestroy(e);
     if (h->pinned_info) (void)hipHostFree(h->pinned_info);
-    // the side streams belong to the process (ensure_lookahead_streams), not to the handle
+    if (h->fork_stream) (void)hipStreamDestroy(h->fork_stream);
+    for (auto e : h->ev_chain)
+        if (e) (void)hipEventDestroy(e);
+    // the other side streams belong to the process (ensure_lookahead_streams), not to the handle
     delete h;
     return GPIMHIP_OK;
 }
@@ -970,27 +1026,69 @@ static int fit_impl(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X, i
     st.beta1 = 0.9; st.beta2 = 0.999; st.eps = 1e-8; st.lr_over_bc1 = 0.0; st.bc2_sqrt = 1.0;
     // Every iteration enqueues the same launches (the iteration index lives on the device), so one
     // iteration is captured into a hipGraph and replayed: ~10 us of host work per iteration instead
-    // of one launch call per kernel.  Not used with the multi-stream look-ahead schedule (large N,
-    // where launch cost is irrelevant), while stage timing is on, or for very short fits.
+    // of one launch call per kernel.  Not used while stage timing is on or for very short fits.
+    // Large N (the look-ahead regime): the launch cost itself no longer matters, but a replayed graph also makes the
+    // ~600 dependent launches of an iteration independent of how the HIP runtime maps the caller's stream onto its
+    // hardware queues -- with the runtime's default of 4 queues per device, a process that holds a few more streams
+    // than that made every launch boundary of the eagerly enqueued chain ~14 us instead of ~1 us (Cholesky at
+    // N = 16384: 29 -> 45 ms; tools/r3_single_ctx.py), while replayed iterations were unaffected.
+    // Only the step schedule (one in-order stream) can be captured there: the float engine's look-ahead schedule lives
+    // on a priority stream and a CU-masked stream, which a graph does not preserve.
+    // OPT-IN (GPIMHIP_GRAPH_LARGE=1), not the default: same bits as the eager iteration (tools/r3_graph_large_check.py),
+    // and in the shared-queue situation it restores the speed (N = 16384: 92.4 -> 74.8 ms per iteration), but the side
+    // branch (the mat-vecs over L^-1 beside the K^-1 product) loses its priority stream inside a graph and whether it
+    // still overlaps is up to the runtime's queue mapping: on a warm handle in a clean process the replayed iteration
+    // measured 7.19 / 19.98 / 45.3 / 89.0 ms at N = 6200 / 8192 / 12288 / 16384 against 7.15 / 12.96 / 34.5 / 74.3 eager
+    // (tools/r3_graph_large_cost.py).  The remedy that costs nothing is more hardware queues: GPU_MAX_HW_QUEUES=8,
+    // which the Python package asks for at import (gpim_amd/__init__.py) and INTEGRATION.md tells other hosts to set.
     const int npanel = (int)((h->np / NB + OUTER_W - 1) / OUTER_W);
-    bool use_graph = T >= 8 && !h->timing && npanel < LOOKAHEAD_MIN_PANELS && ensure_capture_stream(h) &&
-                     !getenv("GPIMHIP_NO_GRAPH");
+    const bool large = npanel >= LOOKAHEAD_MIN_PANELS;
+    const char* gl = getenv("GPIMHIP_GRAPH_LARGE");
+    bool use_graph = T >= 8 && !h->timing && !getenv("GPIMHIP_NO_GRAPH") &&
+                     (!large || (use_step_schedule(h, h->np) && gl && atoi(gl) != 0)) &&
+                     ensure_capture_stream(h);
+    if (use_graph && large) {
+        // everything the captured iteration needs is created BEFORE the capture begins
+        if (!h->fork_stream && hipStreamCreateWithFlags(&h->fork_stream, hipStreamNonBlocking) != hipSuccess) {
+            h->fork_stream = nullptr;
+            (void)hipGetLastError();
+        }
+        while (h->ev_pool.size() < 2) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            h->ev_pool.push_back(e);
+        }
+    }
     if (use_graph) {
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;
         hipStream_t main_s = h->stream;
         h->stream = h->capture_stream;
+        const bool gprof = getenv("GPIMHIP_GRAPH_PROFILE") != nullptr;     // host cost of capture / instantiate, to stderr
+        const auto tp0 = std::chrono::steady_clock::now();
         capture_lock(h);
         hipError_t e = hipStreamBeginCapture(h->capture_stream, hipStreamCaptureModeRelaxed);
         int rc = GPIMHIP_OK;
         if (e == hipSuccess) {
+            h->capturing = true;
             rc = loss_grad_at_u(h, m, X, x_bs, N, u, 1, st, nullptr, nullptr, nullptr, &tab);
+            h->capturing = false;
             e = hipStreamEndCapture(h->capture_stream, &graph);
         }
         capture_unlock(h);
         h->stream = main_s;
         if (rc != GPIMHIP_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
-        if (e == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+        const auto tp1 = std::chrono::steady_clock::now();
+        const bool inst_ok = e == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
+        if (gprof) {
+            size_t nn = 0;
+            if (graph) (void)hipGraphGetNodes(graph, nullptr, &nn);
+            const auto tp2 = std::chrono::steady_clock::now();
+            fprintf(stderr, "gpimhip graph: np=%lld nodes=%zu capture %.2f ms instantiate %.2f ms (ok=%d)\n", (long long)h->np, nn,
+                    std::chrono::duration<double, std::milli>(tp1 - tp0).count(),
+                    std::chrono::duration<double, std::milli>(tp2 - tp1).count(), (int)inst_ok);
+        }
+        if (inst_ok) {
             RunAhead ra(h, h->np);
             hipError_t le = hipSuccess;
             for (int t = 0; t < T && le == hipSuccess && !ra.stop(t); ++t) le = hipGraphLaunch(exec, main_s);

@@ -104,6 +104,10 @@ struct gpimhip_ctx {
     hipStream_t capture_stream = nullptr; // internal stream used only to capture one iteration into a hipGraph
     bool side_streams_tried = false, capture_stream_tried = false;   // side streams are created on first use
     hipStream_t bulk_stream = nullptr;    // CU-masked stream for the bulk trailing updates (look-ahead)
+    hipStream_t fork_stream = nullptr;    // this handle's own: the side branch of a CAPTURED large-N iteration (never runs eagerly)
+    hipStream_t chain_stream = nullptr;   // high-priority stream that drives the large-N factorisation and inverse (api.hip)
+    hipEvent_t ev_chain[2] = {nullptr, nullptr};   // hop onto the chain stream and back
+    bool capturing = false;               // fit_impl is recording one iteration into a hipGraph
     std::vector<hipEvent_t> ev_pool;      // cross-stream ordering events (no timing)
     // workspace (sized for np = padded N)
     int64_t np = 0;                 // padded matrix order the buffers are sized for
