@@ -357,3 +357,59 @@ def test_not_pd_freezes_at_failing_iteration(gpim, npts, small, monkeypatch):
     rec._mstruct.jitter = 1e-6
     mean, sd = rec.predict()
     assert np.isfinite(mean).all() and np.isfinite(sd).all()
+
+
+def _large_fit(gpim, N, T, precision, seed=0):
+    """T Adam iterations of gpimhip_fit_exact in the large-N regime on a fresh handle; (history, losses, final u)."""
+    from gpim_amd import _lib
+    from gpim_amd.kernels import KernelSpec
+    dev = torch.device("cuda:0")
+    side = int(np.ceil(np.sqrt(N * 4)))
+    rng = np.random.default_rng(seed)
+    flat = np.sort(rng.choice(side * side, size=N, replace=False))
+    X = np.stack([flat // side, flat % side], 1).astype(np.float64)
+    y = np.sin(X[:, 0] / 7.0) * np.cos(X[:, 1] / 5.0) + 0.05 * rng.standard_normal(N)
+    Xd, yd = torch.from_numpy(X).to(dev), torch.from_numpy(y).to(dev)
+    spec = KernelSpec("Matern52", 2, [[1., 1.], [20., 20.]], jitter=1e-5)
+    u = spec.draw_initial_u(torch.Generator().manual_seed(seed)).to(dev)
+    m = spec.struct()
+    H = _lib.Handle(precision=precision)
+    hist = torch.zeros(T, spec.n_params, dtype=torch.float64, device=dev)
+    loss = torch.zeros(T, dtype=torch.float64, device=dev)
+    _lib.check(H.lib.gpimhip_fit_exact(H.h, ctypes.byref(m), _lib.ptr(Xd), _lib.ptr(yd), N, _lib.ptr(u), 0.1, T,
+                                       _lib.ptr(hist), _lib.ptr(loss)))
+    torch.cuda.synchronize()
+    out = (hist.cpu().numpy().copy(), loss.cpu().numpy().copy(), u.cpu().numpy().copy())
+    H.close()
+    return out
+
+
+@pytest.mark.parametrize("precision", ["double", "single"])
+def test_large_n_chain_stream_same_bits(gpim, precision, monkeypatch):
+    """The large-N factorisation and triangular inverse are driven from the engine's high-priority chain stream
+    (api.hip factor_at_u; two event hops per call) instead of the caller's stream: where the launches are enqueued
+    must not change a bit of the training trajectory.  N = 6200 is just inside the regime (np = 6272, 13 panels of
+    512 columns >= LOOKAHEAD_MIN_PANELS = 12)."""
+    monkeypatch.delenv("GPIMHIP_NO_CHAIN_STREAM", raising=False)
+    monkeypatch.delenv("GPIMHIP_GRAPH_LARGE", raising=False)
+    a = _large_fit(gpim, 6200, 6, precision)
+    monkeypatch.setenv("GPIMHIP_NO_CHAIN_STREAM", "1")
+    b = _large_fit(gpim, 6200, 6, precision)
+    assert np.isfinite(a[0]).all() and np.isfinite(a[1]).all()
+    for x, y_ in zip(a, b):
+        assert np.array_equal(x, y_)
+
+
+def test_large_n_captured_iteration_same_bits(gpim, monkeypatch):
+    """GPIMHIP_GRAPH_LARGE=1 replays one captured iteration of the step schedule at large N too (opt-in; the side
+    branch with the mat-vecs goes to the handle's own fork stream inside the capture): same launches in the same
+    order, so the same bits as the eager iterations, for T >= 8 (shorter fits are never captured)."""
+    monkeypatch.delenv("GPIMHIP_NO_CHAIN_STREAM", raising=False)
+    monkeypatch.delenv("GPIMHIP_GRAPH_LARGE", raising=False)
+    a = _large_fit(gpim, 6200, 9, "double")
+    monkeypatch.setenv("GPIMHIP_GRAPH_LARGE", "1")
+    b = _large_fit(gpim, 6200, 9, "double")
+    c = _large_fit(gpim, 6200, 9, "double")
+    assert np.isfinite(b[0]).all() and np.isfinite(b[1]).all()
+    for x, y_, z in zip(a, b, c):
+        assert np.array_equal(x, y_) and np.array_equal(y_, z)
