@@ -419,7 +419,7 @@ static void ensure_lookahead_streams(gpimhip_ctx* h) {
         // These two stages are chains of hundreds of short dependent launches, and how fast the runtime lets such a
         // chain run on the CALLER's stream depends on the stream population of the whole process: after a mid-size fit
         // and the first use of a few more streams (torch's pool; dist.reconstruct_slices' concurrent batches), every
-        // launch boundary on the default stream and on torch's normal-priority streams cost ~14 us instead of ~1 us
+        // launch on the default stream and on torch's normal-priority streams came ~40 us later than it should
         // for the rest of the process (N = 16384: Cholesky 29.0 -> 44.9 ms, iteration 74.6 -> 92.4 ms; float engine
         // 43.5 -> 57.0 ms), also after those streams were destroyed, also on a stream with a queue of its own
         // (CU mask), not with GPU_MAX_HW_QUEUES = 8 as long as the process stays below that many streams (which in
@@ -1030,7 +1030,7 @@ static int fit_impl(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X, i
     // Large N (the look-ahead regime): the launch cost itself no longer matters, but a replayed graph also makes the
     // ~600 dependent launches of an iteration independent of how the HIP runtime maps the caller's stream onto its
     // hardware queues -- with the runtime's default of 4 queues per device, a process that holds a few more streams
-    // than that made every launch boundary of the eagerly enqueued chain ~14 us instead of ~1 us (Cholesky at
+    // than that delayed every launch of the eagerly enqueued chain by ~40 us (the ~420 launches of the Cholesky at
     // N = 16384: 29 -> 45 ms; tools/r3_single_ctx.py), while replayed iterations were unaffected.
     // Only the step schedule (one in-order stream) can be captured there: the float engine's look-ahead schedule lives
     // on a priority stream and a CU-masked stream, which a graph does not preserve.

@@ -9,7 +9,7 @@ TAG=${1:-r03}
 O=$R/gpurun_out/prof_$TAG
 rm -rf $O; mkdir -p $O
 # 1. kernel stats of the bench command itself (+ the JSON lines with and without the profiler)
-# rocprofv3 died once in 7 runs of the concurrent C3 step (SIGSEGV inside librocprofiler-sdk's queue interceptor, first
+# rocprofv3 died twice in 9 runs of the concurrent C3 step (SIGSEGV inside librocprofiler-sdk's queue interceptor, first
 # submissions of four host threads; profiles/r03_c3_rocprof_crash.txt): a profiled run that leaves no JSON line is
 # repeated (at most 3 attempts) and the failed attempt's log is kept as <name>_profiled.crash<k>.err
 profiled() {  # profiled <name> <bench.py arguments...>
