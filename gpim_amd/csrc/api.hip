@@ -141,7 +141,7 @@ static int ws_ensure_b(gpimhip_ctx* h, int64_t N, int B, int padded, bool matric
                       (rc = dev_alloc(h, &h->B, mat_doubles(h, B * np * ld))) ||
                       (rc = dev_alloc(h, &h->Tm, mat_doubles(h, B * np * ld))))) ||
         (rc = dev_alloc(h, &h->dinv, mat_doubles(h, B * nb * NB * NB))) ||
-        (!h->fp32 && (rc = dev_alloc(h, &h->dinvB, B * nb * NB * NB))) ||
+        (rc = dev_alloc(h, &h->dinvB, B * nb * NB * NB)) ||
         (rc = dev_alloc(h, &h->ypad, B * np)) || (rc = dev_alloc(h, &h->z, B * np)) ||
         (rc = dev_alloc(h, &h->alpha, B * np)) || (rc = dev_alloc(h, &h->logdet_part, B * nb)) ||
         (rc = dev_alloc(h, &h->grad_part, B * nb * (nb + 1) / 2 * 8)) || (rc = dev_alloc(h, &h->theta, (int64_t)B)) ||
@@ -491,10 +491,13 @@ static int panel_steps(gpimhip_ctx* h, double* A, int64_t ld, int32_t* info, int
 // for single-precision ones.  Measured, potrf alone, step schedule vs look-ahead: 0.51 vs 0.66 ms at N = 1280,
 // 1.86 vs 2.72 at 4224, 6.4 vs 7.05 at 8192, 10.2 vs 10.8 at 10240, 15.7 vs 16.1 at 12288, 32.1 vs 32.9 at 16384,
 // 57.9 vs 59.2 at 20480.
+// Single-precision handles run the same schedule since the end of round 3 (cholstep32.hip; GPIMHIP_F32_LOOKAHEAD=1
+// brings their two-stream look-ahead back).
 static bool use_step_schedule(const gpimhip_ctx* h, int64_t np) {
     static const bool off = getenv("GPIMHIP_OLD_POTRF") != nullptr;
     (void)np;
-    return !off && !h->fp32 && h->dinvB != nullptr;
+    if (h->fp32 && getenv("GPIMHIP_F32_LOOKAHEAD")) return false;
+    return !off && h->dinvB != nullptr;
 }
 
 // Hybrid schedule (OFF by default, GPIMHIP_TAIL_BLOCKS > 0 switches it on): the two-stream look-ahead below for the

@@ -274,7 +274,9 @@ static GemmArgs nt_update(double* A, int64_t ld, const TileDesc* tiles, int n, i
 // receive the inverses of the diagonal blocks and the log-determinant partials like the in-order driver of api.hip.
 // blk_off > 0: the trailing sub-matrix that starts at block (blk_off, blk_off) -- a Schur complement the caller has
 // brought up to date with every column left of it (hybrid schedule of api.hip: look-ahead head, step-schedule tail).
+int launch_potrf_steps_f32(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_t* info, int blk_off);   // cholstep32.hip
 int launch_potrf_steps(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_t* info, int blk_off) {
+    if (h->fp32) return launch_potrf_steps_f32(h, A, np, ld, info, blk_off);
     const int nb = (int)(np / NB) - blk_off, W = STEP_W;
     if (blk_off) GP_TRY(step_plan_ensure_tail(h, nb));
     else GP_TRY(step_plan_ensure(h, nb));

@@ -142,8 +142,19 @@ __device__ __forceinline__ R frag(const R* lds, int m0, int kk, int lane) {
 //   (4,  64,  64)  2x2 waves of 32x32 on a quadrant: few tiles, each spread over four CUs
 //   (8,  64, 128)  4x2 waves of 16x64 on a row half: in-place panel solves (a workgroup must own
 //                  whole rows of the tile it overwrites), each tile spread over two CUs
+// LDS elements of one workgroup: two stages of an A and a B operand tile each
+template <typename R, int TSM, int TSN>
+constexpr int gemm_smem_elems_t() {
+    constexpr int TSX = TSM > TSN ? TSM : TSN;
+    constexpr int BK = RT<R>::BK;
+    return 4 * ((TSX * LD_MK_OF(R) > BK * (TSX + 16)) ? TSX * LD_MK_OF(R) : BK * (TSX + 16));
+}
+
+// One workgroup's share of a tile launch as a device function: bx / by = the workgroup's position in the launch
+// (the block index of gemm_tiles_kernel_t; the step kernel of cholstep32.hip hosts tiles next to a factorisation
+// role), smem = gemm_smem_elems_t<R, TSM, TSN>() elements of LDS.
 template <typename R, bool A_KM, bool B_KM, int EPI, int NW, int TSM, int TSN>
-__global__ __launch_bounds__(NW * 64, 2) void gemm_tiles_kernel_t(GemmArgs g) {
+__device__ __forceinline__ void gemm_tile_body_t(GemmArgs g, const int bx, const int by, R* __restrict__ smem) {
     typedef typename RT<R>::CH CH;
     typedef typename RT<R>::ACC ACC;
     constexpr int BK = RT<R>::BK;           // k-depth of one stage
@@ -161,7 +172,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_tiles_kernel_t(GemmArgs g) {
     // m-contiguous k-row, or a float one, is only half a wave-wide load)
     constexpr bool F64 = sizeof(R) == 8;
     constexpr bool ADIR = !A_KM || (F64 && TSM == 128), BDIR = !B_KM || (F64 && TSN == 128);
-    __shared__ __attribute__((aligned(16))) R smem[4 * STAGE];
+    static_assert(4 * STAGE == gemm_smem_elems_t<R, TSM, TSN>(), "LDS size");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
 
@@ -172,7 +183,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_tiles_kernel_t(GemmArgs g) {
     //              and forth, so lists sorted by decreasing k-range stay balanced across XCDs.
     constexpr int QN = 128 / TSN;                       // workgroups per tile along n
     constexpr int QUADS = (128 / TSM) * QN;             // workgroups per 128x128 tile
-    const int n = g.ntiles, b = blockIdx.x / QUADS, quad = blockIdx.x % QUADS;
+    const int n = g.ntiles, b = bx / QUADS, quad = bx % QUADS;
     int p;
     if (QUADS > 1) {
         p = b;
@@ -194,12 +205,12 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_tiles_kernel_t(GemmArgs g) {
     if (g.kfix1 > g.kfix0) { t.kb0 = g.kfix0; t.kb1 = g.kfix1; }
     const int nsteps = (t.kb1 - t.kb0) * (NB / BK);
     const int qi = (quad / QN) * TSM, qj = (quad % QN) * TSN;
-    // batch: blockIdx.y selects the problem; operands advance by their per-problem strides.  The pointers of
+    // batch: by selects the problem; operands advance by their per-problem strides.  The pointers of
     // GemmArgs are typed double* on the host side whatever the handle's precision.
-    const R* gA = reinterpret_cast<const R*>(g.A) + blockIdx.y * g.sA;
-    const R* gB = reinterpret_cast<const R*>(g.B) + blockIdx.y * g.sB;
-    R* gC = g.C ? reinterpret_cast<R*>(g.C) + blockIdx.y * g.sC : nullptr;
-    if (g.colpart) g.colpart += blockIdx.y * g.sColpart;
+    const R* gA = reinterpret_cast<const R*>(g.A) + by * g.sA;
+    const R* gB = reinterpret_cast<const R*>(g.B) + by * g.sB;
+    R* gC = g.C ? reinterpret_cast<R*>(g.C) + by * g.sC : nullptr;
+    if (g.colpart) g.colpart += by * g.sColpart;
 
     // operand origins (element units)
     const int64_t a_m0 = (int64_t)(t.ci + (A_KM ? g.a_coff : g.a_roff)) * NB + qi;
@@ -328,6 +339,12 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_tiles_kernel_t(GemmArgs g) {
             g.colpart[(int64_t)t.ci * g.ld_colpart + (int64_t)(t.cj + g.c_coff) * NB + tid] = tot;
         }
     }
+}
+
+template <typename R, bool A_KM, bool B_KM, int EPI, int NW, int TSM, int TSN>
+__global__ __launch_bounds__(NW * 64, 2) void gemm_tiles_kernel_t(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) R smem[gemm_smem_elems_t<R, TSM, TSN>()];
+    gemm_tile_body_t<R, A_KM, B_KM, EPI, NW, TSM, TSN>(g, (int)blockIdx.x, (int)blockIdx.y, smem);
 }
 
 // Launches of a few tiles per CU with very different k-ranges (mid-size N): the launch lasts as long as its
