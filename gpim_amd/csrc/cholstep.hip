@@ -171,9 +171,11 @@ static void lower_patches(std::vector<TileDesc>& out, int lo, int hi, int kb0, i
                     if (j <= i) out.push_back({i, j, kb0, kb1});
 }
 
-static bool pair_mode(int nb) {
+static bool pair_mode(int nb, bool fp32) {
     static const int v = getenv("GPIMHIP_PAIR") ? atoi(getenv("GPIMHIP_PAIR")) : -1;
     if (v >= 0) return v != 0;
+    // float matrices (tools/r3_f32_sweep2.sh): pairs lose up to N = 16384 (17.70 vs 17.33 ms), draw at 20480 (30.6 / 30.8)
+    if (fp32) return nb >= 160;
     return nb >= 112;     // N = 16384: 32.2 -> 31.4 ms, 20480: 57.9 -> 57.3; no gain at 8192 / 12288
 }
 
@@ -183,15 +185,21 @@ static bool pair_mode(int nb) {
 // nb = 63 everything is hosted (the factorisation is bound by the chain of diagonal blocks, hosted tiles are
 // free), beyond that 32 tiles per launch (N = 16384: 32.1 ms with 0 / 32 / 128, 34.0 with everything hosted;
 // N = 10240: 10.6 / 10.2 / 10.8 / 10.6).
-static int fill_cap(int nb) {
+// Float matrices: a hosted tile takes half the matrix-core time while the factorisation role (double) lasts as long
+// as ever, so more is hosted: everything up to nb = 87 (potrf at N = 6400 / 8192 / 10240: 2.65 / 4.04 / 6.23 ms; with
+// 64 tiles per launch 2.72 / 4.19 / 6.42), 128 tiles per launch beyond (12288: 9.10 vs 9.25 (64) / 9.35 (all);
+// 16384: 17.33 vs 17.68 / 18.58), tools/r3_f32_sweep2.sh.
+static int fill_cap(int nb, bool fp32) {
     static const int v = getenv("GPIMHIP_FILL_CAP") ? atoi(getenv("GPIMHIP_FILL_CAP")) : -1;
     if (v >= 0) return v;
-    if (pair_mode(nb)) return 0;       // hosted k-depth-1024 tiles would outlast the factorisation role by far
+    if (pair_mode(nb, fp32)) return fp32 ? 64 : 0;   // fp64: hosted k-depth-1024 tiles would outlast the factorisation role by far
+    if (fp32) return nb < 88 ? (1 << 30) : 128;
     return nb < 64 ? (1 << 30) : 32;
 }
 
 static int step_plan_build(gpimhip_ctx* h, int nb, StepPlan& P) {
-    if (P.nb == nb) return GPIMHIP_OK;
+    const bool fp32 = h->fp32 != 0;
+    if (P.nb == nb && P.fp32 == (int)fp32) return GPIMHIP_OK;
     if (P.d_tiles) { (void)hipFree(P.d_tiles); P.d_tiles = nullptr; }
     const int W = STEP_W;
     std::vector<TileDesc> tl;
@@ -212,7 +220,7 @@ static int step_plan_build(gpimhip_ctx* h, int nb, StepPlan& P) {
         // the left-looking column updates / diagonal updates below.
         std::vector<TileDesc> bulk;
         if (p > 0 && p0 + W < nb) {
-            if (!pair_mode(nb)) {
+            if (!pair_mode(nb, fp32)) {
                 lower_patches(bulk, p0 + W, nb, p0 - W, p0);
             } else if ((p - 1) % 2 == 0) {
                 const int c0 = p0 + W, c1 = std::min(p0 + 2 * W, nb);
@@ -223,7 +231,7 @@ static int step_plan_build(gpimhip_ctx* h, int nb, StepPlan& P) {
                 lower_patches(bulk, p0 + W, nb, p0 - 2 * W, p0);
             }
         }
-        const int per = std::min<int>(fill_cap(nb), (int)((bulk.size() + ncol - 1) / ncol));
+        const int per = std::min<int>(fill_cap(nb, fp32), (int)((bulk.size() + ncol - 1) / ncol));
         size_t taken = 0;
         for (int j = p0; j < p1; ++j) {
             size_t s = tl.size();
@@ -247,6 +255,7 @@ static int step_plan_build(gpimhip_ctx* h, int nb, StepPlan& P) {
     HIP_TRY(hipMemcpyAsync(P.d_tiles, tl.data(), tl.size() * sizeof(TileDesc), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     P.nb = nb;
+    P.fp32 = (int)fp32;
     return GPIMHIP_OK;
 }
 

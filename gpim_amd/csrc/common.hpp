@@ -78,6 +78,7 @@ struct LinalgPlan {
 // left of the previous panel's bulk update.
 struct StepPlan {
     int nb = 0;
+    int fp32 = 0;                       // hosting policy the lists were built for (cholstep.hip: pair_mode / fill_cap)
     TileDesc* d_tiles = nullptr;
     int64_t n_tiles = 0;
     std::vector<PlanRange> fill, diag, bulk_rest;
