@@ -689,42 +689,49 @@ static int solve_vectors(gpimhip_ctx* h, const gpimhip_model_t* m, const double*
 }
 
 // K(u) -> L -> L^-1 (in h->A), and unless `defer_vectors` also z and alpha.
+// Large N, eager launches: the launch-chain stages (factorisation, triangular inverse) run on the engine's
+// high-priority chain stream (see ensure_lookahead_streams), two event hops per call; everything else stays on the
+// caller's stream, below the priority of the side branch that hides the mat-vecs behind the K^-1 product.
+struct ChainHop { hipStream_t caller = nullptr; bool on = false; };
+static int chain_hop_begin(gpimhip_ctx* h, int64_t np, ChainHop& c) {
+    c.caller = h->stream;
+    c.on = false;
+    if (h->capturing || (int)((np / NB + OUTER_W - 1) / OUTER_W) < LOOKAHEAD_MIN_PANELS || getenv("GPIMHIP_NO_CHAIN_STREAM"))
+        return GPIMHIP_OK;
+    ensure_lookahead_streams(h);
+    if (!h->chain_stream) return GPIMHIP_OK;
+    for (auto& e : h->ev_chain)
+        if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(h->ev_chain[0], c.caller));
+    HIP_TRY(hipStreamWaitEvent(h->chain_stream, h->ev_chain[0], 0));
+    h->stream = h->chain_stream;
+    c.on = true;
+    return GPIMHIP_OK;
+}
+// rc: what the hopped stages returned; joined on every path -- after a failed launch the caller's stream (the one a
+// handle synchronises before it frees anything) must still be behind whatever the chain stream was given
+static int chain_hop_end(gpimhip_ctx* h, ChainHop& c, int rc) {
+    if (c.on) {
+        h->stream = c.caller;
+        hipError_t je = hipEventRecord(h->ev_chain[1], h->chain_stream);
+        if (je == hipSuccess) je = hipStreamWaitEvent(c.caller, h->ev_chain[1], 0);
+        c.on = false;
+        if (rc == GPIMHIP_OK) HIP_TRY(je);
+    }
+    return rc;
+}
+
 static int factor_at_u(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X, int64_t x_bs, int64_t N,
                        const double* u, bool defer_vectors = false) {
     const int64_t np = h->np, ld = h->ld;
     GP_TRY(launch_theta(h, m, u));
     GP_TRY(launch_kmat(h, m, X, N, nullptr, N, h->theta, 0.0, 1, h->A, ld, np, np, 1, 1, x_bs, x_bs, np * ld));
-    // Large N, eager launches: the two launch-chain stages run on the engine's high-priority chain stream (see
-    // ensure_lookahead_streams), two event hops per call; everything else stays on the caller's stream, below the
-    // priority of the side branch that hides the mat-vecs behind the K^-1 product.
-    hipStream_t caller_s = h->stream;
-    bool hop = false;
-    if (!h->capturing && (int)((np / NB + OUTER_W - 1) / OUTER_W) >= LOOKAHEAD_MIN_PANELS &&
-        !getenv("GPIMHIP_NO_CHAIN_STREAM")) {
-        ensure_lookahead_streams(h);
-        if (h->chain_stream) {
-            for (auto& e : h->ev_chain)
-                if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            hop = true;
-        }
-    }
-    if (hop) {
-        HIP_TRY(hipEventRecord(h->ev_chain[0], caller_s));
-        HIP_TRY(hipStreamWaitEvent(h->chain_stream, h->ev_chain[0], 0));
-        h->stream = h->chain_stream;
-    }
+    ChainHop hop;
+    GP_TRY(chain_hop_begin(h, np, hop));
     int rc = GPIMHIP_OK;
     { StageTimer t(h, 0); rc = launch_potrf(h, h->A, np, ld, h->info); }
     if (rc == GPIMHIP_OK) { StageTimer t(h, 1); rc = launch_trtri(h, h->A, h->Tm, np, ld); }
-    if (hop) {
-        // joined on every path: after a failed launch the caller's stream (the one a handle synchronises before it
-        // frees anything) must still be behind whatever the chain stream was given
-        h->stream = caller_s;
-        hipError_t je = hipEventRecord(h->ev_chain[1], h->chain_stream);
-        if (je == hipSuccess) je = hipStreamWaitEvent(caller_s, h->ev_chain[1], 0);
-        if (rc == GPIMHIP_OK) HIP_TRY(je);
-    }
-    GP_TRY(rc);
+    GP_TRY(chain_hop_end(h, hop, rc));
     if (!defer_vectors) GP_TRY(solve_vectors(h, m, X, x_bs, N));
     return GPIMHIP_OK;
 }
@@ -1000,7 +1007,9 @@ int gpimhip_potrf(gpimhip_handle h, double* A, int64_t n, int64_t ld, int32_t* i
     const int64_t np = h->np;
     HIP_TRY(hipMemsetAsync(info, 0, sizeof(int32_t), h->stream));
     GP_TRY(launch_pad_matrix_in(h, A, n, ld, h->A, np));
-    GP_TRY(launch_potrf(h, h->A, np, np, info));
+    ChainHop hop;
+    GP_TRY(chain_hop_begin(h, np, hop));
+    GP_TRY(chain_hop_end(h, hop, launch_potrf(h, h->A, np, np, info)));
     GP_TRY(launch_pad_matrix_out_lower(h, h->A, np, A, n, ld));
     return GPIMHIP_OK;
 }
