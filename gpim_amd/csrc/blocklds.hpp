@@ -302,9 +302,9 @@ __device__ __forceinline__ void load_block_chol0(double* D, double* invd, int* s
 // Block row i of L is final once step i-1 is over.  During step i
 //   panel-solve phase : every wave but wave 4 solves one tile below the diagonal tile; wave 4 stores X(i-1,i-1)
 //                       (from the scratch tile) over L(i-1,i-1); the five worker waves store block row i-1 of
-//                       X (held in registers since the previous step) over L(i-1,.); sink(i, t) lets all
-//                       512 threads export block row i of L;
-//   update phase      : next to their trailing tiles, the workers form T(i,j) = sum_k L(i,k) X(k,j) on
+//                       X (held in registers since the previous step) over L(i-1,.);
+//   update phase      : waves 1-3 and 5-7 export block row i of L (sink(i, t)); next to their trailing tiles,
+//                       the workers form T(i,j) = sum_k L(i,k) X(k,j) on
 //                       MFMA and multiply by -X(i,i) (T is already in B-operand layout); the results
 //                       stay in registers until the next step so that no wave overwrites an L(i,k)
 //                       another one still reads.  The row-inverse work grows as the trailing
@@ -318,7 +318,10 @@ __device__ long long g_fprof[128];       // tools/potf2_prof.hip: wave 0's clock
 #define FSTAMP(i) do { } while (0)
 #endif
 #define XS_LD 18
-#define SINK_THREADS 512      // sink(i, t) is called by every thread of the workgroup: t = 0..511
+// sink(i, t) exports block row i of L; it is called in the UPDATE phase of step i by the six waves that are neither
+// the factorising wave 0 nor its SIMD partner wave 4: t = 0..383.  (Until late in round 3 all 512 threads exported in
+// the panel-solve phase, on wave 0's critical path: 1.3K -> 0.6K cycles of that phase per step.)
+#define SINK_THREADS 384
 // FIRST_DONE: the caller has already factored the first diagonal tile (load_block_chol0).
 template <typename Sink, bool FIRST_DONE = false>
 __device__ __forceinline__ void lds_factor_inv(double* D, double* invd, double* Xs, int npan, int* s_bad, int tid,
@@ -374,11 +377,13 @@ __device__ __forceinline__ void lds_factor_inv(double* D, double* invd, double* 
                 tile_write(D + (c0 - 16) * LDD + (c0 - 16), xd, lane);
             }
         }
-        if (p < npan) sink(p, tid);
         FSTAMP(8 * p + 1);
         __syncthreads();
         FSTAMP(8 * p + 2);
         if (p == npan) break;
+        // block row p of L (final since the end of step p-1; the inverse overwrites it in the solve phase of step p+1)
+        // goes back to HBM from the waves off the critical path
+        if (wave != 0 && wave != 4) sink(p, ((wave < 4) ? wave - 1 : wave - 2) * 64 + lane);
         // row p of the inverse: the five workers, two tiles each -- or, in the LAST step (no 16x16 factorisation left
         // to hide behind), seven waves with one tile each
         const bool lastp = (p == npan - 1);
