@@ -64,18 +64,22 @@ __global__ __launch_bounds__(NTH, 1) void chol_step_kernel(StepArgs a) {
 // Panel solve, one workgroup (4 waves) per 32-row strip of the block column below the diagonal block:
 // S = P * Dinv^T, in place.  Wave w owns the 16-column tiles w and 7 - w of the strip (Dinv is lower triangular:
 // tile t needs k-steps 0 .. 4t+3, so every wave runs 36 of them per 16 rows).
+// ROWS = rows of one workgroup's strip: 32, or 16 (twice the workgroups, half the MFMA chain per wave: the kernel is
+// latency-bound, and the inverse it re-reads per workgroup comes out of L2).
+template <int ROWS>
 __global__ __launch_bounds__(256) void panel_solve_kernel(double* __restrict__ A, int64_t ld, int kblk, int nb,
                                                           const double* __restrict__ dinvB_all) {
     constexpr int LDS_LD = 130;             // 130 % 32 == 2: the A-fragment reads below are bank-conflict free
-    __shared__ __attribute__((aligned(16))) double S[32 * LDS_LD];
+    constexpr int MTS = ROWS / 16;
+    __shared__ __attribute__((aligned(16))) double S[ROWS * LDS_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     A += (int64_t)blockIdx.y * nb * NB * ld;
     const d2* DB = reinterpret_cast<const d2*>(dinvB_all + ((int64_t)blockIdx.y * nb + kblk) * (NB * NB));
-    double* P = A + ((int64_t)(kblk + 1) * NB + (int64_t)blockIdx.x * 32) * ld + (int64_t)kblk * NB;
+    double* P = A + ((int64_t)(kblk + 1) * NB + (int64_t)blockIdx.x * ROWS) * ld + (int64_t)kblk * NB;
     // the strip: one 1 KB row per wave-wide load, global -> LDS directly
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int row = wave * 8 + i;
+    for (int i = 0; i < ROWS / 4; ++i) {
+        const int row = wave * (ROWS / 4) + i;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(P + (int64_t)row * ld + lane * 2),
                                          (__attribute__((address_space(3))) void*)(S + row * LDS_LD), 16, 0, 0);
     }
@@ -99,13 +103,11 @@ __global__ __launch_bounds__(256) void panel_solve_kernel(double* __restrict__ A
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int s = 2 * s2 + e;
-            const double a0 = Sa[4 * s], a1 = Sa[16 * LDS_LD + 4 * s];
-            if (first) {
-                acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bf[q][e], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bf[q][e], acc[0][1], 0, 0, 0);
-            } else {
-                acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bf[q][e], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bf[q][e], acc[1][1], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MTS; ++mt) {
+                const double av = Sa[mt * 16 * LDS_LD + 4 * s];
+                if (first) acc[0][mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bf[q][e], acc[0][mt], 0, 0, 0);
+                else acc[1][mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bf[q][e], acc[1][mt], 0, 0, 0);
             }
         }
     }
@@ -113,7 +115,7 @@ __global__ __launch_bounds__(256) void panel_solve_kernel(double* __restrict__ A
     for (int x = 0; x < 2; ++x) {
         const int t = x == 0 ? t0 : t1;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MTS; ++mt)
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg)
                 P[(int64_t)(mt * 16 + (lane >> 4) + 4 * rg) * ld + t * 16 + (lane & 15)] = acc[x][mt][rg];
@@ -299,6 +301,8 @@ int launch_potrf_steps(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_
     static const int half_max = getenv("GPIMHIP_FILL_HALF_MAX") ? atoi(getenv("GPIMHIP_FILL_HALF_MAX")) : 512;
     static const bool old_diag = getenv("GPIMHIP_OLD_DIAG") != nullptr;
     static const int host_max_batch = getenv("GPIMHIP_HOST_MAX_BATCH") ? atoi(getenv("GPIMHIP_HOST_MAX_BATCH")) : 4;
+    static const int strip16_env = getenv("GPIMHIP_STRIP16") ? atoi(getenv("GPIMHIP_STRIP16")) : -1;
+    const bool strip16 = strip16_env >= 0 ? strip16_env != 0 : false;
     for (int j = 0; j < nb; ++j) {
         if (j % W == 0 && P.bulk_rest[j / W].n) {
             GemmArgs g = nt_update(A, ld, P.d_tiles + P.bulk_rest[j / W].off, P.bulk_rest[j / W].n, h->np);
@@ -326,8 +330,12 @@ int launch_potrf_steps(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_
             hipLaunchKernelGGL((chol_step_kernel<128, 128>), dim3(8 + nf, B), dim3(NTH), 0, h->stream, a);
         HIP_TRY(hipGetLastError());
         if (j + 1 < nb) {
-            hipLaunchKernelGGL(panel_solve_kernel, dim3(4 * (nb - j - 1), B), dim3(256), 0, h->stream, A, ld, j, nb,
-                               (const double*)dinvB);
+            if (strip16)
+                hipLaunchKernelGGL(panel_solve_kernel<16>, dim3(8 * (nb - j - 1), B), dim3(256), 0, h->stream, A, ld, j, nb,
+                                   (const double*)dinvB);
+            else
+                hipLaunchKernelGGL(panel_solve_kernel<32>, dim3(4 * (nb - j - 1), B), dim3(256), 0, h->stream, A, ld, j, nb,
+                                   (const double*)dinvB);
             HIP_TRY(hipGetLastError());
             if (old_diag) {
                 GemmArgs g = nt_update(A, ld, P.d_tiles + P.diag[j].off, P.diag[j].n, h->np);
@@ -362,7 +370,7 @@ int launch_panel_chain(gpimhip_ctx* h, double* A, int64_t ld, int p0, int p1, in
             hipLaunchKernelGGL((chol_step_kernel<128, 64>), dim3(8 + 2 * f.n, B), dim3(NTH), 0, h->stream, a);
         HIP_TRY(hipGetLastError());
         if (j + 1 < nb) {
-            hipLaunchKernelGGL(panel_solve_kernel, dim3(4 * (nb - j - 1), B), dim3(256), 0, h->stream, A, ld, j, nb,
+            hipLaunchKernelGGL(panel_solve_kernel<32>, dim3(4 * (nb - j - 1), B), dim3(256), 0, h->stream, A, ld, j, nb,
                                (const double*)h->dinvB);
             HIP_TRY(hipGetLastError());
         }
