@@ -65,7 +65,8 @@ __global__ __launch_bounds__(NTH, 1) void chol_step_kernel(StepArgs a) {
 // S = P * Dinv^T, in place.  Wave w owns the 16-column tiles w and 7 - w of the strip (Dinv is lower triangular:
 // tile t needs k-steps 0 .. 4t+3, so every wave runs 36 of them per 16 rows).
 // ROWS = rows of one workgroup's strip: 32, or 16 (twice the workgroups, half the MFMA chain per wave: the kernel is
-// latency-bound, and the inverse it re-reads per workgroup comes out of L2).
+// latency-bound, and the inverse it re-reads per workgroup comes out of L2).  Measured: 16 and 64 are both slower than
+// 32 (potrf at N = 4212: 1.694 / 1.647 / 1.783 ms, at 16384: 29.65 / 28.96 / 29.60); GPIMHIP_STRIP16=1 selects 16.
 template <int ROWS>
 __global__ __launch_bounds__(256) void panel_solve_kernel(double* __restrict__ A, int64_t ld, int kblk, int nb,
                                                           const double* __restrict__ dinvB_all) {
@@ -94,7 +95,11 @@ __global__ __launch_bounds__(256) void panel_solve_kernel(double* __restrict__ A
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const d4 zero = (d4){0.0, 0.0, 0.0, 0.0};
-    d4 acc[2][2] = {{zero, zero}, {zero, zero}};
+    d4 acc[2][MTS];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int mt = 0; mt < MTS; ++mt) acc[x][mt] = zero;
     const double* Sa = S + (lane & 15) * LDS_LD + (lane >> 4);
 #pragma unroll
     for (int q = 0; q < 18; ++q) {
