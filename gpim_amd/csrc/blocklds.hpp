@@ -11,6 +11,28 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 #define LDD 130   // row stride of the LDS block: 130 % 32 == 2 keeps MK fragment reads conflict free
 #define NTH 512
 
+// Where element (16 ti + rr, 16 tj + cc) of the block lives in LDS: D[Lay::tile(ti, tj) + Lay::in(rr, cc)].
+//   LayPad  the full square, row-major with stride LDD (133 KB for 128 x 128): the fused small-N trainer, whose other
+//           phases address D[i * LDD + j] directly.
+//   LayTri  only the 36 lower 16x16 tiles of a 128 x 128 block, packed (tile (ti, tj) is number ti (ti + 1) / 2 + tj,
+//           2 KB each = 72 KB): the diagonal-block role of the Cholesky step kernel -- under 80 KB with its scratch, so
+//           two workgroups of that launch share a CU and the trailing-update tiles it hosts run two per CU
+//           like in a launch of their own.  Rows of a tile are 16 doubles = 32 banks apart, so columns are XOR-swizzled
+//           with 2 (rr >> 1): a ds_read_b64 is served in two groups of 32 lanes over 64 banks, and for all three
+//           access patterns of this file -- A operand (rr = lane & 15, cc = 4 s + (lane >> 4)), B operand / accumulator
+//           (rr = 4 s + (lane >> 4), cc = lane & 15) -- the 32 lanes of a group then hit 32 distinct bank pairs.  The
+//           swizzle is even: the pair (cc, cc + 1), cc even, stays one aligned 16-byte chunk.
+struct LayPad {
+    static constexpr int DOUBLES = NB * LDD;
+    __device__ __forceinline__ static int tile(int ti, int tj) { return ti * 16 * LDD + tj * 16; }
+    __device__ __forceinline__ static int in(int rr, int cc) { return rr * LDD + cc; }
+};
+struct LayTri {
+    static constexpr int DOUBLES = 36 * 256;
+    __device__ __forceinline__ static int tile(int ti, int tj) { return ((ti * (ti + 1)) / 2 + tj) * 256; }
+    __device__ __forceinline__ static int in(int rr, int cc) { return rr * 16 + (cc ^ ((rr >> 1) << 1)); }
+};
+
 __device__ __forceinline__ double bcast_lane(double v, int srclane) {
     int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane);
     int hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
@@ -57,8 +79,8 @@ __device__ __forceinline__ double pick4(double v0, double v1, double v2, double 
     return r;
 }
 
-// 16x16 lower Cholesky by one full wave; D points at the (c0,c0) corner (stride LDD, lower part
-// valid).  Writes L16 (lower) back and 1/L_jj to invd_out[0..15]; returns 0 or 1 + first bad
+// 16x16 lower Cholesky by one full wave; D points at the tile's origin (element (rr, cc) at D[Lay::in(rr, cc)], lower
+// part valid).  Writes L16 (lower) back and 1/L_jj to invd_out[0..15]; returns 0 or 1 + first bad
 // local column (wave-uniform).
 //
 // The tile lives in the MFMA accumulator layout of the symmetric matrix: lane l, register g holds
@@ -72,6 +94,7 @@ __device__ __forceinline__ double pick4(double v0, double v1, double v2, double 
 // independent of the factorisation's own dependency chain.  Cost, one wave alone (tools/chol16_var.hip): 4.43K cycles
 // without, 5.23K with the inverse (fp64 MFMAs and the wave's fp64 scalar chains share the SIMD's fp64 unit); handing
 // the two operands per panel to a helper wave through LDS behind a flag instead measured 5.60K -- not kept.
+template <class Lay = LayPad>
 __device__ __forceinline__ int chol16(double* D, double* invd_out, int lane, d4* xinv = nullptr) {
     const int r = lane & 15, kq = lane >> 4, p = r & 3;
     d4 acc, Lf;
@@ -84,7 +107,7 @@ __device__ __forceinline__ int chol16(double* D, double* invd_out, int lane, d4*
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const int c = kq + 4 * g;
-        acc[g] = D[(r > c ? r : c) * LDD + (r > c ? c : r)];
+        acc[g] = D[Lay::in(r > c ? r : c, r > c ? c : r)];
     }
     int bad = 0;
 #pragma unroll
@@ -147,7 +170,7 @@ __device__ __forceinline__ int chol16(double* D, double* invd_out, int lane, d4*
 #pragma unroll
     for (int jb = 0; jb < 4; ++jb) {
         const int c = 4 * jb + kq;
-        if (c <= r) D[r * LDD + c] = Lf[jb];
+        if (c <= r) D[Lay::in(r, c)] = Lf[jb];
     }
     if (xinv) *xinv = Xf;
     return bad;
@@ -241,51 +264,57 @@ __device__ __forceinline__ void trinv16(const double* L, int ldl, const double* 
     for (int g = 0; g < 4; ++g) out[((lane >> 4) + 4 * g) * ldo + (lane & 15)] = X[g];
 }
 
+template <class Lay = LayPad>
 __device__ __forceinline__ d4 tile_read(const double* C, int lane) {
     d4 v;
 #pragma unroll
-    for (int rg = 0; rg < 4; ++rg) v[rg] = C[((lane >> 4) + 4 * rg) * LDD + (lane & 15)];
+    for (int rg = 0; rg < 4; ++rg) v[rg] = C[Lay::in((lane >> 4) + 4 * rg, lane & 15)];
     return v;
 }
+template <class Lay = LayPad>
 __device__ __forceinline__ void tile_write(double* C, d4 v, int lane) {
 #pragma unroll
-    for (int rg = 0; rg < 4; ++rg) C[((lane >> 4) + 4 * rg) * LDD + (lane & 15)] = v[rg];
+    for (int rg = 0; rg < 4; ++rg) C[Lay::in((lane >> 4) + 4 * rg, lane & 15)] = v[rg];
 }
 
-// Loads the 128x128 block into D AND factors its first 16x16 tile: all 16 loads of a thread are put in
-// flight, the two chunks that make up rows 0..15 are stored as soon as they arrive, and wave 0 runs
-// chol16 on them while the rest of the block is still on its way (it stores its own remaining
-// chunks afterwards).  Pairs with lds_factor_inv<.., true>.
+// Loads the lower 16x16 tiles of the 128x128 block into D (LayTri) AND factors its first tile: all 9 loads of a
+// thread are put in flight (16-byte chunk q = tid + 512 i of the packed lower triangle: tile q >> 7 in the order
+// (0,0) (1,0) (1,1) (2,0) ..., row (q >> 3) & 15 of it, column pair q & 7 -- eight lanes fetch one 128-byte row segment),
+// the first chunk of every thread (tiles 0 - 3) is stored as soon as it arrives, and wave 0 runs chol16 on tile (0,0)
+// while the rest of the block is still on its way.  Pairs with lds_factor_inv<.., true, LayTri>.  The strictly upper
+// tiles of the block are never read.
 // R: element type of the matrix in HBM (double, or float for single-precision handles; the block is factored in
 // double either way).
+__device__ __forceinline__ void tri_tile_of(int t, int& ti, int& tj) {
+    ti = (t >= 1) + (t >= 3) + (t >= 6) + (t >= 10) + (t >= 15) + (t >= 21) + (t >= 28);
+    tj = t - (ti * (ti + 1)) / 2;
+}
 template <typename R>
 __device__ __forceinline__ void load_block_chol0(double* D, double* invd, int* s_bad,
                                                  const R* __restrict__ Ablk, int64_t ld, int tid, double* Xs) {
     typedef R RV2 __attribute__((ext_vector_type(2)));
-    d2 r[16];
+    constexpr int NCH = 36 * 128 / NTH;      // 9
+    d2 r[NCH];
+    int off[NCH];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int e = tid + NTH * i, row = e >> 6, c2 = (e & 63) * 2;
-        const RV2 v = *reinterpret_cast<const RV2*>(Ablk + (int64_t)row * ld + c2);
+    for (int i = 0; i < NCH; ++i) {
+        const int q = tid + NTH * i, rr = (q >> 3) & 15, c2 = (q & 7) * 2;
+        int ti, tj;
+        tri_tile_of(q >> 7, ti, tj);
+        const RV2 v = *reinterpret_cast<const RV2*>(Ablk + (int64_t)(ti * 16 + rr) * ld + tj * 16 + c2);
         r[i] = (d2){(double)v[0], (double)v[1]};
+        off[i] = (q >> 7) * 256 + LayTri::in(rr, c2);
     }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int e = tid + NTH * i, row = e >> 6, c2 = (e & 63) * 2;
-        *reinterpret_cast<d2*>(D + row * LDD + c2) = r[i];
-    }
+    *reinterpret_cast<d2*>(D + off[0]) = r[0];
     __syncthreads();
     if (tid < 64) {
         d4 x0;
-        const int bad = chol16(D, invd, tid, &x0);
+        const int bad = chol16<LayTri>(D, invd, tid, &x0);
         xs_write(Xs, x0, tid);
         if (tid == 0 && bad && *s_bad == 0) *s_bad = bad;
     }
 #pragma unroll
-    for (int i = 2; i < 16; ++i) {
-        const int e = tid + NTH * i, row = e >> 6, c2 = (e & 63) * 2;
-        *reinterpret_cast<d2*>(D + row * LDD + c2) = r[i];
-    }
+    for (int i = 1; i < NCH; ++i) *reinterpret_cast<d2*>(D + off[i]) = r[i];
     __syncthreads();
 }
 
@@ -323,10 +352,10 @@ __device__ long long g_fprof[128];       // tools/potf2_prof.hip: wave 0's clock
 // the panel-solve phase, on wave 0's critical path: 1.3K -> 0.6K cycles of that phase per step.)
 #define SINK_THREADS 384
 // FIRST_DONE: the caller has already factored the first diagonal tile (load_block_chol0).
-template <typename Sink, bool FIRST_DONE = false>
+template <typename Sink, bool FIRST_DONE = false, class Lay = LayPad>
 __device__ __forceinline__ void lds_factor_inv(double* D, double* invd, double* Xs, int npan, int* s_bad, int tid,
                                                Sink sink) {
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (scalar: tile-base arithmetic on the SALU)
     const int r = lane & 15, kq = lane >> 4;
     const d4 zero = (d4){0.0, 0.0, 0.0, 0.0};
     // row-inverse workers: waves 2, 3, 5, 6, 7; wave 4 moves finished diagonal inverses into D
@@ -337,7 +366,7 @@ __device__ __forceinline__ void lds_factor_inv(double* D, double* invd, double* 
     if (!FIRST_DONE) {
         if (wave == 0) {
             d4 x0;
-            const int bad = chol16(D, invd, lane, &x0);
+            const int bad = chol16<Lay>(D, invd, lane, &x0);
             xs_write(Xs, x0, lane);
             if (lane == 0 && bad && *s_bad == 0) *s_bad = bad;
         }
@@ -352,12 +381,12 @@ __device__ __forceinline__ void lds_factor_inv(double* D, double* invd, double* 
             // panel solve of tile (p + 1 + slot, p):  S = A X_p^T
             const int t = p + 1 + slot;
             if (p < npan && t < npan) {
-                double* C = D + t * 16 * LDD + c0;
+                double* C = D + Lay::tile(t, p);
                 d4 acc = zero;
 #pragma unroll
                 for (int sft = 0; sft < 16; sft += 4)
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(C[r * LDD + sft + kq], Xp[r * XS_LD + sft + kq], acc, 0, 0, 0);
-                tile_write(C, acc, lane);
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(C[Lay::in(r, sft + kq)], Xp[r * XS_LD + sft + kq], acc, 0, 0, 0);
+                tile_write<Lay>(C, acc, lane);
             }
             // block row p-1 of X, held in registers since the previous step (by seven waves if that was the last one)
             if ((p == npan) ? true : worker) {
@@ -365,7 +394,7 @@ __device__ __forceinline__ void lds_factor_inv(double* D, double* invd, double* 
 #pragma unroll
                 for (int cnt = 0; cnt < 2; ++cnt) {
                     const int j = hw + hs * cnt;
-                    if (j < p - 1) tile_write(D + (c0 - 16) * LDD + j * 16, keep[cnt], lane);
+                    if (j < p - 1) tile_write<Lay>(D + Lay::tile(p - 1, j), keep[cnt], lane);
                 }
             }
         } else {
@@ -374,7 +403,7 @@ __device__ __forceinline__ void lds_factor_inv(double* D, double* invd, double* 
                 d4 xd;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) xd[g] = Xq[(kq + 4 * g) * XS_LD + r];
-                tile_write(D + (c0 - 16) * LDD + (c0 - 16), xd, lane);
+                tile_write<Lay>(D + Lay::tile(p - 1, p - 1), xd, lane);
             }
         }
         FSTAMP(8 * p + 1);
@@ -397,8 +426,8 @@ __device__ __forceinline__ void lds_factor_inv(double* D, double* invd, double* 
                 for (int k = j; k < p; ++k)
 #pragma unroll
                     for (int sft = 0; sft < 16; sft += 4) {
-                        const double a = D[(c0 + r) * LDD + k * 16 + sft + kq];
-                        const double b = D[(k * 16 + sft + kq) * LDD + j * 16 + r];
+                        const double a = D[Lay::tile(p, k) + Lay::in(r, sft + kq)];
+                        const double b = D[Lay::tile(k, j) + Lay::in(sft + kq, r)];
                         t = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, t, 0, 0, 0);
                     }
                 d4 x = zero;
@@ -414,14 +443,16 @@ __device__ __forceinline__ void lds_factor_inv(double* D, double* invd, double* 
         const int nworkers = NTH / 64 - 1;
         if (wave == 0 && ntile > 0) {
             // the tile the next 16x16 factorisation waits for: two accumulation chains instead of four dependent MFMAs
-            double* C = D + (c0 + 16) * LDD + c0 + 16;
-            d4 acc = tile_read(C, lane), acc2 = zero;
-            const double* Pr = D + (c0 + 16 + r) * LDD + c0 + kq;
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Pr[0], Pr[0], acc, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-Pr[4], Pr[4], acc2, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Pr[8], Pr[8], acc, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-Pr[12], Pr[12], acc2, 0, 0, 0);
-            tile_write(C, acc + acc2, lane);
+            double* C = D + Lay::tile(p + 1, p + 1);
+            d4 acc = tile_read<Lay>(C, lane), acc2 = zero;
+            const double* Pr = D + Lay::tile(p + 1, p);
+            const double p0v = Pr[Lay::in(r, kq)], p1v = Pr[Lay::in(r, kq + 4)], p2v = Pr[Lay::in(r, kq + 8)],
+                         p3v = Pr[Lay::in(r, kq + 12)];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-p0v, p0v, acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-p1v, p1v, acc2, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-p2v, p2v, acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-p3v, p3v, acc2, 0, 0, 0);
+            tile_write<Lay>(C, acc + acc2, lane);
         }
         // (wave 4 shares its SIMD with wave 0, whose 16x16 factorisation is the critical path: it takes no tiles)
         const int widx6 = (wave < 4) ? wave - 1 : wave - 2;
@@ -431,23 +462,28 @@ __device__ __forceinline__ void lds_factor_inv(double* D, double* invd, double* 
             while ((i + 1) * (i + 2) / 2 <= q) ++i;
             const int j = q - i * (i + 1) / 2;
             const int rt = p + 1 + i, ct = p + 1 + j;
-            double* C = D + rt * 16 * LDD + ct * 16;
-            d4 acc = tile_read(C, lane);
+            double* C = D + Lay::tile(rt, ct);
+            d4 acc = tile_read<Lay>(C, lane);
 #pragma unroll
             for (int sft = 0; sft < 16; sft += 4) {
-                const double a = -D[(rt * 16 + (lane & 15)) * LDD + c0 + sft + (lane >> 4)];
-                const double b = D[(ct * 16 + (lane & 15)) * LDD + c0 + sft + (lane >> 4)];
+                const double a = -D[Lay::tile(rt, p) + Lay::in(r, sft + kq)];
+                const double b = D[Lay::tile(ct, p) + Lay::in(r, sft + kq)];
                 acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
             }
-            tile_write(C, acc, lane);
+            tile_write<Lay>(C, acc, lane);
         }
         FSTAMP(8 * p + 3);
         if (wave == 0 && p + 1 < npan) {
             const int c1 = c0 + 16;
             d4 xn;
-            const int bad = chol16(D + c1 * LDD + c1, invd + c1, lane, &xn);
+            const int bad = chol16<Lay>(D + Lay::tile(p + 1, p + 1), invd + c1, lane, &xn);
             xs_write(Xs + ((p + 1) & 1) * 16 * XS_LD, xn, lane);
             if (lane == 0 && bad && *s_bad == 0) *s_bad = c1 + bad;
+            // wave 0 carries no row of the inverse out of a step that has a 16x16 factorisation (it holds one only after
+            // the LAST step): redefining `keep` here ends its live range at the top of this block, so that the register
+            // allocator does not hold 16 registers across chol16 for the one wave that runs it
+            keep[0] = zero;
+            keep[1] = zero;
         }
         FSTAMP(8 * p + 4);
         __syncthreads();

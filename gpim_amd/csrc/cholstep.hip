@@ -22,6 +22,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <functional>
 #include "potf2_body.hpp"
 #include "gemm_body.hpp"
 
@@ -42,7 +43,7 @@ struct StepArgs {
 // k-steps in flight was measured and does NOT help: potrf 1.91 vs 1.86 ms at N = 4224, 6.58 vs 6.39 at 8192,
 // 32.7 vs 32.1 at 16384 -- what a lone 8-wave workgroup lacks is not load latency cover.
 template <int FTM, int FTN>
-__global__ __launch_bounds__(NTH, 1) void chol_step_kernel(StepArgs a) {
+__global__ __launch_bounds__(NTH, 4) void chol_step_kernel(StepArgs a) {
 #ifdef GPIMHIP_STEP_RING
     constexpr int NSTG = (FTM == 128 && FTN == 128) ? 3 : (FTM == 128 ? 4 : 6);
 #else
@@ -204,6 +205,111 @@ static int fill_cap(int nb, bool fp32) {
     return nb < 64 ? (1 << 30) : 32;
 }
 
+// ---- hosting plan for double-precision matrices of nb >= 64 block columns -------------------------------------
+// Everything the trailing matrix receives from panels older than the window is HOSTED by the step launches (two
+// workgroups per CU since the factorisation role fits 79 KB).  What a launch hosts is chosen so that it ends on a
+// full round of the chip's 512 workgroup slots:
+//   * tile (i, jj) keeps the first block column it has not yet received (`pend`); a flush applies [pend, p0) in ONE
+//     tile operation, so a tile that is skipped for a panel comes back twice as deep (k = 1024: half the
+//     read-modify-write passes over C, half the prologues -- what r3's "pair mode" did for whole panels);
+//   * tiles of the NEXT panel's columns must be flushed during this panel (deadline), the others are optional;
+//   * steady state: the two patch classes ((i / 8 + jj / 8) & 1) take turns, each flushed every other panel at depth
+//     8 -- every panel carries the same amount of work -- and the holes of a launch's last round are filled with
+//     whatever else is pending (list scheduling on 512 slots, the order the hardware dispatches workgroups in).
+// Below 64 remaining block columns a panel's updates are less than one round per launch: the chain of diagonal
+// blocks bounds the factorisation and everything pending is flushed at once, evenly over the panel's launches.
+struct HostSim {
+    std::vector<double> slot;       // min-heap of slot finish times
+    double makespan = 0.0;
+    explicit HostSim(int S) : slot(S, 0.0) {}
+    static double cost(const TileDesc& t) { return (t.kb1 - t.kb0) + 0.5; }     // k-blocks + prologue / epilogue
+    double peek() const { return slot.front(); }
+    void add(double c) {
+        std::pop_heap(slot.begin(), slot.end(), std::greater<double>());
+        slot.back() += c;
+        makespan = std::max(makespan, slot.back());
+        std::push_heap(slot.begin(), slot.end(), std::greater<double>());
+    }
+};
+
+static void step_plan_hosted(int nb, std::vector<TileDesc>& tl, StepPlan& P) {
+    const int W = STEP_W, S = 512;
+    auto mark = [&](size_t start) { return PlanRange{(int64_t)start, (int32_t)(tl.size() - start)}; };
+    const int npanel = (nb + W - 1) / W;
+    std::vector<int> pend((size_t)nb * nb, 0);        // first source block column tile (i, jj) has not received via bulk
+    for (int p = 0; p < npanel; ++p) {
+        const int p0 = p * W, p1 = std::min(p0 + W, nb), ncol = p1 - p0;
+        const int rem = nb - p0 - W;
+        std::vector<TileDesc> req, opt;
+        if (p > 0 && rem > 0) {
+            const int c0 = p0 + W, c1 = std::min(p0 + 2 * W, nb);
+            for (int i = c0; i < nb; ++i)
+                for (int jj = c0; jj < std::min(c1, i + 1); ++jj) req.push_back({i, jj, pend[(size_t)i * nb + jj], p0});
+            if (c1 < nb) lower_patches(opt, c1, nb, 0, p0);
+            for (auto& t : opt) t.kb0 = pend[(size_t)t.ci * nb + t.cj];
+        }
+        const bool bulk_regime = rem >= 64;
+        if (bulk_regime) {
+            // due first (deepest first), then the rest; both in patch order
+            auto due = [&](const TileDesc& t) { return (t.kb1 - t.kb0) >= 2 * W || (((t.ci >> 3) + (t.cj >> 3)) & 1) == (p & 1); };
+            std::stable_sort(opt.begin(), opt.end(), [&](const TileDesc& a, const TileDesc& b) {
+                const int da = due(a), db = due(b);
+                if (da != db) return da > db;
+                return (a.kb1 - a.kb0) > (b.kb1 - b.kb0);
+            });
+        }
+        double due_cost = 0.0;                 // cost of the due tiles not yet hosted
+        size_t n_due = 0;
+        if (bulk_regime)
+            for (auto& t : opt)
+                if ((t.kb1 - t.kb0) >= 2 * W || (((t.ci >> 3) + (t.cj >> 3)) & 1) == (p & 1)) { ++n_due; due_cost += HostSim::cost(t); }
+        size_t rtaken = 0, otaken = 0;
+        for (int j = p0; j < p1; ++j) {
+            const int left = p1 - j;
+            size_t s = tl.size();
+            const int kb0 = std::max(0, p0 - W);
+            if (j > kb0)
+                for (int i = j + 1; i < nb; ++i) tl.push_back({i, j, kb0, j});
+            const size_t nreq = (req.size() - rtaken + left - 1) / left;
+            for (size_t q = 0; q < nreq; ++q) tl.push_back(req[rtaken++]);
+            if (!bulk_regime) {
+                const size_t nopt = (opt.size() - otaken + left - 1) / left;
+                for (size_t q = 0; q < nopt; ++q) tl.push_back(opt[otaken++]);
+            } else {
+                HostSim sim(S);
+                sim.add(1.0);                                               // the factorisation role
+                std::stable_sort(tl.begin() + s, tl.end(), [](const TileDesc& a, const TileDesc& b) {
+                    return (a.kb1 - a.kb0) > (b.kb1 - b.kb0); });
+                for (size_t q = s; q < tl.size(); ++q) sim.add(HostSim::cost(tl[q]));
+                // This launch's length: its share of the due work, rounded to whole deep tiles per slot (a slot runs
+                // a sequence of tiles; 8.5 = one tile of depth 8) and never shorter than what it must host anyway.
+                double base = 0.0;
+                for (size_t q = s; q < tl.size(); ++q) base += HostSim::cost(tl[q]);
+                const double per_slot = (base + due_cost / left) / S;
+                const double target = std::max(sim.makespan, 8.5 * std::max(1.0, std::floor(per_slot / 8.5 + 0.5)));
+                double got = 0.0;
+                // due tiles first (the sorted list starts with them), then anything else that still ends in time
+                while (otaken < opt.size() && sim.peek() + HostSim::cost(opt[otaken]) <= target + 0.25) {
+                    const double c = HostSim::cost(opt[otaken]);
+                    sim.add(c);
+                    if (otaken < n_due) got += c;
+                    tl.push_back(opt[otaken++]);
+                }
+                due_cost -= std::min(due_cost, got);
+            }
+            // dispatch order = list order: deepest tiles first
+            std::stable_sort(tl.begin() + s, tl.end(), [](const TileDesc& a, const TileDesc& b) {
+                return (a.kb1 - a.kb0) > (b.kb1 - b.kb0); });
+            for (size_t q = s; q < tl.size(); ++q)
+                if (tl[q].cj != j) pend[(size_t)tl[q].ci * nb + tl[q].cj] = tl[q].kb1;
+            P.fill[j] = mark(s);
+            s = tl.size();
+            for (int jj = j + 1; jj < std::min(nb, p1 + W); ++jj) tl.push_back({jj, jj, j, j + 1});
+            P.diag[j] = mark(s);
+        }
+    }
+}
+
 static int step_plan_build(gpimhip_ctx* h, int nb, StepPlan& P) {
     const bool fp32 = h->fp32 != 0;
     if (P.nb == nb && P.fp32 == (int)fp32) return GPIMHIP_OK;
@@ -215,6 +321,10 @@ static int step_plan_build(gpimhip_ctx* h, int nb, StepPlan& P) {
     P.diag.assign(nb, {0, 0});
     const int npanel = (nb + W - 1) / W;
     P.bulk_rest.assign(npanel, {0, 0});
+    static const bool old_plan = getenv("GPIMHIP_OLD_PLAN") != nullptr;
+    if (!fp32 && nb >= 64 && !old_plan) {
+        step_plan_hosted(nb, tl, P);
+    } else
     for (int p = 0; p < npanel; ++p) {
         const int p0 = p * W, p1 = std::min(p0 + W, nb), ncol = p1 - p0;
         // bulk(p-1): columns >= p0 + W, k-blocks = the columns of panel p-1.
@@ -320,7 +430,8 @@ int launch_potrf_steps(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_
         a.g = nt_update(A, ld, P.d_tiles + P.fill[j].off, P.fill[j].n, h->np);
         const int nf = P.fill[j].n;
         // mixed k-ranges (column updates are up to 2W-1 blocks deep, bulk tiles W): deal the list to the XCDs in chunks
-        a.g.chunk = std::max(1, std::min(64, nf / 512));
+        static const int host_chunk = getenv("GPIMHIP_HOST_CHUNK") ? atoi(getenv("GPIMHIP_HOST_CHUNK")) : 0;
+        a.g.chunk = host_chunk > 0 ? host_chunk : std::max(1, std::min(64, nf / 512));
         if (B > host_max_batch) {
             // large batches saturate the chip by themselves: the pending tiles run as their own launch (two to four
             // workgroups per CU) in front of a factorisation-only step launch.  Same tile operations in the same

@@ -32,7 +32,7 @@ struct StepArgs32 {
 
 // blockIdx.x == 0: the factorisation; 1..7 idle (filler b stays on XCD b % 8); >= 8: filler tile b - 8
 template <int FTM, int FTN>
-__global__ __launch_bounds__(NTH, 1) void chol_step_kernel_f32(StepArgs32 a) {
+__global__ __launch_bounds__(NTH, 4) void chol_step_kernel_f32(StepArgs32 a) {
     constexpr int GS = (gemm_smem_elems_t<float, FTM, FTN>() + 1) / 2;           // in doubles
     constexpr int SM = POTF2_SMEM_DOUBLES > GS ? POTF2_SMEM_DOUBLES : GS;
     static_assert(SM * 8 <= 160 * 1024, "LDS");

@@ -15,8 +15,11 @@
 // SIMD: hence 512-thread workgroups.
 #include "potf2_body.hpp"
 
+#ifndef POTF2_WAVES_PER_EU
+#define POTF2_WAVES_PER_EU 4
+#endif
 template <typename R>
-__global__ __launch_bounds__(NTH, 1) void potf2_kernel(R* __restrict__ A, int64_t ld, int kblk,
+__global__ __launch_bounds__(NTH, POTF2_WAVES_PER_EU) void potf2_kernel(R* __restrict__ A, int64_t ld, int kblk,
                                                        R* __restrict__ dinv_all,
                                                        double* __restrict__ logdet_out,
                                                        int32_t* __restrict__ info, int nb PROF_ARG) {

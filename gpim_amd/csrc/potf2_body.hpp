@@ -17,22 +17,24 @@
 // dinvB_all (optional): the same inverse once more in the B-operand order of the f64 MFMA for the product
 // S = P * Dinv^T of the panel solve (cholstep.hip): dinvB[t][s2][lane][e] = Dinv[16 t + (lane & 15)][8 s2 + 4 e + (lane >> 4)],
 // so that a wave fetches the fragments of two k-steps of one 16-column tile with ONE coalesced 16-byte load per lane.
-// smem: POTF2_SMEM_DOUBLES doubles of LDS.
-#define POTF2_SMEM_DOUBLES (NB * LDD + NB + 32 * XS_LD + 4)
+// smem: POTF2_SMEM_DOUBLES doubles of LDS -- the 36 lower 16x16 tiles of the block, packed (blocklds.hpp: LayTri), the
+// reciprocal pivots, two scratch tiles: 79 392 bytes, so that TWO workgroups of a launch with this role fit one CU.
+#define POTF2_SMEM_DOUBLES (LayTri::DOUBLES + NB + 32 * XS_LD + 4)
+typedef LayTri PL;
 template <typename R>
 __device__ __forceinline__ void potf2_body(double* __restrict__ smem, const int by, R* __restrict__ A, int64_t ld, int kblk,
                                            R* __restrict__ dinv_all, double* __restrict__ dinvB_all,
                                            double* __restrict__ logdet_out, int32_t* __restrict__ info, int nb PROF_ARG,
                                            int col_off = 0) {
     double* D = smem;
-    double* invd = D + NB * LDD;
+    double* invd = D + PL::DOUBLES;
     double* Xs = invd + NB;
     double* red = Xs + 32 * XS_LD;
     int& s_bad = *reinterpret_cast<int*>(red + 2);
     A += (int64_t)by * nb * NB * ld;
     dinv_all += (int64_t)by * nb * NB * NB;
     logdet_out += (int64_t)by * nb;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     typedef R RV2 __attribute__((ext_vector_type(2)));
     R* Ablk = A + ((int64_t)kblk * NB) * ld + (int64_t)kblk * NB;
     if (tid == 0) s_bad = 0;
@@ -42,16 +44,31 @@ __device__ __forceinline__ void potf2_body(double* __restrict__ smem, const int 
     STAMP(1);
     // factor and invert in one sweep; block row i of L goes back to HBM (zeros above the diagonal)
     // during step i, just before the inverse overwrites it in LDS
+    // 16-byte chunk e of block row i (16 rows x 128 columns) in tile-major order: tile e >> 7, row (e >> 3) & 15 of it,
+    // column pair e & 7 -- one wave-wide access covers 8 rows x 128 bytes of ONE tile, which is conflict-free in the
+    // packed layout (a matrix row across tiles would put all 64 lanes on the same 32 banks) and whole 128-byte lines
+    // in HBM.  Elements above the diagonal are 0; tiles right of the diagonal tile do not exist in LDS.
+    auto lower_chunk = [&](int i, int e, int& r, int& c) {
+        const int tj = e >> 7, rr = (e >> 3) & 15, c2 = (e & 7) * 2;
+        r = i * 16 + rr;
+        c = tj * 16 + c2;
+        d2 v = (d2){0.0, 0.0};
+        if (tj <= i) v = *reinterpret_cast<const d2*>(D + PL::tile(i, tj) + PL::in(rr, c2));
+        if (c > r) v[0] = 0.0;
+        if (c + 1 > r) v[1] = 0.0;
+        return v;
+    };
     auto export_row = [&](int i, int t) {
         for (int e = t; e < 16 * 64; e += SINK_THREADS) {
-            const int r = i * 16 + (e >> 6), c = (e & 63) * 2;
+            int r, c;
+            const d2 w = lower_chunk(i, e, r, c);
             RV2 v;
-            v[0] = (R)((c <= r) ? D[r * LDD + c] : 0.0);
-            v[1] = (R)((c + 1 <= r) ? D[r * LDD + c + 1] : 0.0);
+            v[0] = (R)w[0];
+            v[1] = (R)w[1];
             *reinterpret_cast<RV2*>(Ablk + (int64_t)r * ld + c) = v;
         }
     };
-    lds_factor_inv<decltype(export_row), true>(D, invd, Xs, 8, &s_bad, tid, export_row);
+    lds_factor_inv<decltype(export_row), true, PL>(D, invd, Xs, 8, &s_bad, tid, export_row);
     STAMP(2);
     // log-determinant partial (fixed order) from the reciprocal pivots
     if (wave < 2) {
@@ -67,20 +84,22 @@ __device__ __forceinline__ void potf2_body(double* __restrict__ smem, const int 
     STAMP(4);
     R* dinv = dinv_all + (int64_t)kblk * NB * NB;
     for (int e = tid; e < NB * NB / 2; e += NTH) {
-        const int r = e >> 6, c = (e & 63) * 2;
+        int r, c;
+        const d2 w = lower_chunk(e >> 10, e & 1023, r, c);
         RV2 v;
-        v[0] = (R)((c <= r) ? D[r * LDD + c] : 0.0);
-        v[1] = (R)((c + 1 <= r) ? D[r * LDD + c + 1] : 0.0);
+        v[0] = (R)w[0];
+        v[1] = (R)w[1];
         *reinterpret_cast<RV2*>(dinv + r * NB + c) = v;
     }
     if (dinvB_all) {
         double* dB = dinvB_all + ((int64_t)by * nb + kblk) * (NB * NB);
         for (int e = tid; e < NB * NB / 2; e += NTH) {
             const int t = e >> 10, s2 = (e >> 6) & 15, l = e & 63;
-            const int r = 16 * t + (l & 15), c = 8 * s2 + (l >> 4);
+            const int r = 16 * t + (l & 15), c = 8 * s2 + (l >> 4);     // c and c + 4 lie in the same 16-column tile
+            const double* T = D + PL::tile(t, (s2 >> 1) <= t ? (s2 >> 1) : t);
             d2 v;
-            v[0] = (c <= r) ? D[r * LDD + c] : 0.0;
-            v[1] = (c + 4 <= r) ? D[r * LDD + c + 4] : 0.0;
+            v[0] = (c <= r) ? T[PL::in(r & 15, c & 15)] : 0.0;
+            v[1] = (c + 4 <= r) ? T[PL::in(r & 15, (c + 4) & 15)] : 0.0;
             *reinterpret_cast<d2*>(dB + 2 * e) = v;
         }
     }
