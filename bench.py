@@ -90,7 +90,9 @@ def cpu_baseline(N, M, T, workload=None, full=True):
     threads = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(threads)
 
-    def sample(n, iters, predict):
+    kept = {}
+
+    def sample(n, iters, predict, keep=False):
         size = int(round(math.sqrt(n / W["frac"])))
         R, _ = lattice_image(size=size, frac=W["frac"], seed=1)
         X, Xf = O.get_sparse_grid(R), O.get_full_grid(R)
@@ -102,8 +104,13 @@ def cpu_baseline(N, M, T, workload=None, full=True):
         t_pr = None
         if predict:
             t0 = time.time()
-            rec.predict()
+            mean, sd = rec.predict()
             t_pr = time.time() - t0
+            if keep:
+                # what the timed oracle run computed: the posterior after `iters` Adam iterations from the seeded draw
+                # and the hyper-parameter history -- the headline parity check compares the engine with it
+                kept.update(mean=np.asarray(mean), sd=np.asarray(sd), iterations=iters,
+                            hyper={k: np.asarray(v) for k, v in rec.hyperparams.items()})
         return rec.X.shape[0], size * size, t_it, t_pr
 
     sample(256, 1, True)                          # thread-pool / allocator warm-up, not timed
@@ -139,7 +146,7 @@ def cpu_baseline(N, M, T, workload=None, full=True):
         avail = None
     measured = full and (avail is None or avail > 1.3 * need)
     if measured:
-        n_full, m_full, t_iter_full, t_pred_full = sample(N, 1, True)
+        n_full, m_full, t_iter_full, t_pred_full = sample(N, 1, True, keep=True)
         assert n_full == N and m_full == M, (n_full, m_full)
     else:
         t_iter_full, t_pred_full = fit_iter, fit_pred
@@ -151,7 +158,8 @@ def cpu_baseline(N, M, T, workload=None, full=True):
             % (threads, _cpu_model(), os.cpu_count(), "MEASURED" if measured else "NOT measured (host memory), fit evaluated",
                N, M, t_iter_full, t_pred_full, T,
                [(int(p[0]), int(p[1]), round(p[2], 3), round(p[3], 3)) for p in pts], fit_iter, fit_pred))
-    return {"value": M / t_full, "unit": "grid-points/s", "cores": threads, "kind": "port", "sample": text,
+    return {"_oracle_full": kept or None,
+            "value": M / t_full, "unit": "grid-points/s", "cores": threads, "kind": "port", "sample": text,
             "measured_at_full_size": bool(measured), "cpu_model": _cpu_model(), "os_cpu_count": os.cpu_count(),
             "torch_num_threads": torch.get_num_threads(),
             "s_per_iteration_full": t_iter_full, "s_per_predict_full": t_pred_full,
@@ -399,8 +407,7 @@ def main():
     for _ in range(args.warmup):
         step()
     tot, cnt = ctypes.c_double(), ctypes.c_int64()
-    # c2 runs the multi-stream look-ahead schedule, which is never graph-captured: its stage timers sit inside the
-    # timed region.  c1 / c3 replay one captured iteration per Adam step, which the timers would switch off: their
+    # c2 (large N) is enqueued launch by launch, never graph-captured: its stage timers sit inside the timed region.  c1 / c3 replay one captured iteration per Adam step, which the timers would switch off: their
     # stage breakdown comes from ONE extra step after the timed ones.
     timers_inside = args.workload == "c2"
     if lib is not None and timers_inside:
@@ -447,12 +454,18 @@ def main():
             flop per call (all `nprob_` problems of a lock-step batch), TFLOP/s, fraction of the fp64 MFMA peak and
             share of the time of the step(s) the timers covered."""
             n3 = float(n_obs) ** 3 * nprob_
-            per_call = {"potrf": n3 / 3, "trtri": n3 / 3, "lauum": n3 / 3}
-            label = {"potrf": "potrf", "trtri": "trtri", "lauum": "lauum (K^-1 = L^-T L^-1)",
-                     "predict_var": "predict_var (L^-1 K*)"}
+            # The triangular inverse rides in the launches of the factorisation (cholstep.hip: plan_inverse); the two
+            # timers are "the step launches" (timer 0) and "what is left of the inverse afterwards" (timer 1), so the
+            # stage that can be priced is their sum: 2 N^3 / 3 flop.
+            pm, pn = stage_ms["potrf"]
+            tm, tn = stage_ms["trtri"]
+            per_call = {"factor_inverse": 2 * n3 / 3, "lauum": n3 / 3}
+            label = {"factor_inverse": "potrf + trtri (L^-1 in one pass: inverse tiles hosted by the factorisation's launches)",
+                     "lauum": "lauum (K^-1 = L^-T L^-1)", "predict_var": "predict_var (L^-1 K*)"}
+            stage_ms_ = dict(stage_ms, factor_inverse=(pm + tm, pn))
             stages = []
-            for name in ("potrf", "trtri", "lauum", "predict_var"):
-                ms, n = stage_ms[name]
+            for name in ("factor_inverse", "lauum", "predict_var"):
+                ms, n = stage_ms_[name]
                 if not n:
                     continue
                 # predict_var: one launch per slab of test points, N^2*M flop per problem over all slabs of a step
@@ -461,6 +474,9 @@ def main():
                 stages.append({"stage": label[name], "calls": n, "ms_per_call": ms / n, "flop_per_call": fl,
                                "tflops": tf, "frac": tf / FP64_MFMA_PEAK_TFLOPS,
                                "share_of_step": ms / (ms_step * stage_steps)})
+                if name == "factor_inverse":
+                    stages[-1]["ms_step_launches"] = pm / pn
+                    stages[-1]["ms_after_last_step"] = tm / pn
             return stages
 
         if args.workload in ("c2", "c1"):
@@ -486,16 +502,18 @@ def main():
             pot_ms, pot_n = stage_ms["potrf"]
             traffic = None
             pmc = os.path.join(ROOT, "profiles", "pmc_lauum.json")
+            traffic_from = None
             if args.workload == "c2" and os.path.exists(pmc):
                 traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                traffic_from = "profiles/pmc_lauum.json (separate rocprofv3 --pmc passes of the same kernel; not measured by this run)"
             lauum_kernel = ("gemm_tiles_kernel<true, true, 0, 4, 128, 128>" if args.workload == "c2" else
                             "gemm_tiles_kernel<true, true, 0, 4, 64, 64> (64x64 quadrants: 561 tiles)")
             out["roofline"] = {
                 "bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_from": traffic_from,
                 "scope": "whole step: algorithmic flop (T*N^3 + 2N^3/3 + N^2*M = %.4g per GPU) / ms_per_step" % flop_step,
-                "kernel": "gemm_tiles_kernel / chol_step_kernel (fp64 MFMA tile engine, every O(N^3) stage); largest "
-                          "share of the step: the Cholesky stage",
+                "kernel": "chol_step_kernel / gemm_tiles_kernel (fp64 MFMA tile engine, every O(N^3) stage); largest "
+                          "share of the step: factorisation + inverse (chol_step_kernel launches)",
                 "stages": stages,
                 "stages_from": "the timed steps" if timers_inside else "one extra step after the timed ones (timers off "
                                "in the timed steps: they replay a captured iteration)",
@@ -522,7 +540,7 @@ def main():
             out["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
                                "scope": "whole step per GPU: (N^3/3 factorisation + N^2*M variance solves) / ms_per_step / "
-                                        "n_gpus; the variance GEMMs are rocBLAS (plain library GEMMs through torch)"}
+                                        "n_gpus; factorisation and variance solves on the MFMA tile engine (gpimhip_dist_*)"}
         else:
             mean_c, sd_c = res
             assert mean_c.shape == cube.shape and np.isfinite(mean_c).all() and np.isfinite(sd_c).all()
@@ -548,6 +566,25 @@ def main():
                 out["cpu_baseline"] = None
             elif args.workload == "c2":
                 out["cpu_baseline"] = cpu_baseline(N, M, T)
+                # The timed oracle run IS a full-size reference result: one Adam iteration from the seeded draw and the
+                # posterior on all M grid points at N = 16384.  The engine repeats exactly that (same image, same seed).
+                orc = out["cpu_baseline"].pop("_oracle_full", None)
+                if orc:
+                    rec_h = gpim_amd.reconstructor(X, R, Xf, iterations=orc["iterations"], verbose=0, seed=0, **kw)
+                    mean_h, sd_h, hyp_h = rec_h.run()
+                    rel = lambda a, b: float(np.max(np.abs(np.asarray(a, dtype=float) - np.asarray(b, dtype=float))
+                                                    / np.abs(np.asarray(b, dtype=float))))
+                    out["rmse_vs_oracle_headline"] = {
+                        "config": "the headline workload itself (C2: N=%d, M=%d, Matern52), %d Adam iteration(s) from the "
+                                  "seeded draw + predict; oracle = the full-size run timed for cpu_baseline" % (N, M, orc["iterations"]),
+                        "rmse_mean": float(np.sqrt(np.mean((mean_h - orc["mean"]) ** 2))),
+                        "rmse_sd": float(np.sqrt(np.mean((sd_h - orc["sd"]) ** 2))),
+                        "max_abs_mean": float(np.max(np.abs(mean_h - orc["mean"]))),
+                        "max_abs_sd": float(np.max(np.abs(sd_h - orc["sd"]))),
+                        "hyperparams_max_rel": max(rel(hyp_h["lengthscale"], orc["hyper"]["lengthscale"]),
+                                                   rel(hyp_h["noise"], orc["hyper"]["noise"]),
+                                                   rel(hyp_h["variance"], orc["hyper"]["variance"]))}
+                    del rec_h
             elif args.workload == "c1":
                 out["cpu_baseline"] = cpu_baseline_c1(R, T)
             else:

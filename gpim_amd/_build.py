@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgpimhip.so")
-SOURCES = ["gemm.hip", "gemm32.hip", "potf2.hip", "cholstep.hip", "cholstep32.hip", "distops.hip", "engine.hip", "smalln.hip", "vfe.hip", "kron.hip", "select.hip", "predict.hip", "api.hip"]
+SOURCES = ["gemm.hip", "gemm32.hip", "cholstep.hip", "cholstep32.hip", "distops.hip", "engine.hip", "smalln.hip", "vfe.hip", "kron.hip", "select.hip", "predict.hip", "api.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc"]
 
 

@@ -102,6 +102,8 @@ _PROTOS = {
                                              ctypes.c_double, ctypes.c_double, c_dp, c_dp, c_dp, c_dp]),
     "gpimhip_thin_batch": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_dp, ctypes.c_int32, ctypes.c_int32, c_dp,
                                           ctypes.c_double, ctypes.c_int32, c_dp, c_dp]),
+    "gpimhip_step_plan_host": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32),
+                                              ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]),
 }
 EXPORTS = tuple(_PROTOS)
 

@@ -15,7 +15,6 @@ int launch_kmat(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X, int64
                 int64_t M, const ThetaDev* theta, double diag_add, int use_theta_diag, double* out,
                 int64_t ld, int64_t rows_pad, int64_t cols_pad, int sym, int lower_only, int64_t x_bs,
                 int64_t z_bs, int64_t out_bs);
-int launch_potf2(gpimhip_ctx* h, double* A, int64_t ld, int kblk, int32_t* info);
 int launch_pad_copy(gpimhip_ctx* h, const double* src, int64_t n, double* dst, int64_t np);
 int launch_diag_inv_copy(gpimhip_ctx* h, double* A, int64_t ld, int nb);
 int launch_pad_matrix_in(gpimhip_ctx* h, const double* src, int64_t n, int64_t ld, double* dst, int64_t np);
@@ -51,22 +50,15 @@ int launch_fit_small(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X, 
 static thread_local std::string g_err;
 void gpim_set_error(const std::string& s) { g_err = s; }
 
-#define RESERVED_CUS 16
-#define LOOKAHEAD_MIN_PANELS_DEFAULT 12
 // XCD dealing chunk for lists sorted by decreasing cost: 64-tile chunks keep neighbouring tiles (shared operand
 // panels) on one XCD's L2, but a list of a few hundred tiles dealt 64 at a time puts all the longest tiles on
 // XCD 0 (N = 4206: K^-1 product 0.92 -> 0.72 ms with single-tile dealing); grow the chunk with the list.
-static int deal_chunk(int ntiles = 1 << 30) {
-    static const int v = getenv("GPIMHIP_CHUNK") ? atoi(getenv("GPIMHIP_CHUNK")) : 0;
-    if (v > 0) return v;
-    return std::max(1, std::min(64, ntiles / 512));
-}
-static int lookahead_min_panels() {
-    static const int v = getenv("GPIMHIP_LOOKAHEAD_MIN_PANELS") ? atoi(getenv("GPIMHIP_LOOKAHEAD_MIN_PANELS")) : LOOKAHEAD_MIN_PANELS_DEFAULT;
-    return v;
-}
-#define LOOKAHEAD_MIN_PANELS lookahead_min_panels()
-#define OUTER_W 4    // outer Cholesky panel = 4 x 128 columns: trailing updates run with k-depth 512
+static int deal_chunk(int ntiles = 1 << 30) { return std::max(1, std::min(64, ntiles / 512)); }
+// "large N": from 12 outer panels (6144 unknowns) on an iteration is enqueued launch by launch (below: one captured
+// iteration is replayed), its launch-chain stages are driven from the engine's high-priority stream and the two
+// mat-vecs over L^-1 run on a side stream beside the K^-1 product
+#define LOOKAHEAD_MIN_PANELS 12
+#define OUTER_W 4    // outer Cholesky panel = 4 x 128 columns
 
 // ------------------------------------------------------------------------------------------
 // workspace
@@ -162,8 +154,11 @@ static int ws_ensure_b(gpimhip_ctx* h, int64_t N, int B, int padded, bool matric
     // launch plans of the single-GPU path (built here: building one synchronises the stream, which a graph
     // capture does not allow); the distributed factorisation has its own (gpimhip_dist_setup)
     if (matrices) {
-        GP_TRY(plan_ensure(h, (int)nb));
-        if (h->dinvB) GP_TRY(step_plan_ensure(h, (int)nb));
+        int rc = plan_ensure(h, (int)nb);
+        // fit / predict invert the factor in the factorisation's launches (double precision); float matrices and
+        // gpimhip_potrf use the plain plan, which is built on first use (never inside a capture)
+        if (rc == GPIMHIP_OK) rc = h->fp32 ? step_plan_ensure(h, (int)nb) : step_plan_ensure_inv(h, (int)nb);
+        if (rc != GPIMHIP_OK) { ws_release_matrix(h); return rc; }     // (a later call must not find buffers without plans)
     }
     return GPIMHIP_OK;
 }
@@ -280,32 +275,6 @@ int plan_ensure(gpimhip_ctx* h, int nb) {
     if (P.d_tiles) { (void)hipFree(P.d_tiles); P.d_tiles = nullptr; }
     std::vector<TileDesc> tl;
     auto mark = [&](size_t start) { return PlanRange{(int64_t)start, (int32_t)(tl.size() - start)}; };
-    P.trsm.assign(nb, {0, 0});
-    P.inner.assign(nb, {0, 0});
-    P.trail.assign(nb, {0, 0});
-    P.trail_next.assign(nb, {0, 0});
-    for (int k = 0; k < nb; ++k) {
-        const int p0 = (k / OUTER_W) * OUTER_W, p1 = std::min(p0 + OUTER_W, nb);
-        size_t s = tl.size();
-        for (int i = k + 1; i < nb; ++i) tl.push_back({i, k, k, k + 1});
-        P.trsm[k] = mark(s);
-        s = tl.size();
-        for (int i = k + 1; i < nb; ++i)
-            for (int j = k + 1; j < std::min(p1, i + 1); ++j) tl.push_back({i, j, k, k + 1});
-        P.inner[k] = mark(s);
-        if (k == p1 - 1 && p1 < nb) {
-            // trailing update split for look-ahead: the columns of the NEXT outer panel first ...
-            const int q1 = std::min(p1 + OUTER_W, nb);
-            s = tl.size();
-            for (int i = p1; i < nb; ++i)
-                for (int j = p1; j < std::min(q1, i + 1); ++j) tl.push_back({i, j, p0, p1});
-            P.trail_next[k] = mark(s);
-            // ... then everything to the right of it (the bulk), 8x8-patch ordered
-            s = tl.size();
-            if (q1 < nb) lower_patch_order(tl, q1, nb, p0, p1);
-            P.trail[k] = mark(s);
-        }
-    }
     // triangular inversion, bottom-up by subtree height
     std::vector<std::vector<TriNode>> levels;
     tri_build(0, nb, levels);
@@ -377,29 +346,14 @@ static GemmArgs gemm_args(const double* A, int64_t lda, const double* B, int64_t
     return g;
 }
 
-// right-looking blocked Cholesky, lower, in place.  Per 128-column step: potf2 (+inverse) on the
-// diagonal block, panel solve as GEMM with the inverse, update of the remaining columns of the
-// current 512-wide outer panel; after the last column of an outer panel one SYRK-shaped trailing
-// update with k-depth 512 (keeps the update MFMA-bound instead of HBM-bound on the C tiles).
-//
-// Look-ahead (large N): the panel chain (potf2 -> inverse -> solve -> in-panel update, 4 small
-// launches per column) is latency-bound and would leave the chip idle, so after panel p is final the
-// work forks:
-//   panel stream (high priority): trail_next(p) [update of the next panel's columns] . panel(p+1)
-//   bulk stream  (CU-masked)    : trail_rest(p) [everything to the right of them]
-// trail_next(p) touches exactly the columns panel(p+1) factors; trail_rest(p) touches the columns to
-// the right of them, so the two streams never write the same tile.  Both join the caller's stream
-// before the next round.
 // Side streams are created on first use and then SHARED by every handle of the device for the life of the
 // process: HIP maps streams onto a few hardware queues (four by default), and which queue a new stream gets depends
-// on every stream the process has created and destroyed before.  With side streams per handle the third handle of
-// a process that needed them ran its look-ahead 4-14 ms per factorisation slower than the first (N = 16384; panel,
-// bulk or the caller's stream ending up on one queue) -- a fixed set created once keeps the mapping, and the speed,
-// independent of the process's history.  Work of different handles on a shared stream only serialises (every
+// on every stream the process has created and destroyed before -- a fixed set created once keeps the mapping, and the
+// speed, independent of the process's history.  Work of different handles on a shared stream only serialises (every
 // cross-stream dependency is an event of the handle that recorded it).  Handles that only ever run the fused
 // small-N trainer use none.
 struct SideStreams {
-    hipStream_t panel = nullptr, bulk = nullptr, capture = nullptr, chain = nullptr;
+    hipStream_t panel = nullptr, capture = nullptr, chain = nullptr;
     bool lookahead_tried = false, capture_tried = false;
 };
 static std::mutex g_side_mutex;
@@ -428,22 +382,8 @@ static void ensure_lookahead_streams(gpimhip_ctx* h) {
         // section 6).  The mechanism inside the runtime is not known to us: this is an empirical remedy, and
         // GPIMHIP_NO_CHAIN_STREAM=1 switches it off.
         if (hipStreamCreateWithPriority(&S.chain, hipStreamNonBlocking, hi) != hipSuccess) S.chain = nullptr;
-        // The bulk trailing updates run on a stream whose CU mask leaves RESERVED_CUS compute units
-        // free (the mask is interleaved over the XCDs: 16 reserved = 2 per XCD, tools/cumask_probe.hip):
-        // potf2 needs ~135 KB of LDS, i.e. a whole CU, and would otherwise wait until the bulk kernel
-        // (2 x 74 KB per CU, thousands of workgroups queued) has drained.
-        hipDeviceProp_t prop;
-        if (S.panel && hipGetDeviceProperties(&prop, h->device) == hipSuccess && !getenv("GPIMHIP_NO_CUMASK")) {
-            const int ncu = prop.multiProcessorCount;
-            std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
-            int reserved = RESERVED_CUS;
-            if (const char* e = getenv("GPIMHIP_RESERVED_CUS")) reserved = std::max(1, std::min(ncu / 2, atoi(e)));
-            for (int c = reserved; c < ncu; ++c) mask[c / 32] |= (1u << (c % 32));
-            if (hipExtStreamCreateWithCUMask(&S.bulk, (uint32_t)mask.size(), mask.data()) != hipSuccess) S.bulk = nullptr;
-        }
     }
-    h->panel_stream = S.panel;                       // null: fall back to the in-order schedule
-    h->bulk_stream = S.bulk;
+    h->panel_stream = S.panel;                       // null: the mat-vecs stay on the caller's stream
     h->chain_stream = S.chain;                       // null: the caller's stream drives every stage
 }
 // The capture stream is shared by every handle of a device: two threads fitting at the same time must not
@@ -467,140 +407,9 @@ hipStream_t ensure_capture_stream(gpimhip_ctx* h) {
     return h->capture_stream;
 }
 
-static int panel_steps(gpimhip_ctx* h, double* A, int64_t ld, int32_t* info, int p0, int p1) {
-    const LinalgPlan& P = h->plan;
-    for (int k = p0; k < p1; ++k) {
-        GP_TRY(launch_potf2(h, A, ld, k, info));
-        if (P.trsm[k].n) {
-            GemmArgs g = gemm_args(A, ld, h->dinv, NB, A, ld, 1.0, 0.0, P.d_tiles + P.trsm[k].off, P.trsm[k].n, h->np);
-            g.b_coff = -k;            // dinv is a (nb*128) x 128 matrix: block (k, 0)
-            g.inplace = 1;            // A[i,k] <- A[i,k] * Dinv^T overwrites its own operand
-            g.sB = (h->np / NB) * NB * NB;
-            GP_TRY(launch_gemm(h, false, false, EPI_STORE, g));
-        }
-        if (P.inner[k].n) {
-            GemmArgs g = gemm_args(A, ld, A, ld, A, ld, -1.0, 1.0, P.d_tiles + P.inner[k].off, P.inner[k].n, h->np);
-            GP_TRY(launch_gemm(h, false, false, EPI_STORE, g));
-        }
-    }
-    return GPIMHIP_OK;
-}
-
-// Which schedule factors a matrix: the single-stream step schedule of cholstep.hip (the launch that factors a
-// diagonal block hosts the pending column updates) for double-precision handles, the two-stream look-ahead below
-// for single-precision ones.  Measured, potrf alone, step schedule vs look-ahead: 0.51 vs 0.66 ms at N = 1280,
-// 1.86 vs 2.72 at 4224, 6.4 vs 7.05 at 8192, 10.2 vs 10.8 at 10240, 15.7 vs 16.1 at 12288, 32.1 vs 32.9 at 16384,
-// 57.9 vs 59.2 at 20480.
-// Single-precision handles run the same schedule since the end of round 3 (cholstep32.hip; GPIMHIP_F32_LOOKAHEAD=1
-// brings their two-stream look-ahead back).
-static bool use_step_schedule(const gpimhip_ctx* h, int64_t np) {
-    static const bool off = getenv("GPIMHIP_OLD_POTRF") != nullptr;
-    (void)np;
-    if (h->fp32 && getenv("GPIMHIP_F32_LOOKAHEAD")) return false;
-    return !off && h->dinvB != nullptr;
-}
-
-// Hybrid schedule (OFF by default, GPIMHIP_TAIL_BLOCKS > 0 switches it on): the two-stream look-ahead below for the
-// head of a large factorisation, where the bulk update of a round outlasts the panel chain, and the single-stream step
-// schedule for the last tail_blocks() block columns, which the head leaves fully updated.  Measured, potrf alone at
-// N = 16384 / 20480: 31.4 / 56.7 ms without it, 32.9 / 59.6 with a 48-block tail, 33.9 / 60.1 with 72, 34.6 / 61.2 with
-// 96 -- the look-ahead head (bulk on 240 CUs, k-depth 512, chain kernels competing for the rest) is slower than the
-// step schedule's in-order head with k-depth-1024 pair updates on all 256 CUs.
-static int tail_blocks() {
-    static const int v = getenv("GPIMHIP_TAIL_BLOCKS") ? atoi(getenv("GPIMHIP_TAIL_BLOCKS")) : 0;
-    return v;
-}
-static int launch_potrf_lookahead(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_t* info, int stop_panel);
-
+// The blocked Cholesky: the step schedule of cholstep.hip (float matrices: cholstep32.hip).
 int launch_potrf(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_t* info) {
-    const int nb_all = (int)(np / NB), npanel_all = (nb_all + OUTER_W - 1) / OUTER_W;
-    if (use_step_schedule(h, np)) {
-        const int tail = tail_blocks() / OUTER_W * OUTER_W;
-        if (h->nbatch == 1 && tail > 0 && nb_all - tail >= 4 * OUTER_W) {
-            ensure_lookahead_streams(h);
-            if (h->panel_stream && h->bulk_stream) {
-                const int head_panels = (nb_all - tail) / OUTER_W;
-                GP_TRY(plan_ensure(h, nb_all));
-                GP_TRY(launch_potrf_lookahead(h, A, np, ld, info, head_panels));
-                return launch_potrf_steps(h, A, np, ld, info, head_panels * OUTER_W);
-            }
-        }
-        return launch_potrf_steps(h, A, np, ld, info);
-    }
-    return launch_potrf_lookahead(h, A, np, ld, info, npanel_all);
-}
-
-// Factors the panels [0, stop_panel) and applies their updates to everything right of them.
-static int launch_potrf_lookahead(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_t* info, int stop_panel) {
-    const int nb = (int)(np / NB);
-    GP_TRY(plan_ensure(h, nb));
-    const LinalgPlan& P = h->plan;
-    const int npanel = (nb + OUTER_W - 1) / OUTER_W;
-    hipStream_t main_s = h->stream;
-    // below ~6k unknowns (12 outer panels) the trailing updates are too short to hide a panel chain
-    // behind them (measured: 9.4 vs 9.5 ms at N = 6144, 15.5 vs 16.2 at 8192, 25.8 vs 27.5 at 10240)
-    if (npanel >= LOOKAHEAD_MIN_PANELS) ensure_lookahead_streams(h);
-    const bool ahead = (h->panel_stream != nullptr) && npanel >= LOOKAHEAD_MIN_PANELS;
-    const int last = std::min(stop_panel, npanel) - 1;          // last panel this routine factors
-    while ((int)h->ev_pool.size() < 2 * npanel + 2) {
-        hipEvent_t e;
-        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        h->ev_pool.push_back(e);
-    }
-    auto evF = [&](int p) { return h->ev_pool[2 * p]; };        // panel p+1 factored (panel stream)
-    auto evB = [&](int p) { return h->ev_pool[2 * p + 1]; };    // bulk update with panel p done
-    hipEvent_t ev0 = h->ev_pool[2 * npanel];                    // panel 0 factored (caller's stream)
-    int rc = GPIMHIP_OK;
-    // panel 0 has nothing to overlap with
-    GP_TRY(panel_steps(h, A, ld, info, 0, std::min(OUTER_W, nb)));
-    for (int p = 0; p <= last && p + 1 < npanel; ++p) {
-        const bool factor_next = p + 1 <= last;
-        const int klast = std::min((p + 1) * OUTER_W, nb) - 1;      // last column of panel p
-        const int q0 = (p + 1) * OUTER_W, q1 = std::min(q0 + OUTER_W, nb);
-        GemmArgs gn = gemm_args(A, ld, A, ld, A, ld, -1.0, 1.0, P.d_tiles + P.trail_next[klast].off,
-                                P.trail_next[klast].n, h->np);
-        GemmArgs gb = gemm_args(A, ld, A, ld, A, ld, -1.0, 1.0, P.d_tiles + P.trail[klast].off, P.trail[klast].n, h->np);
-        if (!(ahead && h->bulk_stream)) {
-            // in-order schedule (small / mid N, or no side streams)
-            if (gn.ntiles) GP_TRY(launch_gemm(h, false, false, EPI_STORE, gn));
-            if (gb.ntiles) GP_TRY(launch_gemm(h, false, false, EPI_STORE, gb));
-            if (factor_next) GP_TRY(panel_steps(h, A, ld, info, q0, q1));
-            continue;
-        }
-        // Panel p is final (ev0 / evF(p-1)).  Two chains, ordered by events between the two side
-        // streams only -- the caller's stream joins once at the end, not every round (a round trip
-        // through it cost ~90 us per round):
-        //   panel stream (high priority): trail_next(p) [columns of panel p+1], then factor panel p+1.
-        //       trail_next(p) also needs bulk(p-1) done: both accumulate into the columns of panel p+1.
-        //   bulk stream (CU-masked): bulk(p) [columns right of panel p+1]; needs panel p, and follows
-        //       bulk(p-1) in stream order.
-        // bulk(p) and the panel chain of the same round write disjoint columns and only read panel p.
-        hipStream_t bs = h->bulk_stream;
-        if (p == 0) {
-            HIP_TRY(hipEventRecord(ev0, main_s));
-            HIP_TRY(hipStreamWaitEvent(h->panel_stream, ev0, 0));
-            HIP_TRY(hipStreamWaitEvent(bs, ev0, 0));
-        } else {
-            HIP_TRY(hipStreamWaitEvent(h->panel_stream, evB(p - 1), 0));
-            HIP_TRY(hipStreamWaitEvent(bs, evF(p - 1), 0));
-        }
-        h->stream = h->panel_stream;
-        rc = gn.ntiles ? launch_gemm(h, false, false, EPI_STORE, gn) : GPIMHIP_OK;
-        if (rc == GPIMHIP_OK && factor_next) rc = panel_steps(h, A, ld, info, q0, q1);
-        h->stream = main_s;
-        GP_TRY(rc);
-        HIP_TRY(hipEventRecord(evF(p), h->panel_stream));
-        h->stream = bs;
-        rc = gb.ntiles ? launch_gemm(h, false, false, EPI_STORE, gb) : GPIMHIP_OK;
-        h->stream = main_s;
-        GP_TRY(rc);
-        HIP_TRY(hipEventRecord(evB(p), bs));
-        if (p + 2 == npanel || p == last) {
-            HIP_TRY(hipStreamWaitEvent(main_s, evF(p), 0));
-            HIP_TRY(hipStreamWaitEvent(main_s, evB(p), 0));
-        }
-    }
-    return GPIMHIP_OK;
+    return launch_potrf_steps(h, A, np, ld, info, nullptr);
 }
 
 // in-place inverse of the lower-triangular factor: recursive halving, all nodes of one subtree
@@ -622,6 +431,16 @@ int launch_trtri(gpimhip_ctx* h, double* A, double* Tm, int64_t np, int64_t ld) 
     return GPIMHIP_OK;
 }
 
+// A <- L^-1 for the SPD matrix in A (Tm: np x np temporary).  Double precision: one pass -- the tile operations of the
+// inverse ride in the launches of the factorisation (cholstep.hip: plan_inverse); float matrices: factorisation, then
+// the level-by-level inverse above.
+int launch_potrf_inv(gpimhip_ctx* h, double* A, double* Tm, int64_t np, int64_t ld, int32_t* info) {
+    if (!h->fp32) return launch_potrf_steps(h, A, np, ld, info, Tm);
+    { StageTimer t(h, 0); GP_TRY(launch_potrf_steps(h, A, np, ld, info, nullptr)); }
+    StageTimer t(h, 1);
+    return launch_trtri(h, A, Tm, np, ld);
+}
+
 // B(lower) = A^T A for lower-triangular A (= L^-1): K^-1.
 int launch_lauum(gpimhip_ctx* h, const double* A, double* B, int64_t np, int64_t ld) {
     const int nb = (int)(np / NB);
@@ -632,19 +451,6 @@ int launch_lauum(gpimhip_ctx* h, const double* A, double* B, int64_t np, int64_t
     g.krev = 1;                   // ranges [ci, nb) share their end
     return launch_gemm(h, true, true, EPI_STORE, g);
 }
-
-// stage timers: 0 potrf, 1 trtri, 2 lauum (one gemm launch), 3 predictive-variance product
-struct StageTimer {
-    gpimhip_ctx* h; int stage; hipEvent_t e1 = nullptr;
-    StageTimer(gpimhip_ctx* h_, int s) : h(h_), stage(s) {
-        if (!h->timing) return;
-        hipEvent_t e0;
-        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { e1 = nullptr; return; }
-        (void)hipEventRecord(e0, h->stream);
-        h->ev[stage].push_back({e0, e1});
-    }
-    ~StageTimer() { if (e1) (void)hipEventRecord(e1, h->stream); }
-};
 
 // N <= 128: the fused single-workgroup trainer (smalln.hip) replaces the blocked path
 static bool use_small_path(int64_t N) { return N <= NB && !getenv("GPIMHIP_NO_SMALLN"); }
@@ -728,9 +534,7 @@ static int factor_at_u(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X
     GP_TRY(launch_kmat(h, m, X, N, nullptr, N, h->theta, 0.0, 1, h->A, ld, np, np, 1, 1, x_bs, x_bs, np * ld));
     ChainHop hop;
     GP_TRY(chain_hop_begin(h, np, hop));
-    int rc = GPIMHIP_OK;
-    { StageTimer t(h, 0); rc = launch_potrf(h, h->A, np, ld, h->info); }
-    if (rc == GPIMHIP_OK) { StageTimer t(h, 1); rc = launch_trtri(h, h->A, h->Tm, np, ld); }
+    const int rc = launch_potrf_inv(h, h->A, h->Tm, np, ld, h->info);
     GP_TRY(chain_hop_end(h, hop, rc));
     if (!defer_vectors) GP_TRY(solve_vectors(h, m, X, x_bs, N));
     return GPIMHIP_OK;
@@ -742,17 +546,11 @@ static int loss_grad_at_u(gpimhip_ctx* h, const gpimhip_model_t* m, const double
                           double* u, int do_adam, AdamStep st, double* loss_out, double* grad_out,
                           double* hist_row, const IterTable* tab = nullptr) {
     const int64_t np = h->np;
-    // In the look-ahead regime the panel stream exists and is idle after the factorisation: the two
-    // HBM-bound mat-vecs over L^-1 run there, next to the MFMA-bound K^-1 product (both only read L^-1).
-    // While an iteration is being CAPTURED (fit_impl, large N) the branch goes to the handle's own fork stream: the
-    // panel stream is shared by every handle of the device and may be running another handle's eager work, which a
-    // capture on it would swallow.  fit_impl creates the fork stream and the events before the capture begins.
-    bool side = (int)((np / NB + OUTER_W - 1) / OUTER_W) >= LOOKAHEAD_MIN_PANELS;
+    // Large N (never captured): the two HBM-bound mat-vecs over L^-1 run on the engine's side stream, next to the
+    // MFMA-bound K^-1 product (both only read L^-1).
+    bool side = !h->capturing && (int)((np / NB + OUTER_W - 1) / OUTER_W) >= LOOKAHEAD_MIN_PANELS;
     hipStream_t side_s = nullptr;
-    if (side && h->capturing) {
-        side_s = h->fork_stream;
-        side = side_s != nullptr && h->ev_pool.size() >= 2;
-    } else if (side) {
+    if (side) {
         ensure_lookahead_streams(h);
         while (h->ev_pool.size() < 2) {
             hipEvent_t e;
@@ -765,7 +563,7 @@ static int loss_grad_at_u(gpimhip_ctx* h, const gpimhip_model_t* m, const double
     GP_TRY(factor_at_u(h, m, X, x_bs, N, u, side));
     if (side) {
         hipStream_t main_s = h->stream;
-        hipEvent_t ev_in = h->ev_pool[0], ev_out = h->ev_pool[1];    // free again once launch_potrf has joined
+        hipEvent_t ev_in = h->ev_pool[0], ev_out = h->ev_pool[1];
         HIP_TRY(hipEventRecord(ev_in, main_s));
         HIP_TRY(hipStreamWaitEvent(side_s, ev_in, 0));
         h->stream = side_s;
@@ -876,7 +674,6 @@ int gpimhip_shutdown(void) {
     std::lock_guard<std::mutex> lock(g_side_mutex);
     for (auto& S : g_side) {
         if (S.panel) (void)hipStreamDestroy(S.panel);
-        if (S.bulk) (void)hipStreamDestroy(S.bulk);
         if (S.capture) (void)hipStreamDestroy(S.capture);
         if (S.chain) (void)hipStreamDestroy(S.chain);
         S = SideStreams();
@@ -935,7 +732,6 @@ int gpimhip_destroy(gpimhip_handle h) {
     for (auto e : h->ra_ev)
         if (e) (void)hipEventDestroy(e);
     if (h->pinned_info) (void)hipHostFree(h->pinned_info);
-    if (h->fork_stream) (void)hipStreamDestroy(h->fork_stream);
     for (auto e : h->ev_chain)
         if (e) (void)hipEventDestroy(e);
     // the other side streams belong to the process (ensure_lookahead_streams), not to the handle
@@ -1039,45 +835,16 @@ static int fit_impl(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X, i
     // Every iteration enqueues the same launches (the iteration index lives on the device), so one
     // iteration is captured into a hipGraph and replayed: ~10 us of host work per iteration instead
     // of one launch call per kernel.  Not used while stage timing is on or for very short fits.
-    // Large N (the look-ahead regime): the launch cost itself no longer matters, but a replayed graph also makes the
-    // ~600 dependent launches of an iteration independent of how the HIP runtime maps the caller's stream onto its
-    // hardware queues -- with the runtime's default of 4 queues per device, a process that holds a few more streams
-    // than that delayed every launch of the eagerly enqueued chain by ~40 us (the ~420 launches of the Cholesky at
-    // N = 16384: 29 -> 45 ms; tools/r3_single_ctx.py), while replayed iterations were unaffected.
-    // Only the step schedule (one in-order stream) can be captured there: the float engine's look-ahead schedule lives
-    // on a priority stream and a CU-masked stream, which a graph does not preserve.
-    // OPT-IN (GPIMHIP_GRAPH_LARGE=1), not the default: same bits as the eager iteration (tools/r3_graph_large_check.py),
-    // and in the shared-queue situation it restores the speed (N = 16384: 92.4 -> 74.8 ms per iteration), but the side
-    // branch (the mat-vecs over L^-1 beside the K^-1 product) loses its priority stream inside a graph and whether it
-    // still overlaps is up to the runtime's queue mapping: on a warm handle in a clean process the replayed iteration
-    // measured 7.19 / 19.98 / 45.3 / 89.0 ms at N = 6200 / 8192 / 12288 / 16384 against 7.15 / 12.96 / 34.5 / 74.3 eager
-    // (tools/r3_graph_large_cost.py).  The remedy that costs nothing is more hardware queues: GPU_MAX_HW_QUEUES=8,
-    // which the Python package asks for at import (gpim_amd/__init__.py) and INTEGRATION.md tells other hosts to set.
+    // Large N: the launch cost no longer matters and the iteration is enqueued launch by launch, its launch-chain
+    // stages on the engine's high-priority stream and the mat-vecs on a side stream (factor_at_u, loss_grad_at_u).
     const int npanel = (int)((h->np / NB + OUTER_W - 1) / OUTER_W);
     const bool large = npanel >= LOOKAHEAD_MIN_PANELS;
-    const char* gl = getenv("GPIMHIP_GRAPH_LARGE");
-    bool use_graph = T >= 8 && !h->timing && !getenv("GPIMHIP_NO_GRAPH") &&
-                     (!large || (use_step_schedule(h, h->np) && gl && atoi(gl) != 0)) &&
-                     ensure_capture_stream(h);
-    if (use_graph && large) {
-        // everything the captured iteration needs is created BEFORE the capture begins
-        if (!h->fork_stream && hipStreamCreateWithFlags(&h->fork_stream, hipStreamNonBlocking) != hipSuccess) {
-            h->fork_stream = nullptr;
-            (void)hipGetLastError();
-        }
-        while (h->ev_pool.size() < 2) {
-            hipEvent_t e;
-            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            h->ev_pool.push_back(e);
-        }
-    }
+    const bool use_graph = T >= 8 && !h->timing && !getenv("GPIMHIP_NO_GRAPH") && !large && ensure_capture_stream(h);
     if (use_graph) {
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;
         hipStream_t main_s = h->stream;
         h->stream = h->capture_stream;
-        const bool gprof = getenv("GPIMHIP_GRAPH_PROFILE") != nullptr;     // host cost of capture / instantiate, to stderr
-        const auto tp0 = std::chrono::steady_clock::now();
         capture_lock(h);
         hipError_t e = hipStreamBeginCapture(h->capture_stream, hipStreamCaptureModeRelaxed);
         int rc = GPIMHIP_OK;
@@ -1090,16 +857,7 @@ static int fit_impl(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X, i
         capture_unlock(h);
         h->stream = main_s;
         if (rc != GPIMHIP_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
-        const auto tp1 = std::chrono::steady_clock::now();
         const bool inst_ok = e == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
-        if (gprof) {
-            size_t nn = 0;
-            if (graph) (void)hipGraphGetNodes(graph, nullptr, &nn);
-            const auto tp2 = std::chrono::steady_clock::now();
-            fprintf(stderr, "gpimhip graph: np=%lld nodes=%zu capture %.2f ms instantiate %.2f ms (ok=%d)\n", (long long)h->np, nn,
-                    std::chrono::duration<double, std::milli>(tp1 - tp0).count(),
-                    std::chrono::duration<double, std::milli>(tp2 - tp1).count(), (int)inst_ok);
-        }
         if (inst_ok) {
             RunAhead ra(h, h->np);
             hipError_t le = hipSuccess;

@@ -32,47 +32,59 @@ struct StepArgs {
     double* A; int64_t ld; int kblk; int nb;
     double* dinv_all; double* dinvB_all; double* logdet; int32_t* info;
     int col_off;                // global index of the sub-matrix's first column (non-PD reporting)
-    GemmArgs g;                 // filler tiles (NT, alpha = -1, beta = 1)
+    int potf2;                  // 0: no factorisation role in this launch (hosted tiles only)
+    double* Tm;                 // != nullptr: fused inverse -- temporary of the T phases; the factorisation role writes
+                                // the INVERSE of its block into A's diagonal block (a leaf of the inverse) instead of dinv_all
+    GemmArgs g;                 // hosted tiles; trailing-update tiles are NT with alpha = -1, beta = 1
 };
 
-// blockIdx.x == 0: potf2 of block kblk; 1..7: idle (keeps filler b on XCD b % 8, which the tile engine's
-// XCD-aware list mapping assumes); >= 8: filler tile b - 8.  FTS: 128 = one workgroup per 128x128 tile,
-// 64 = one per 64x64 quadrant (few tiles: spread each over four CUs).
-// The hosted tiles run one workgroup per CU.  A ring of 3 - 6 LDS stages (the factorisation role's 134 KB are
-// reserved anyway; gemm_tile_body<..., NSTG>, build with -DGPIMHIP_STEP_RING) that keeps the loads of several
-// k-steps in flight was measured and does NOT help: potrf 1.91 vs 1.86 ms at N = 4224, 6.58 vs 6.39 at 8192,
-// 32.7 vs 32.1 at 16384 -- what a lone 8-wave workgroup lacks is not load latency cover.
-template <int FTM, int FTN>
+// blockIdx.x == 0: potf2 of block kblk; 1..7: idle (keeps hosted workgroup b on XCD b % 8, which the tile engine's
+// XCD-aware list mapping assumes); >= 8: hosted tile b - 8.  FTM x FTN: 128x128 = one workgroup per tile, 128x64 =
+// one per row half, 64x64 = one per quadrant (few tiles: spread each over four CUs).
+// A hosted tile's kind sits in bits 16.. of its kb1 field: 0 = trailing update A[ci,cj] -= L[ci,k] L[cj,k]^T; 1 / 2 =
+// T phase of the triangular inverse, Tm[ci,cj] (=|+=) A[ci,k] A[k,cj]; 3 / 4 = X phase, A[ci,cj] (=|-=) -A[ci,k] Tm[k,cj]
+// (plan_inverse below).  The factorisation role's 79 KB and 126 registers let two workgroups share a CU -- what the
+// launches that host whole rounds of deep tiles want.  ALONE = the launch declares 84 KB instead, one workgroup per CU:
+// where the chain of diagonal blocks bounds the launch, a hosted workgroup on the factorisation role's CU stretches
+// the role from 35 to 50 us (its serial fp64 chain shares the SIMD's fp64 pipe with the neighbour's MFMAs), and what
+// such a launch hosts for free is one quadrant per CU anyway.
+template <int FTM, int FTN, bool ALONE>
 __global__ __launch_bounds__(NTH, 4) void chol_step_kernel(StepArgs a) {
-#ifdef GPIMHIP_STEP_RING
-    constexpr int NSTG = (FTM == 128 && FTN == 128) ? 3 : (FTM == 128 ? 4 : 6);
-#else
-    constexpr int NSTG = 2;
-#endif
-    constexpr int SM = POTF2_SMEM_DOUBLES > gemm_smem_doubles<FTM, FTN, NSTG>() ? POTF2_SMEM_DOUBLES
-                                                                                : gemm_smem_doubles<FTM, FTN, NSTG>();
-    static_assert(SM * 8 <= 160 * 1024, "LDS");
+    constexpr int SM0 = POTF2_SMEM_DOUBLES > gemm_smem_doubles<FTM, FTN, 2>() ? POTF2_SMEM_DOUBLES : gemm_smem_doubles<FTM, FTN, 2>();
+    static_assert(SM0 * 8 <= 80 * 1024, "two workgroups per CU");
+    constexpr int SM = ALONE ? 84 * 128 : SM0;
     __shared__ __attribute__((aligned(16))) double smem[SM];
     const int b = blockIdx.x;
     if (b >= 8) {
-        gemm_tile_body<false, false, EPI_STORE, 8, FTM, FTN, NSTG>(a.g, b - 8, (int)blockIdx.y, smem);
+        int quad;
+        const int pos = gemm_tile_pos<FTM, FTN>(a.g.ntiles, a.g.chunk, b - 8, quad);
+        TileDesc t = a.g.tiles[pos];
+        const int kind = t.kb1 >> 16;
+        t.kb1 &= 0xffff;
+        if (kind == 0) {
+            gemm_tile_core<false, false, EPI_STORE, 8, FTM, FTN>(a.g, t, quad, (int)blockIdx.y, smem);
+        } else {
+            GemmArgs g = a.g;
+            if (kind <= 2) { g.C = a.Tm; g.alpha = 1.0; g.beta = kind == 2 ? 1.0 : 0.0; }
+            else { g.B = a.Tm; g.alpha = -1.0; g.beta = kind == 4 ? 1.0 : 0.0; }
+            gemm_tile_core<false, true, EPI_STORE, 8, FTM, FTN>(g, t, quad, (int)blockIdx.y, smem);
+        }
         return;
     }
-    if (b != 0) return;
-    potf2_body<double>(smem, (int)blockIdx.y, a.A, a.ld, a.kblk, a.dinv_all, a.dinvB_all, a.logdet, a.info, a.nb, a.col_off);
+    if (b != 0 || !a.potf2) return;
+    potf2_body<double>(smem, (int)blockIdx.y, a.A, a.ld, a.kblk, a.dinv_all, a.dinvB_all, a.logdet, a.info, a.nb, a.col_off,
+                       a.Tm != nullptr);
 }
 
 // Panel solve, one workgroup (4 waves) per 32-row strip of the block column below the diagonal block:
 // S = P * Dinv^T, in place.  Wave w owns the 16-column tiles w and 7 - w of the strip (Dinv is lower triangular:
 // tile t needs k-steps 0 .. 4t+3, so every wave runs 36 of them per 16 rows).
-// ROWS = rows of one workgroup's strip: 32, or 16 (twice the workgroups, half the MFMA chain per wave: the kernel is
-// latency-bound, and the inverse it re-reads per workgroup comes out of L2).  Measured: 16 and 64 are both slower than
-// 32 (potrf at N = 4212: 1.694 / 1.647 / 1.783 ms, at 16384: 29.65 / 28.96 / 29.60); GPIMHIP_STRIP16=1 selects 16.
-template <int ROWS>
+// (Strips of 16 and of 64 rows were measured in round 3: both slower than 32 -- potrf at N = 4212: 1.694 / 1.647 /
+// 1.783 ms, at 16384: 29.65 / 28.96 / 29.60 -- the launch is bound by its load latency and by re-reading the inverse.)
 __global__ __launch_bounds__(256) void panel_solve_kernel(double* __restrict__ A, int64_t ld, int kblk, int nb,
                                                           const double* __restrict__ dinvB_all) {
     constexpr int LDS_LD = 130;             // 130 % 32 == 2: the A-fragment reads below are bank-conflict free
-    constexpr int MTS = ROWS / 16;
+    constexpr int ROWS = 32, MTS = ROWS / 16;
     __shared__ __attribute__((aligned(16))) double S[ROWS * LDS_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     A += (int64_t)blockIdx.y * nb * NB * ld;
@@ -179,50 +191,21 @@ static void lower_patches(std::vector<TileDesc>& out, int lo, int hi, int kb0, i
                     if (j <= i) out.push_back({i, j, kb0, kb1});
 }
 
-static bool pair_mode(int nb, bool fp32) {
-    static const int v = getenv("GPIMHIP_PAIR") ? atoi(getenv("GPIMHIP_PAIR")) : -1;
-    if (v >= 0) return v != 0;
-    // float matrices (tools/r3_f32_sweep2.sh): pairs lose up to N = 16384 (17.70 vs 17.33 ms), draw at 20480 (30.6 / 30.8)
-    if (fp32) return nb >= 160;
-    return nb >= 112;     // N = 16384: 32.2 -> 31.4 ms, 20480: 57.9 -> 57.3; no gain at 8192 / 12288
-}
+// Hosting policy of single-precision handles (cholstep32.hip; tools/r3_f32_sweep2.sh): a hosted float tile takes half
+// the matrix-core time beside a factorisation role of unchanged length.  Everything is hosted up to nb = 87, 128 tiles
+// per launch beyond (64 in pair mode), the rest of a panel's bulk update runs as a tile-engine launch before the
+// panel's first step; pair mode (panels applied two at a time, k-depth 1024) from nb = 160.
+static bool pair_mode32(int nb) { return nb >= 160; }
+static int fill_cap32(int nb) { return pair_mode32(nb) ? 64 : (nb < 88 ? (1 << 30) : 128); }
 
-// Share of the previous panel's bulk update hosted by one step launch: at most this many tiles; what is left runs
-// as a plain tile-engine launch before the panel's first step.  Hosted tiles run one workgroup per CU (the 134 KB
-// factorisation role sets the launch's LDS size), 7 % slower than in their own launch (two per CU): up to
-// nb = 63 everything is hosted (the factorisation is bound by the chain of diagonal blocks, hosted tiles are
-// free), beyond that 32 tiles per launch (N = 16384: 32.1 ms with 0 / 32 / 128, 34.0 with everything hosted;
-// N = 10240: 10.6 / 10.2 / 10.8 / 10.6).
-// Float matrices: a hosted tile takes half the matrix-core time while the factorisation role (double) lasts as long
-// as ever, so more is hosted: everything up to nb = 87 (potrf at N = 6400 / 8192 / 10240: 2.65 / 4.04 / 6.23 ms; with
-// 64 tiles per launch 2.72 / 4.19 / 6.42), 128 tiles per launch beyond (12288: 9.10 vs 9.25 (64) / 9.35 (all);
-// 16384: 17.33 vs 17.68 / 18.58), tools/r3_f32_sweep2.sh.
-static int fill_cap(int nb, bool fp32) {
-    static const int v = getenv("GPIMHIP_FILL_CAP") ? atoi(getenv("GPIMHIP_FILL_CAP")) : -1;
-    if (v >= 0) return v;
-    if (pair_mode(nb, fp32)) return fp32 ? 64 : 0;   // fp64: hosted k-depth-1024 tiles would outlast the factorisation role by far
-    if (fp32) return nb < 88 ? (1 << 30) : 128;
-    return nb < 64 ? (1 << 30) : 32;
-}
-
-// ---- hosting plan for double-precision matrices of nb >= 64 block columns -------------------------------------
-// Everything the trailing matrix receives from panels older than the window is HOSTED by the step launches (two
-// workgroups per CU since the factorisation role fits 79 KB).  What a launch hosts is chosen so that it ends on a
-// full round of the chip's 512 workgroup slots:
-//   * tile (i, jj) keeps the first block column it has not yet received (`pend`); a flush applies [pend, p0) in ONE
-//     tile operation, so a tile that is skipped for a panel comes back twice as deep (k = 1024: half the
-//     read-modify-write passes over C, half the prologues -- what r3's "pair mode" did for whole panels);
-//   * tiles of the NEXT panel's columns must be flushed during this panel (deadline), the others are optional;
-//   * steady state: the two patch classes ((i / 8 + jj / 8) & 1) take turns, each flushed every other panel at depth
-//     8 -- every panel carries the same amount of work -- and the holes of a launch's last round are filled with
-//     whatever else is pending (list scheduling on 512 slots, the order the hardware dispatches workgroups in).
-// Below 64 remaining block columns a panel's updates are less than one round per launch: the chain of diagonal
-// blocks bounds the factorisation and everything pending is flushed at once, evenly over the panel's launches.
+// List scheduling on the chip's workgroup slots, the order the hardware dispatches the workgroups of a launch in
+// (512 slots: two 8-wave workgroups per CU).  Costs in units of one 128-deep k-block of a 128x128 tile per slot
+// (~34 us at two workgroups per CU; the factorisation role lasts ~1.1).
 struct HostSim {
     std::vector<double> slot;       // min-heap of slot finish times
     double makespan = 0.0;
     explicit HostSim(int S) : slot(S, 0.0) {}
-    static double cost(const TileDesc& t) { return (t.kb1 - t.kb0) + 0.5; }     // k-blocks + prologue / epilogue
+    static double cost(const TileDesc& t) { return ((t.kb1 & 0xffff) - t.kb0) + 0.5; }     // k-blocks + prologue / epilogue
     double peek() const { return slot.front(); }
     void add(double c) {
         std::pop_heap(slot.begin(), slot.end(), std::greater<double>());
@@ -231,14 +214,61 @@ struct HostSim {
         std::push_heap(slot.begin(), slot.end(), std::greater<double>());
     }
 };
+#define HOST_SLOTS 512
+// one hosted workgroup of a tile operation `depth` k-blocks deep in shape q (4: 64x64 quadrant, 2: 128x64 half, 1: whole
+// tile), from kernel traces at two workgroups per CU: quadrants 8 + 6 depth us, whole tiles 34 us per k-block
+static double wg_cost(int depth, int q) { return q == 4 ? 0.18 * depth + 0.24 : (q == 2 ? 0.34 * depth + 0.3 : depth + 0.5); }
 
-static void step_plan_hosted(int nb, std::vector<TileDesc>& tl, StepPlan& P) {
-    const int W = STEP_W, S = 512;
-    auto mark = [&](size_t start) { return PlanRange{(int64_t)start, (int32_t)(tl.size() - start)}; };
+// ---- what the step launches host of the TRAILING UPDATE (double precision) -------------------------------------------
+// nb < 64: the chain of diagonal blocks bounds the factorisation; every launch hosts its column update and a quarter
+// of the previous panel's bulk update (k-depth 512) -- the round-3 lists, unchanged.
+// nb >= 64: everything is hosted as well (two workgroups per CU since the factorisation role fits 79 KB), and what a
+// launch hosts is chosen so that it ends on a full round of the 512 slots:
+//   * tile (i, jj) keeps the first block column it has not yet received (`pend`); a flush applies [pend, p0) in ONE
+//     tile operation, so a tile that is skipped for a panel comes back twice as deep (k = 1024: half the
+//     read-modify-write passes over C, half the prologues -- what round 3's "pair mode" did for whole panels);
+//   * tiles of the NEXT panel's columns must be flushed during this panel (deadline), the others are optional;
+//   * steady state: the two patch classes ((i / 8 + jj / 8) & 1) take turns, each flushed every other panel at depth
+//     8 -- every panel carries the same amount of work -- and the holes of a launch's last round are filled with
+//     whatever else is pending;
+//   * once fewer than 64 block columns remain a panel's updates are less than one round per launch and everything
+//     pending is flushed at once, evenly over the panel's launches.
+static void plan_updates(int nb, std::vector<std::vector<TileDesc>>& fill) {
+    const int W = STEP_W, S = HOST_SLOTS;
     const int npanel = (nb + W - 1) / W;
+    auto by_depth = [](const TileDesc& a, const TileDesc& b) { return (a.kb1 - a.kb0) > (b.kb1 - b.kb0); };
+    // Column update of block column j = p0 + t of panel [p0, p1) where the chain of diagonal blocks bounds the launch:
+    // every hosted tile at most 4 k-blocks deep, so that none outlasts the factorisation role.  The previous panel's
+    // contribution to column j (k-depth 4) is final one launch before the column's own panel contributes its last
+    // block, so it rides one launch earlier (columns p0, p0 + 1: in the panel's first launch) and the launch of
+    // column j itself only applies the panel's own t <= 3 blocks.
+    auto col_split = [&](std::vector<TileDesc>& tl, int p0, int p1, int j) {
+        const int t = j - p0;
+        if (t >= 1)
+            for (int i = j + 1; i < nb; ++i) tl.push_back({i, j, p0, j});
+        if (p0 == 0) return;
+        if (t == 0)
+            for (int i = j + 1; i < nb; ++i) tl.push_back({i, j, p0 - W, p0});
+        if (j + 1 < p1)
+            for (int i = j + 2; i < nb; ++i) tl.push_back({i, j + 1, p0 - W, p0});
+    };
+    if (nb < 64) {
+        for (int p = 0; p < npanel; ++p) {
+            const int p0 = p * W, p1 = std::min(p0 + W, nb), ncol = p1 - p0;
+            std::vector<TileDesc> bulk;
+            if (p > 0 && p0 + W < nb) lower_patches(bulk, p0 + W, nb, p0 - W, p0);
+            const size_t per = (bulk.size() + ncol - 1) / ncol;
+            size_t taken = 0;
+            for (int j = p0; j < p1; ++j) {
+                col_split(fill[j], p0, p1, j);
+                for (size_t q = 0; q < per && taken < bulk.size(); ++q) fill[j].push_back(bulk[taken++]);
+            }
+        }
+        return;
+    }
     std::vector<int> pend((size_t)nb * nb, 0);        // first source block column tile (i, jj) has not received via bulk
     for (int p = 0; p < npanel; ++p) {
-        const int p0 = p * W, p1 = std::min(p0 + W, nb), ncol = p1 - p0;
+        const int p0 = p * W, p1 = std::min(p0 + W, nb);
         const int rem = nb - p0 - W;
         std::vector<TileDesc> req, opt;
         if (p > 0 && rem > 0) {
@@ -249,26 +279,26 @@ static void step_plan_hosted(int nb, std::vector<TileDesc>& tl, StepPlan& P) {
             for (auto& t : opt) t.kb0 = pend[(size_t)t.ci * nb + t.cj];
         }
         const bool bulk_regime = rem >= 64;
+        auto due = [&](const TileDesc& t) { return (t.kb1 - t.kb0) >= 2 * W || (((t.ci >> 3) + (t.cj >> 3)) & 1) == (p & 1); };
+        double due_cost = 0.0;                 // cost of the due tiles not yet hosted
+        size_t n_due = 0;
         if (bulk_regime) {
-            // due first (deepest first), then the rest; both in patch order
-            auto due = [&](const TileDesc& t) { return (t.kb1 - t.kb0) >= 2 * W || (((t.ci >> 3) + (t.cj >> 3)) & 1) == (p & 1); };
+            // due first (deepest first), then the rest; each group in patch order
             std::stable_sort(opt.begin(), opt.end(), [&](const TileDesc& a, const TileDesc& b) {
                 const int da = due(a), db = due(b);
                 if (da != db) return da > db;
-                return (a.kb1 - a.kb0) > (b.kb1 - b.kb0);
+                return da ? by_depth(a, b) : false;
             });
-        }
-        double due_cost = 0.0;                 // cost of the due tiles not yet hosted
-        size_t n_due = 0;
-        if (bulk_regime)
             for (auto& t : opt)
-                if ((t.kb1 - t.kb0) >= 2 * W || (((t.ci >> 3) + (t.cj >> 3)) & 1) == (p & 1)) { ++n_due; due_cost += HostSim::cost(t); }
+                if (due(t)) { ++n_due; due_cost += HostSim::cost(t); }
+        }
         size_t rtaken = 0, otaken = 0;
         for (int j = p0; j < p1; ++j) {
             const int left = p1 - j;
-            size_t s = tl.size();
+            std::vector<TileDesc>& tl = fill[j];
             const int kb0 = std::max(0, p0 - W);
-            if (j > kb0)
+            if (!bulk_regime) col_split(tl, p0, p1, j);
+            else if (j > kb0)
                 for (int i = j + 1; i < nb; ++i) tl.push_back({i, j, kb0, j});
             const size_t nreq = (req.size() - rtaken + left - 1) / left;
             for (size_t q = 0; q < nreq; ++q) tl.push_back(req[rtaken++]);
@@ -278,13 +308,11 @@ static void step_plan_hosted(int nb, std::vector<TileDesc>& tl, StepPlan& P) {
             } else {
                 HostSim sim(S);
                 sim.add(1.0);                                               // the factorisation role
-                std::stable_sort(tl.begin() + s, tl.end(), [](const TileDesc& a, const TileDesc& b) {
-                    return (a.kb1 - a.kb0) > (b.kb1 - b.kb0); });
-                for (size_t q = s; q < tl.size(); ++q) sim.add(HostSim::cost(tl[q]));
+                std::stable_sort(tl.begin(), tl.end(), by_depth);
+                double base = 0.0;
+                for (auto& t : tl) { sim.add(HostSim::cost(t)); base += HostSim::cost(t); }
                 // This launch's length: its share of the due work, rounded to whole deep tiles per slot (a slot runs
                 // a sequence of tiles; 8.5 = one tile of depth 8) and never shorter than what it must host anyway.
-                double base = 0.0;
-                for (size_t q = s; q < tl.size(); ++q) base += HostSim::cost(tl[q]);
                 const double per_slot = (base + due_cost / left) / S;
                 const double target = std::max(sim.makespan, 8.5 * std::max(1.0, std::floor(per_slot / 8.5 + 0.5)));
                 double got = 0.0;
@@ -298,73 +326,184 @@ static void step_plan_hosted(int nb, std::vector<TileDesc>& tl, StepPlan& P) {
                 due_cost -= std::min(due_cost, got);
             }
             // dispatch order = list order: deepest tiles first
-            std::stable_sort(tl.begin() + s, tl.end(), [](const TileDesc& a, const TileDesc& b) {
-                return (a.kb1 - a.kb0) > (b.kb1 - b.kb0); });
-            for (size_t q = s; q < tl.size(); ++q)
-                if (tl[q].cj != j) pend[(size_t)tl[q].ci * nb + tl[q].cj] = tl[q].kb1;
-            P.fill[j] = mark(s);
-            s = tl.size();
-            for (int jj = j + 1; jj < std::min(nb, p1 + W); ++jj) tl.push_back({jj, jj, j, j + 1});
-            P.diag[j] = mark(s);
+            std::stable_sort(tl.begin(), tl.end(), by_depth);
+            for (auto& t : tl)
+                if (t.cj >= p0 + W) pend[(size_t)t.ci * nb + t.cj] = t.kb1;
         }
     }
 }
 
-static int step_plan_build(gpimhip_ctx* h, int nb, StepPlan& P) {
+// ---- the triangular inverse as hosted work -----------------------------------------------------------------------------
+// X = L^-1 by recursive halving: node [lo, mid, hi) needs  T = L21 X11  (T phase; Tm[ci, cj] = sum_{k in [cj, mid)}
+// L[ci, k] X[k, cj], ci in [mid, hi), cj in [lo, mid)) and then  X21 = -X22 T  (X phase; A[ci, cj] = -sum_{k in [mid, ci]}
+// X[ci, k] Tm[k, cj], in place of L21).  The leaves are the inverses of the diagonal blocks, which the factorisation
+// role writes into A's diagonal blocks itself.  Instead of 2 log2(nb) launches AFTER the factorisation, the tile
+// operations of a node are handed to the step launches as soon as their operands are final:
+//   T phase of a node: block columns < mid factored and solved (launch index >= mid) and the left child inverted;
+//   X phase: T phase complete, the right child inverted, block rows < hi dead for the factorisation (index >= hi).
+// A step launch that the chain of diagonal blocks bounds (most of them at mid-size N, the last third at N = 16384)
+// has idle workgroup slots for about the length of the factorisation role: it hosts chunks of <= 4 k-blocks (one chunk
+// of a tile per launch, accumulated into the output across launches) up to that length.  What is left when the
+// factorisation ends -- the X phases of the nodes that contain the last block column, and most of the root's work at
+// large N -- runs as a few launches of the same kernel without the factorisation role.
+enum { TK_UPDATE = 0, TK_T_FIRST = 1, TK_T_ACC = 2, TK_X_FIRST = 3, TK_X_ACC = 4 };
+struct TriOp { int ci, cj, k0, k1, kp; };
+struct TriNodeS {
+    int lo, mid, hi, left, right, height;
+    int t_done = 1 << 30, x_done = 1 << 30;     // launch index that issues the last chunk of the phase
+    std::vector<TriOp> T, X;
+    size_t t_open = 0, x_open = 0;
+};
+static int tri_nodes(int lo, int hi, std::vector<TriNodeS>& nodes) {
+    TriNodeS n;
+    n.lo = lo; n.hi = hi; n.mid = lo; n.left = n.right = -1; n.height = 0;
+    if (hi - lo <= 1) {
+        n.t_done = n.x_done = lo;               // the factorisation role of launch `lo` writes the block's inverse
+        nodes.push_back(n);
+        return (int)nodes.size() - 1;
+    }
+    n.mid = lo + (hi - lo + 1) / 2;
+    n.left = tri_nodes(lo, n.mid, nodes);
+    n.right = tri_nodes(n.mid, hi, nodes);
+    n.height = 1 + std::max(nodes[n.left].height, nodes[n.right].height);
+    for (int cj = lo; cj < n.mid; ++cj)         // longest k-ranges first
+        for (int ci = n.mid; ci < hi; ++ci) n.T.push_back({ci, cj, cj, n.mid, cj});
+    for (int ci = hi - 1; ci >= n.mid; --ci)
+        for (int cj = lo; cj < n.mid; ++cj) n.X.push_back({ci, cj, n.mid, ci + 1, n.mid});
+    n.t_open = n.T.size();
+    n.x_open = n.X.size();
+    nodes.push_back(n);
+    return (int)nodes.size() - 1;
+}
+
+// shape of a step launch's hosted workgroups by the k-blocks of trailing update it hosts (times the batch):
+// 4 = 64x64 quadrants (the work of a chain-bound launch spread over the chip), 2 = 128x64 halves, 1 = whole tiles.
+// (Round 3 drew the lines at 128 / 512 tiles of average depth 5; tools/r3_exp*.sh.)
+static int host_shape(int64_t update_kblocks) { return update_kblocks <= 700 ? 4 : (update_kblocks <= 2800 ? 2 : 1); }
+
+static void plan_inverse(int nb, std::vector<std::vector<TileDesc>>& fill, std::vector<std::vector<TileDesc>>& post) {
+    std::vector<TriNodeS> nodes;
+    tri_nodes(0, nb, nodes);
+    std::vector<int> order(nodes.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return nodes[a].height < nodes[b].height; });
+    size_t open_nodes = 0;
+    for (auto& n : nodes) open_nodes += (n.height > 0);
+    const double CHAIN = 1.1;                   // length of the factorisation role in cost units
+    for (int L = 0; open_nodes > 0; ++L) {
+        const bool hosted = L < nb;
+        if (!hosted) post.emplace_back();
+        std::vector<TileDesc>& out = hosted ? fill[L] : post.back();
+        int64_t upd = 0;
+        for (auto& t : out) upd += t.kb1 - t.kb0;
+        const int q = hosted ? host_shape(upd) : 1;
+        const int cd = !hosted ? (1 << 20) : 4;
+        // quadrants / halves: what a chain-bound launch hosts for free is about ONE workgroup per CU (traces at
+        // N = 4212: up to ~250 quadrant workgroups leave the launch at the factorisation role's 35 us, 400 make it 50)
+        HostSim sim(q == 1 ? HOST_SLOTS : HOST_SLOTS / 2);
+        double target = 1e30;
+        if (hosted) {
+            sim.add(CHAIN);
+            for (auto& t : out)
+                for (int w = 0; w < q; ++w) sim.add(wg_cost(t.kb1 - t.kb0, q));
+            target = std::max(sim.makespan, CHAIN);
+        }
+        bool full = false;
+        for (int idx : order) {
+            TriNodeS& n = nodes[idx];
+            if (n.height == 0 || n.x_open == 0 || full) continue;
+            const bool t_phase = n.t_open > 0;
+            if (t_phase ? !(nodes[n.left].x_done < L && n.mid <= L) : !(n.t_done < L && nodes[n.right].x_done < L && n.hi <= L)) continue;
+            std::vector<TriOp>& ops = t_phase ? n.T : n.X;
+            size_t& open = t_phase ? n.t_open : n.x_open;
+            for (auto& o : ops) {
+                if (o.kp >= o.k1) continue;
+                int depth = std::min(o.k1 - o.kp, cd);
+                if (hosted) {
+                    // the deepest chunk that still ends with the launch
+                    while (depth >= 1 && sim.peek() + wg_cost(depth, q) > target + 0.02) --depth;
+                    if (depth < 1) { full = true; break; }
+                }
+                const int k1 = o.kp + depth;
+                const double c = wg_cost(depth, q);
+                for (int w = 0; w < q; ++w) sim.add(c);
+                const int kind = t_phase ? (o.kp == o.k0 ? TK_T_FIRST : TK_T_ACC) : (o.kp == o.k0 ? TK_X_FIRST : TK_X_ACC);
+                out.push_back({o.ci, o.cj, o.kp, k1 | (kind << 16)});
+                o.kp = k1;
+                if (o.kp >= o.k1 && --open == 0) {
+                    if (t_phase) n.t_done = L;
+                    else { n.x_done = L; --open_nodes; }
+                }
+            }
+        }
+        if (!hosted && out.empty()) post.pop_back();      // (dependencies only resolve across launches)
+        if (L > nb + 4 * 64) break;                        // cannot happen: every launch completes at least one phase
+    }
+}
+
+static int step_plan_build(gpimhip_ctx* h, int nb, StepPlan& P, bool with_inverse) {
     const bool fp32 = h->fp32 != 0;
     if (P.nb == nb && P.fp32 == (int)fp32) return GPIMHIP_OK;
     if (P.d_tiles) { (void)hipFree(P.d_tiles); P.d_tiles = nullptr; }
     const int W = STEP_W;
+    const int npanel = (nb + W - 1) / W;
+    std::vector<std::vector<TileDesc>> fill(nb), post, rest(npanel);
+    if (!fp32) {
+        plan_updates(nb, fill);
+    } else {
+        for (int p = 0; p < npanel; ++p) {
+            const int p0 = p * W, p1 = std::min(p0 + W, nb), ncol = p1 - p0;
+            // bulk(p-1): columns >= p0 + W, k-blocks = the columns of panel p-1.
+            // Pair mode (large matrices): panels are applied two at a time to everything at least two panels to their
+            // right -- k-depth 1024, half the passes over the trailing matrix -- and an even panel alone only to the
+            // one destination panel that needs it before its partner is factored:
+            //   start of an odd panel p  (p-1 even): panel p-1 -> destination panel p+1 only           (k-depth 512)
+            //   start of an even panel p (p-1 odd) : panels p-2, p-1 -> every column >= p0 + W          (k-depth 1024)
+            std::vector<TileDesc> bulk;
+            if (p > 0 && p0 + W < nb) {
+                if (!pair_mode32(nb)) {
+                    lower_patches(bulk, p0 + W, nb, p0 - W, p0);
+                } else if ((p - 1) % 2 == 0) {
+                    const int c0 = p0 + W, c1 = std::min(p0 + 2 * W, nb);
+                    for (int ig = c0 / 8; ig <= (nb - 1) / 8; ++ig)
+                        for (int i = std::max(c0, ig * 8); i < std::min(nb, ig * 8 + 8); ++i)
+                            for (int j = c0; j < std::min(c1, i + 1); ++j) bulk.push_back({i, j, p0 - W, p0});
+                } else {
+                    lower_patches(bulk, p0 + W, nb, p0 - 2 * W, p0);
+                }
+            }
+            const size_t per = std::min<size_t>((size_t)fill_cap32(nb), (bulk.size() + ncol - 1) / ncol);
+            size_t taken = 0;
+            for (int j = p0; j < p1; ++j) {
+                const int kb0 = std::max(0, p0 - W);
+                if (j > kb0)
+                    for (int i = j + 1; i < nb; ++i) fill[j].push_back({i, j, kb0, j});
+                for (size_t q = 0; q < per && taken < bulk.size(); ++q) fill[j].push_back(bulk[taken++]);
+            }
+            while (taken < bulk.size()) rest[p].push_back(bulk[taken++]);
+        }
+    }
+    P.n_update.assign(nb, 0);
+    for (int j = 0; j < nb; ++j)
+        for (auto& t : fill[j]) P.n_update[j] += t.kb1 - t.kb0;
+    if (with_inverse) plan_inverse(nb, fill, post);
     std::vector<TileDesc> tl;
-    auto mark = [&](size_t start) { return PlanRange{(int64_t)start, (int32_t)(tl.size() - start)}; };
+    auto put = [&](const std::vector<TileDesc>& v) {
+        PlanRange r{(int64_t)tl.size(), (int32_t)v.size()};
+        tl.insert(tl.end(), v.begin(), v.end());
+        return r;
+    };
     P.fill.assign(nb, {0, 0});
     P.diag.assign(nb, {0, 0});
-    const int npanel = (nb + W - 1) / W;
     P.bulk_rest.assign(npanel, {0, 0});
-    static const bool old_plan = getenv("GPIMHIP_OLD_PLAN") != nullptr;
-    if (!fp32 && nb >= 64 && !old_plan) {
-        step_plan_hosted(nb, tl, P);
-    } else
-    for (int p = 0; p < npanel; ++p) {
-        const int p0 = p * W, p1 = std::min(p0 + W, nb), ncol = p1 - p0;
-        // bulk(p-1): columns >= p0 + W, k-blocks = the columns of panel p-1.
-        // Pair mode (large matrices): panels are applied two at a time to everything at least two panels to their
-        // right -- k-depth 1024, half the passes over the trailing matrix -- and an even panel alone only to the one
-        // destination panel that needs it before its partner is factored:
-        //   start of an odd panel p  (p-1 even): panel p-1 -> destination panel p+1 only           (k-depth 512)
-        //   start of an even panel p (p-1 odd) : panels p-2, p-1 -> every column >= p0 + W          (k-depth 1024)
-        // Each destination panel Q still receives every source panel S <= Q-2 exactly once here and S >= Q-1 through
-        // the left-looking column updates / diagonal updates below.
-        std::vector<TileDesc> bulk;
-        if (p > 0 && p0 + W < nb) {
-            if (!pair_mode(nb, fp32)) {
-                lower_patches(bulk, p0 + W, nb, p0 - W, p0);
-            } else if ((p - 1) % 2 == 0) {
-                const int c0 = p0 + W, c1 = std::min(p0 + 2 * W, nb);
-                for (int ig = c0 / 8; ig <= (nb - 1) / 8; ++ig)
-                    for (int i = std::max(c0, ig * 8); i < std::min(nb, ig * 8 + 8); ++i)
-                        for (int j = c0; j < std::min(c1, i + 1); ++j) bulk.push_back({i, j, p0 - W, p0});
-            } else {
-                lower_patches(bulk, p0 + W, nb, p0 - 2 * W, p0);
-            }
-        }
-        const int per = std::min<int>(fill_cap(nb, fp32), (int)((bulk.size() + ncol - 1) / ncol));
-        size_t taken = 0;
-        for (int j = p0; j < p1; ++j) {
-            size_t s = tl.size();
-            const int kb0 = std::max(0, p0 - W);
-            if (j > kb0)
-                for (int i = j + 1; i < nb; ++i) tl.push_back({i, j, kb0, j});
-            for (int q = 0; q < per && taken < bulk.size(); ++q) tl.push_back(bulk[taken++]);
-            P.fill[j] = mark(s);
-            s = tl.size();
-            for (int jj = j + 1; jj < std::min(nb, p1 + W); ++jj) tl.push_back({jj, jj, j, j + 1});
-            P.diag[j] = mark(s);
-        }
-        size_t s = tl.size();
-        while (taken < bulk.size()) tl.push_back(bulk[taken++]);
-        P.bulk_rest[p] = mark(s);
+    P.post.clear();
+    for (int j = 0; j < nb; ++j) {
+        P.fill[j] = put(fill[j]);
+        const int p1 = std::min((j / W) * W + W, nb);
+        P.diag[j] = PlanRange{0, std::max(0, std::min(nb, p1 + W) - (j + 1))};     // the next diagonal tiles (count only)
     }
+    for (int p = 0; p < npanel; ++p) P.bulk_rest[p] = put(rest[p]);
+    for (auto& v : post) P.post.push_back(put(v));
     P.n_tiles = (int64_t)tl.size();
     void* q = nullptr;
     HIP_TRY(hipMalloc(&q, std::max<size_t>(tl.size(), 1) * sizeof(TileDesc)));
@@ -376,11 +515,34 @@ static int step_plan_build(gpimhip_ctx* h, int nb, StepPlan& P) {
     return GPIMHIP_OK;
 }
 
-int step_plan_ensure(gpimhip_ctx* h, int nb) { return step_plan_build(h, nb, h->splan); }
-int step_plan_ensure_tail(gpimhip_ctx* h, int nb) { return step_plan_build(h, nb, h->splan_tail); }
+// The double-precision plan as host data, for tests (no GPU involved): records of six int32 -- launch index (< nb: the
+// step launch of that block column; >= nb: the launches after the last step), ci, cj, kb0, kb1, kind.
+extern "C" int gpimhip_step_plan_host(int32_t nb, int32_t with_inverse, int32_t* out, int64_t cap, int64_t* n_out) {
+    if (nb < 1 || nb > 4096 || !n_out) return GPIMHIP_E_BADARG;
+    std::vector<std::vector<TileDesc>> fill(nb), post;
+    plan_updates(nb, fill);
+    if (with_inverse) plan_inverse(nb, fill, post);
+    int64_t n = 0;
+    auto emit = [&](int launch, const std::vector<TileDesc>& v) {
+        for (const TileDesc& t : v) {
+            if (out && n < cap) {
+                int32_t* r = out + 6 * n;
+                r[0] = launch; r[1] = t.ci; r[2] = t.cj; r[3] = t.kb0; r[4] = t.kb1 & 0xffff; r[5] = t.kb1 >> 16;
+            }
+            ++n;
+        }
+    };
+    for (int j = 0; j < nb; ++j) emit(j, fill[j]);
+    for (size_t q = 0; q < post.size(); ++q) emit(nb + (int)q, post[q]);
+    *n_out = n;
+    return GPIMHIP_OK;
+}
+
+int step_plan_ensure(gpimhip_ctx* h, int nb) { return step_plan_build(h, nb, h->splan, false); }
+int step_plan_ensure_inv(gpimhip_ctx* h, int nb) { return step_plan_build(h, nb, h->splan_inv, true); }
 
 void step_plan_release(gpimhip_ctx* h) {
-    for (StepPlan* P : {&h->splan, &h->splan_tail}) {
+    for (StepPlan* P : {&h->splan, &h->splan_inv}) {
         if (P->d_tiles) (void)hipFree(P->d_tiles);
         P->d_tiles = nullptr;
         P->nb = 0;
@@ -396,70 +558,73 @@ static GemmArgs nt_update(double* A, int64_t ld, const TileDesc* tiles, int n, i
     return g;
 }
 
-// lower Cholesky of the np x np matrix A (np = nb * 128), in place, on h->stream; h->dinv / h->dinvB / h->logdet_part
-// receive the inverses of the diagonal blocks and the log-determinant partials like the in-order driver of api.hip.
-// blk_off > 0: the trailing sub-matrix that starts at block (blk_off, blk_off) -- a Schur complement the caller has
-// brought up to date with every column left of it (hybrid schedule of api.hip: look-ahead head, step-schedule tail).
-int launch_potrf_steps_f32(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_t* info, int blk_off);   // cholstep32.hip
-int launch_potrf_steps(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_t* info, int blk_off) {
-    if (h->fp32) return launch_potrf_steps_f32(h, A, np, ld, info, blk_off);
-    const int nb = (int)(np / NB) - blk_off, W = STEP_W;
-    if (blk_off) GP_TRY(step_plan_ensure_tail(h, nb));
-    else GP_TRY(step_plan_ensure(h, nb));
-    const StepPlan& P = blk_off ? h->splan_tail : h->splan;
-    A += (int64_t)blk_off * NB * (ld + 1);
-    double* const dinv = h->dinv + (int64_t)blk_off * NB * NB;
-    double* const dinvB = h->dinvB + (int64_t)blk_off * NB * NB;
-    double* const logdet = h->logdet_part + blk_off;
+// one launch of the step kernel: `potf2` = with the factorisation role for block a.kblk, n hosted tiles in shape q
+static int launch_step(gpimhip_ctx* h, StepArgs& a, bool potf2, int n, int q) {
     const int B = h->nbatch;
-    static const int quad_max = getenv("GPIMHIP_FILL_QUAD_MAX") ? atoi(getenv("GPIMHIP_FILL_QUAD_MAX")) : 128;
-    static const int half_max = getenv("GPIMHIP_FILL_HALF_MAX") ? atoi(getenv("GPIMHIP_FILL_HALF_MAX")) : 512;
-    static const bool old_diag = getenv("GPIMHIP_OLD_DIAG") != nullptr;
-    static const int host_max_batch = getenv("GPIMHIP_HOST_MAX_BATCH") ? atoi(getenv("GPIMHIP_HOST_MAX_BATCH")) : 4;
-    static const int strip16_env = getenv("GPIMHIP_STRIP16") ? atoi(getenv("GPIMHIP_STRIP16")) : -1;
-    const bool strip16 = strip16_env >= 0 ? strip16_env != 0 : false;
-    for (int j = 0; j < nb; ++j) {
-        if (j % W == 0 && P.bulk_rest[j / W].n) {
-            GemmArgs g = nt_update(A, ld, P.d_tiles + P.bulk_rest[j / W].off, P.bulk_rest[j / W].n, h->np);
-            GP_TRY(launch_gemm(h, false, false, EPI_STORE, g));
-        }
-        StepArgs a;
-        a.A = A; a.ld = ld; a.kblk = j; a.nb = nb;
-        a.dinv_all = dinv; a.dinvB_all = dinvB; a.logdet = logdet; a.info = info;
-        a.col_off = blk_off * NB;
-        a.g = nt_update(A, ld, P.d_tiles + P.fill[j].off, P.fill[j].n, h->np);
-        const int nf = P.fill[j].n;
-        // mixed k-ranges (column updates are up to 2W-1 blocks deep, bulk tiles W): deal the list to the XCDs in chunks
-        static const int host_chunk = getenv("GPIMHIP_HOST_CHUNK") ? atoi(getenv("GPIMHIP_HOST_CHUNK")) : 0;
-        a.g.chunk = host_chunk > 0 ? host_chunk : std::max(1, std::min(64, nf / 512));
-        if (B > host_max_batch) {
-            // large batches saturate the chip by themselves: the pending tiles run as their own launch (two to four
-            // workgroups per CU) in front of a factorisation-only step launch.  Same tile operations in the same
-            // order per output element as the hosted form, hence the same bits as a stand-alone problem.
-            if (nf) GP_TRY(launch_gemm(h, false, false, EPI_STORE, a.g));
-            hipLaunchKernelGGL((chol_step_kernel<64, 64>), dim3(1, B), dim3(NTH), 0, h->stream, a);
-        } else if ((int64_t)nf * B <= quad_max)
-            hipLaunchKernelGGL((chol_step_kernel<64, 64>), dim3(nf ? 8 + 4 * nf : 1, B), dim3(NTH), 0, h->stream, a);
-        else if ((int64_t)nf * B <= half_max)
-            hipLaunchKernelGGL((chol_step_kernel<128, 64>), dim3(8 + 2 * nf, B), dim3(NTH), 0, h->stream, a);
-        else
-            hipLaunchKernelGGL((chol_step_kernel<128, 128>), dim3(8 + nf, B), dim3(NTH), 0, h->stream, a);
-        HIP_TRY(hipGetLastError());
-        if (j + 1 < nb) {
-            if (strip16)
-                hipLaunchKernelGGL(panel_solve_kernel<16>, dim3(8 * (nb - j - 1), B), dim3(256), 0, h->stream, A, ld, j, nb,
-                                   (const double*)dinvB);
-            else
-                hipLaunchKernelGGL(panel_solve_kernel<32>, dim3(4 * (nb - j - 1), B), dim3(256), 0, h->stream, A, ld, j, nb,
-                                   (const double*)dinvB);
-            HIP_TRY(hipGetLastError());
-            if (old_diag) {
-                GemmArgs g = nt_update(A, ld, P.d_tiles + P.diag[j].off, P.diag[j].n, h->np);
-                GP_TRY(launch_gemm(h, false, false, EPI_STORE, g));
+    a.potf2 = potf2 ? 1 : 0;
+    if (!potf2 && n == 0) return GPIMHIP_OK;
+    const dim3 grid(n ? 8 + q * n : 1, B);
+    if (q == 4 && potf2) hipLaunchKernelGGL((chol_step_kernel<64, 64, true>), grid, dim3(NTH), 0, h->stream, a);
+    else if (q == 4) hipLaunchKernelGGL((chol_step_kernel<64, 64, false>), grid, dim3(NTH), 0, h->stream, a);
+    else if (q == 2) hipLaunchKernelGGL((chol_step_kernel<128, 64, false>), grid, dim3(NTH), 0, h->stream, a);
+    else hipLaunchKernelGGL((chol_step_kernel<128, 128, false>), grid, dim3(NTH), 0, h->stream, a);
+    HIP_TRY(hipGetLastError());
+    return GPIMHIP_OK;
+}
+
+// Lower Cholesky of the np x np matrix A (np = nb * 128), in place, on h->stream; h->dinvB / h->logdet_part receive the
+// inverses of the diagonal blocks (MFMA operand order) and the log-determinant partials.
+// Tm == nullptr: A <- L, h->dinv <- the inverses of the diagonal blocks (gpimhip_potrf, the distributed driver).
+// Tm != nullptr: A <- L^-1 (every training iteration and prediction inverts the factor right away, gpr.py:192-193,248):
+//                the tile operations of the triangular inverse ride in the step launches (plan_inverse), Tm is the
+//                np x np temporary of its T phases.
+int launch_potrf_steps_f32(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_t* info);   // cholstep32.hip
+int launch_potrf_steps(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_t* info, double* Tm) {
+    if (h->fp32) return launch_potrf_steps_f32(h, A, np, ld, info);
+    const int nb = (int)(np / NB), W = STEP_W;
+    if (Tm) GP_TRY(step_plan_ensure_inv(h, nb));
+    else GP_TRY(step_plan_ensure(h, nb));
+    const StepPlan& P = Tm ? h->splan_inv : h->splan;
+    const int B = h->nbatch;
+    const int host_max_batch = 4;
+    StepArgs a;
+    a.A = A; a.ld = ld; a.nb = nb; a.Tm = Tm;
+    a.dinv_all = h->dinv; a.dinvB_all = h->dinvB; a.logdet = h->logdet_part; a.info = info;
+    a.col_off = 0;
+    {
+        StageTimer t(h, 0);
+        for (int j = 0; j < nb; ++j) {
+            a.kblk = j;
+            const int nf = P.fill[j].n;
+            a.g = nt_update(A, ld, P.d_tiles + P.fill[j].off, nf, h->np);
+            // mixed k-ranges (column updates are up to 2W-1 blocks deep, bulk tiles W or 2W): deal the list to the XCDs in chunks
+            a.g.chunk = std::max(1, std::min(64, nf / 512));
+            const int q = host_shape((int64_t)P.n_update[j] * B);
+            if (B > host_max_batch) {
+                // large batches saturate the chip by themselves: the pending tiles run as their own launch in front of a
+                // factorisation-only step launch.  Same tile operations in the same order per output element as the
+                // hosted form, hence the same bits as a stand-alone problem.
+                GP_TRY(launch_step(h, a, false, nf, host_shape((int64_t)P.n_update[j])));
+                GP_TRY(launch_step(h, a, true, 0, 4));
             } else {
+                GP_TRY(launch_step(h, a, true, nf, q));
+            }
+            if (j + 1 < nb) {
+                hipLaunchKernelGGL(panel_solve_kernel, dim3(4 * (nb - j - 1), B), dim3(256), 0, h->stream, A, ld, j, nb,
+                                   (const double*)h->dinvB);
+                HIP_TRY(hipGetLastError());
                 hipLaunchKernelGGL(diag_update_kernel, dim3(10 * P.diag[j].n, B), dim3(256), 0, h->stream, A, ld, j, nb);
                 HIP_TRY(hipGetLastError());
             }
+        }
+    }
+    if (Tm) {
+        StageTimer t(h, 1);
+        a.kblk = -1;
+        for (const PlanRange& r : P.post) {
+            a.g = nt_update(A, ld, P.d_tiles + r.off, r.n, h->np);
+            a.g.chunk = std::max(1, std::min(64, r.n / 512));
+            GP_TRY(launch_step(h, a, false, r.n, r.n * B <= 128 ? 4 : (r.n * B <= 512 ? 2 : 1)));
         }
     }
     return GPIMHIP_OK;
@@ -472,21 +637,18 @@ int launch_potrf_steps(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_
 int launch_panel_chain(gpimhip_ctx* h, double* A, int64_t ld, int p0, int p1, int nb, const TileDesc* tiles,
                        const PlanRange* colfill, int32_t* info) {
     const int B = h->nbatch;
+    StepArgs a;
+    a.A = A; a.ld = ld; a.nb = nb; a.Tm = nullptr;
+    a.dinv_all = h->dinv; a.dinvB_all = h->dinvB; a.logdet = h->logdet_part; a.info = info;
+    a.col_off = 0;
     for (int j = p0; j < p1; ++j) {
-        StepArgs a;
-        a.A = A; a.ld = ld; a.kblk = j; a.nb = nb;
-        a.dinv_all = h->dinv; a.dinvB_all = h->dinvB; a.logdet = h->logdet_part; a.info = info;
-        a.col_off = 0;
+        a.kblk = j;
         const PlanRange f = colfill[j - p0];
         a.g = nt_update(A, ld, tiles + f.off, f.n, h->np);
         a.g.chunk = 1;
-        if (f.n <= 128)
-            hipLaunchKernelGGL((chol_step_kernel<64, 64>), dim3(f.n ? 8 + 4 * f.n : 1, B), dim3(NTH), 0, h->stream, a);
-        else
-            hipLaunchKernelGGL((chol_step_kernel<128, 64>), dim3(8 + 2 * f.n, B), dim3(NTH), 0, h->stream, a);
-        HIP_TRY(hipGetLastError());
+        GP_TRY(launch_step(h, a, true, f.n, f.n <= 128 ? 4 : 2));
         if (j + 1 < nb) {
-            hipLaunchKernelGGL(panel_solve_kernel<32>, dim3(4 * (nb - j - 1), B), dim3(256), 0, h->stream, A, ld, j, nb,
+            hipLaunchKernelGGL(panel_solve_kernel, dim3(4 * (nb - j - 1), B), dim3(256), 0, h->stream, A, ld, j, nb,
                                (const double*)h->dinvB);
             HIP_TRY(hipGetLastError());
         }

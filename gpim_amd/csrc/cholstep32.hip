@@ -154,9 +154,6 @@ __global__ __launch_bounds__(256) void diag_update_kernel_f32(float* __restrict_
 // ------------------------------------------------------------------------------------------
 // host side (plans: cholstep.hip)
 // ------------------------------------------------------------------------------------------
-int step_plan_ensure(gpimhip_ctx* h, int nb);
-int step_plan_ensure_tail(gpimhip_ctx* h, int nb);
-
 static GemmArgs nt_update32(double* A, int64_t ld, const TileDesc* tiles, int n, int64_t rows) {
     GemmArgs g;
     memset(&g, 0, sizeof(g));
@@ -167,20 +164,15 @@ static GemmArgs nt_update32(double* A, int64_t ld, const TileDesc* tiles, int n,
 }
 
 // launch_potrf_steps of cholstep.hip for a single-precision handle: A is a float matrix behind its double* type
-int launch_potrf_steps_f32(gpimhip_ctx* h, double* A_, int64_t np, int64_t ld, int32_t* info, int blk_off) {
-    const int nb = (int)(np / NB) - blk_off, W = 4;
-    if (blk_off) GP_TRY(step_plan_ensure_tail(h, nb));
-    else GP_TRY(step_plan_ensure(h, nb));
-    const StepPlan& P = blk_off ? h->splan_tail : h->splan;
-    float* A = reinterpret_cast<float*>(A_) + (int64_t)blk_off * NB * (ld + 1);
-    float* const dinv = reinterpret_cast<float*>(h->dinv) + (int64_t)blk_off * NB * NB;
-    double* const dinvB = h->dinvB + (int64_t)blk_off * NB * NB;
-    double* const logdet = h->logdet_part + blk_off;
+int launch_potrf_steps_f32(gpimhip_ctx* h, double* A_, int64_t np, int64_t ld, int32_t* info) {
+    const int nb = (int)(np / NB), W = 4;
+    GP_TRY(step_plan_ensure(h, nb));
+    const StepPlan& P = h->splan;
+    float* A = reinterpret_cast<float*>(A_);
+    float* const dinv = reinterpret_cast<float*>(h->dinv);
     double* const Ad = reinterpret_cast<double*>(A);
     const int B = h->nbatch;
-    static const int quad_max = getenv("GPIMHIP_FILL_QUAD_MAX") ? atoi(getenv("GPIMHIP_FILL_QUAD_MAX")) : 128;
-    static const int half_max = getenv("GPIMHIP_FILL_HALF_MAX") ? atoi(getenv("GPIMHIP_FILL_HALF_MAX")) : 512;
-    static const int host_max_batch = getenv("GPIMHIP_HOST_MAX_BATCH") ? atoi(getenv("GPIMHIP_HOST_MAX_BATCH")) : 4;
+    const int quad_max = 128, half_max = 512, host_max_batch = 4;
     for (int j = 0; j < nb; ++j) {
         if (j % W == 0 && P.bulk_rest[j / W].n) {
             GemmArgs g = nt_update32(Ad, ld, P.d_tiles + P.bulk_rest[j / W].off, P.bulk_rest[j / W].n, h->np);
@@ -188,8 +180,8 @@ int launch_potrf_steps_f32(gpimhip_ctx* h, double* A_, int64_t np, int64_t ld, i
         }
         StepArgs32 a;
         a.A = A; a.ld = ld; a.kblk = j; a.nb = nb;
-        a.dinv_all = dinv; a.dinvB_all = dinvB; a.logdet = logdet; a.info = info;
-        a.col_off = blk_off * NB;
+        a.dinv_all = dinv; a.dinvB_all = h->dinvB; a.logdet = h->logdet_part; a.info = info;
+        a.col_off = 0;
         a.g = nt_update32(Ad, ld, P.d_tiles + P.fill[j].off, P.fill[j].n, h->np);
         const int nf = P.fill[j].n;
         a.g.chunk = std::max(1, std::min(64, nf / 512));
@@ -205,7 +197,7 @@ int launch_potrf_steps_f32(gpimhip_ctx* h, double* A_, int64_t np, int64_t ld, i
         HIP_TRY(hipGetLastError());
         if (j + 1 < nb) {
             hipLaunchKernelGGL(panel_solve_kernel_f32, dim3(4 * (nb - j - 1), B), dim3(256), 0, h->stream, A, ld, j, nb,
-                               (const double*)dinvB);
+                               (const double*)h->dinvB);
             HIP_TRY(hipGetLastError());
             hipLaunchKernelGGL(diag_update_kernel_f32, dim3(10 * P.diag[j].n, B), dim3(256), 0, h->stream, A, ld, j, nb);
             HIP_TRY(hipGetLastError());

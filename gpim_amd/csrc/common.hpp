@@ -55,18 +55,13 @@ struct AdamStep {
     double beta1, beta2, eps;
 };
 
-// A cached launch plan: tile lists for every GEMM-like launch of potrf/trtri/lauum at a given nb.
+// A cached launch plan: tile lists of the level-by-level triangular inverse and of the K^-1 product at a given nb.
 struct PlanRange { int64_t off; int32_t n; };
 
 struct LinalgPlan {
     int nb = 0;
     TileDesc* d_tiles = nullptr;          // device copy of all tile lists
     int64_t n_tiles = 0;
-    // potrf
-    std::vector<PlanRange> trsm;          // per inner step k
-    std::vector<PlanRange> inner;         // per inner step k (may be empty)
-    std::vector<PlanRange> trail;         // per inner step k: non-empty only at the last column of an outer panel
-    std::vector<PlanRange> trail_next;    // ditto: the part of that update that feeds the next panel
     // trtri: per level two launches
     std::vector<PlanRange> tri_t, tri_x;
     // lauum
@@ -78,10 +73,14 @@ struct LinalgPlan {
 // left of the previous panel's bulk update.
 struct StepPlan {
     int nb = 0;
-    int fp32 = 0;                       // hosting policy the lists were built for (cholstep.hip: pair_mode / fill_cap)
+    int fp32 = 0;                       // hosting policy the lists were built for (cholstep.hip)
     TileDesc* d_tiles = nullptr;
     int64_t n_tiles = 0;
-    std::vector<PlanRange> fill, diag, bulk_rest;
+    std::vector<PlanRange> fill;        // per block column: what its step launch hosts
+    std::vector<PlanRange> diag;        // per block column: .n = diagonal tiles updated after its panel solve
+    std::vector<PlanRange> bulk_rest;   // per outer panel: bulk update launched before its first step (float handles)
+    std::vector<PlanRange> post;        // fused inverse: what is left of it after the last step, launch by launch
+    std::vector<int32_t> n_update;      // per block column: k-blocks of trailing update among fill[] (sets the hosted shape)
 };
 
 // Launch plans of the distributed (block-column-cyclic, 1 x P) factorisation for one rank (api.hip: gpimhip_dist_*)
@@ -101,11 +100,9 @@ struct DistPlan {
 struct gpimhip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t panel_stream = nullptr;   // high-priority side stream for the Cholesky panel chain
+    hipStream_t panel_stream = nullptr;   // high-priority side stream: the two mat-vecs over L^-1 beside the K^-1 product (large N)
     hipStream_t capture_stream = nullptr; // internal stream used only to capture one iteration into a hipGraph
     bool side_streams_tried = false, capture_stream_tried = false;   // side streams are created on first use
-    hipStream_t bulk_stream = nullptr;    // CU-masked stream for the bulk trailing updates (look-ahead)
-    hipStream_t fork_stream = nullptr;    // this handle's own: the side branch of a CAPTURED large-N iteration (never runs eagerly)
     hipStream_t chain_stream = nullptr;   // high-priority stream that drives the large-N factorisation and inverse (api.hip)
     hipEvent_t ev_chain[2] = {nullptr, nullptr};   // hop onto the chain stream and back
     bool capturing = false;               // fit_impl is recording one iteration into a hipGraph
@@ -142,7 +139,7 @@ struct gpimhip_ctx {
     int64_t pred_ntiles = 0;
     int64_t bytes = 0;
     LinalgPlan plan;
-    StepPlan splan, splan_tail;     // whole matrix / the trailing sub-matrix of the hybrid schedule
+    StepPlan splan, splan_inv;      // factorisation alone / with the triangular inverse riding in its launches
     DistPlan dplan;
     // optional stage timing (bench.py): HIP event pairs on the handle's stream
     bool timing = false;
@@ -180,15 +177,29 @@ struct gpimhip_ctx {
 
 static inline int64_t pad_to(int64_t n, int64_t m) { return (n + m - 1) / m * m; }
 
+// stage timers (bench.py): 0 factorisation (with the part of the inverse its launches host), 1 rest of the triangular
+// inverse, 2 K^-1 product (one tile-engine launch), 3 predictive-variance product
+struct StageTimer {
+    gpimhip_ctx* h; int stage; hipEvent_t e1 = nullptr;
+    StageTimer(gpimhip_ctx* h_, int s) : h(h_), stage(s) {
+        if (!h->timing) return;
+        hipEvent_t e0;
+        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { e1 = nullptr; return; }
+        (void)hipEventRecord(e0, h->stream);
+        h->ev[stage].push_back({e0, e1});
+    }
+    ~StageTimer() { if (e1) (void)hipEventRecord(e1, h->stream); }
+};
+
 // ---- drivers shared between translation units ----
 int ws_ensure(gpimhip_ctx* h, int64_t N);
 int ws_ensure_predict(gpimhip_ctx* h, int64_t np, int64_t mc);
 int plan_ensure(gpimhip_ctx* h, int nb);
 // cholstep.hip
-int launch_potrf_steps(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_t* info, int blk_off = 0);
-int step_plan_ensure_tail(gpimhip_ctx* h, int nb);
+int launch_potrf_steps(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_t* info, double* Tm = nullptr);
 void step_plan_release(gpimhip_ctx* h);
 int step_plan_ensure(gpimhip_ctx* h, int nb);
+int step_plan_ensure_inv(gpimhip_ctx* h, int nb);
 int launch_panel_chain(gpimhip_ctx* h, double* A, int64_t ld, int p0, int p1, int nb, const TileDesc* tiles,
                        const PlanRange* colfill, int32_t* info);
 // distops.hip

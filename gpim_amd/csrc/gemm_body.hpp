@@ -125,8 +125,45 @@ __host__ __device__ constexpr int gemm_smem_doubles() {
     constexpr int TSX = TSM > TSN ? TSM : TSN;
     return 2 * NSTG * ((TSX * LD_MK > GEMM_BK * (TSX + 16)) ? TSX * LD_MK : GEMM_BK * (TSX + 16));
 }
+// XCD-aware bijective remap of a launch's workgroup index to a position of its tile list (block b runs on XCD
+// b % 8, in order b / 8 on that XCD).
+//  chunk == 0: every XCD gets one contiguous slice of the tile list -- best L2 reuse when all
+//              tiles cost the same (SYRK-shaped trailing updates).
+//  chunk  > 0: the list is dealt to the XCDs in chunks of that many tiles (one 8x8 patch), back
+//              and forth, so lists sorted by decreasing k-range stay balanced across XCDs.
+template <int TSM, int TSN>
+__device__ __forceinline__ int gemm_tile_pos(int n, int chunk, int bx, int& quad) {
+    constexpr int QUADS = (128 / TSM) * (128 / TSN);    // workgroups per 128x128 tile
+    const int b = bx / QUADS;
+    quad = bx % QUADS;
+    if (QUADS > 1) return b;
+    if (chunk == 0) {
+        const int q = n >> 3, r = n & 7, x = b & 7, yy = b >> 3;
+        return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + yy;
+    }
+    const int C = chunk, full = (n / (8 * C)) * (8 * C);
+    if (b < full) {
+        // serpentine: odd rounds deal in reverse, so that on a list sorted by cost no XCD always
+        // gets the most expensive chunk of the round (16 % spread between XCD 0 and 7 otherwise)
+        const int x = b & 7, y = b >> 3, round = y / C;
+        return (round * 8 + ((round & 1) ? 7 - x : x)) * C + (y % C);
+    }
+    return b;
+}
+
+template <bool A_KM, bool B_KM, int EPI, int NW, int TSM, int TSN, int NSTG = 2>
+__device__ __forceinline__ void gemm_tile_core(GemmArgs g, TileDesc t, const int quad, const int by, double* __restrict__ smem);
+
 template <bool A_KM, bool B_KM, int EPI, int NW, int TSM, int TSN, int NSTG = 2>
 __device__ __forceinline__ void gemm_tile_body(GemmArgs g, const int bx, const int by, double* __restrict__ smem) {
+    int quad;
+    const int p = gemm_tile_pos<TSM, TSN>(g.ntiles, g.chunk, bx, quad);
+    gemm_tile_core<A_KM, B_KM, EPI, NW, TSM, TSN, NSTG>(g, g.tiles[p], quad, by, smem);
+}
+
+// one tile (or its quadrant / half `quad`) of a tile-engine launch
+template <bool A_KM, bool B_KM, int EPI, int NW, int TSM, int TSN, int NSTG>
+__device__ __forceinline__ void gemm_tile_core(GemmArgs g, TileDesc t, const int quad, const int by, double* __restrict__ smem) {
     constexpr int NT = NW * 64;             // threads
     constexpr int WGM = NW / 2;             // waves along m (2 along n)
     constexpr int WROWS = TSM / WGM;        // rows per wave
@@ -141,33 +178,7 @@ __device__ __forceinline__ void gemm_tile_body(GemmArgs g, const int bx, const i
     constexpr bool ADIR = TSM == 128 || !A_KM, BDIR = TSN == 128 || !B_KM;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-
-    // XCD-aware bijective remap (block b runs on XCD b%8, in order b/8 on that XCD).
-    //  chunk == 0: every XCD gets one contiguous slice of the tile list -- best L2 reuse when all
-    //              tiles cost the same (SYRK-shaped trailing updates).
-    //  chunk  > 0: the list is dealt to the XCDs in chunks of that many tiles (one 8x8 patch), back
-    //              and forth, so lists sorted by decreasing k-range stay balanced across XCDs.
     constexpr int QN = 128 / TSN;                       // workgroups per tile along n
-    constexpr int QUADS = (128 / TSM) * QN;             // workgroups per 128x128 tile
-    const int n = g.ntiles, b = bx / QUADS, quad = bx % QUADS;
-    int p;
-    if (QUADS > 1) {
-        p = b;
-    } else if (g.chunk == 0) {
-        const int q = n >> 3, r = n & 7, x = b & 7, yy = b >> 3;
-        p = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + yy;
-    } else {
-        const int C = g.chunk, full = (n / (8 * C)) * (8 * C);
-        if (b < full) {
-            // serpentine: odd rounds deal in reverse, so that on a list sorted by cost no XCD always
-            // gets the most expensive chunk of the round (16 % spread between XCD 0 and 7 otherwise)
-            const int x = b & 7, y = b >> 3, round = y / C;
-            p = (round * 8 + ((round & 1) ? 7 - x : x)) * C + (y % C);
-        } else {
-            p = b;
-        }
-    }
-    TileDesc t = g.tiles[p];
     if (g.cj_max > 0 && t.cj >= g.cj_max) return;   // (the whole workgroup: t is uniform)
     const int ccb = g.cmap ? t.kb0 : t.cj;          // block column of the output (see GemmArgs::cmap)
     if (g.kfix1 > g.kfix0) { t.kb0 = g.kfix0; t.kb1 = g.kfix1; }

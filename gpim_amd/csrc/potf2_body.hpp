@@ -12,7 +12,8 @@
 #endif
 
 // A: matrix (row-major, ld); kblk: which diagonal block; by: problem of a batch.
-// dinv_all[kblk] <- inverse of the factored block (ld 128, zeros above the diagonal).
+// dinv_all[kblk] <- inverse of the factored block (ld 128, zeros above the diagonal); with inv_to_A the inverse
+// replaces the block of L in A instead (the caller inverts the whole factor: cholstep.hip, plan_inverse).
 // logdet_out[kblk] = sum_i log L_ii.  info: 1 + first failing global column (set once).
 // dinvB_all (optional): the same inverse once more in the B-operand order of the f64 MFMA for the product
 // S = P * Dinv^T of the panel solve (cholstep.hip): dinvB[t][s2][lane][e] = Dinv[16 t + (lane & 15)][8 s2 + 4 e + (lane >> 4)],
@@ -25,7 +26,7 @@ template <typename R>
 __device__ __forceinline__ void potf2_body(double* __restrict__ smem, const int by, R* __restrict__ A, int64_t ld, int kblk,
                                            R* __restrict__ dinv_all, double* __restrict__ dinvB_all,
                                            double* __restrict__ logdet_out, int32_t* __restrict__ info, int nb PROF_ARG,
-                                           int col_off = 0) {
+                                           int col_off = 0, bool inv_to_A = false) {
     double* D = smem;
     double* invd = D + PL::DOUBLES;
     double* Xs = invd + NB;
@@ -82,14 +83,16 @@ __device__ __forceinline__ void potf2_body(double* __restrict__ smem, const int 
     }
     STAMP(3);
     STAMP(4);
-    R* dinv = dinv_all + (int64_t)kblk * NB * NB;
+    // the inverse of the block: into dinv_all[kblk], or (fused inverse: a leaf of L^-1) over the block itself
+    R* dinv = inv_to_A ? Ablk : dinv_all + (int64_t)kblk * NB * NB;
+    const int64_t ldinv = inv_to_A ? ld : NB;
     for (int e = tid; e < NB * NB / 2; e += NTH) {
         int r, c;
         const d2 w = lower_chunk(e >> 10, e & 1023, r, c);
         RV2 v;
         v[0] = (R)w[0];
         v[1] = (R)w[1];
-        *reinterpret_cast<RV2*>(dinv + r * NB + c) = v;
+        *reinterpret_cast<RV2*>(dinv + r * ldinv + c) = v;
     }
     if (dinvB_all) {
         double* dB = dinvB_all + ((int64_t)by * nb + kblk) * (NB * NB);

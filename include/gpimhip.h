@@ -324,8 +324,17 @@ int gpimhip_thin_batch(gpimhip_handle h, const double* vals, const int64_t* flat
                        const int64_t* shape, double dscale, int32_t max_out, int32_t* keep_out,
                        int32_t* nkeep_out);
 
+/* The launch plan of the factorisation (and of the triangular inverse riding in its launches, with_inverse != 0) for a
+ * double-precision matrix of nb block columns, as HOST data -- no device involved; for tests that replay the schedule
+ * on small blocks (tests/test_step_plan.py).  Records of six int32 in `out` (capacity `cap` records): launch index
+ * (< nb: the step launch that factors that block column; >= nb: the launches after the last step), ci, cj, kb0, kb1,
+ * kind (0: A[ci,cj] -= sum_k L[ci,k] L[cj,k]^T; 1 / 2: Tm[ci,cj] (=|+=) sum_k A[ci,k] A[k,cj]; 3 / 4: A[ci,cj] (=|-=)
+ * -sum_k A[ci,k] Tm[k,cj]; k over block columns [kb0, kb1)).  *n_out = number of records of the plan. */
+int gpimhip_step_plan_host(int32_t nb, int32_t with_inverse, int32_t* out, int64_t cap, int64_t* n_out);
+
 /* Stage timing for bench.py (HIP events on the handle's stream, recorded only while enabled).
- * stage: 0 = Cholesky (all launches of one factorisation), 1 = triangular inverse,
+ * stage: 0 = Cholesky (all launches of one factorisation, including the tile operations of the triangular inverse
+ *            they host), 1 = what is left of the triangular inverse after the last step,
  *        2 = K^-1 = L^-T L^-1 (exactly one gemm_tiles_kernel<true,true,0> launch, N^3/3 flop),
  *        3 = predictive-variance product L^-1 K(X,X*) (one launch per test-point slab).
  * gpimhip_timing_read synchronises, returns the summed milliseconds and the number of timed

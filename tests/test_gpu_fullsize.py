@@ -89,6 +89,30 @@ def test_c2_size_factorisation_identity(gpim):
     H.close()
 
 
+def test_c2_headline_vs_oracle_full_size(gpim):
+    """The headline workload itself (C2: 256x256 lattice image, N = 16384, M = 65536, Matern52) against the oracle at
+    the FULL size: one Adam iteration from the seeded draw + the posterior on all grid points (what bench.py's
+    cpu_baseline times; ~1.5 minutes of host time and ~40 GB of host memory -- skipped on smaller hosts).
+    Tolerances: RMSE(mean), RMSE(sd) <= 1e-8, hyper-parameters rel 1e-9 (reference: gpr.py:185-199,247-250)."""
+    psutil = pytest.importorskip("psutil")
+    R, _ = lattice_image()
+    X, Xf = gpim.utils.get_sparse_grid(R), gpim.utils.get_full_grid(R)
+    N, M = int(np.isfinite(R).sum()), R.size
+    assert (N, M) == (16384, 65536)
+    if psutil.virtual_memory().available < 1.3 * (3 * 8.0 * N * M + 6 * 8.0 * N * N) or (torch.get_num_threads() * 32 < 8):
+        pytest.skip("host too small for the oracle at N = 16384")
+    kw = dict(kernel="Matern52", lengthscale=[[1., 1.], [20., 20.]], learning_rate=0.1, iterations=1, verbose=0, seed=0)
+    mean, sd, hyper = gpim.reconstructor(X, R, Xf, **kw).run()
+    import os
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    mo, so, ho = O.reconstructor(X, R, Xf, **kw).run()
+    torch.set_num_threads(1)
+    for k in ("lengthscale", "noise", "variance"):
+        assert_allclose(hyper[k], ho[k], rtol=1e-9)
+    assert np.sqrt(np.mean((mean - mo) ** 2)) <= 1e-8
+    assert np.sqrt(np.mean((sd - so) ** 2)) <= 1e-8
+
+
 def test_c2_size_fit_predict_properties(gpim):
     R, img = lattice_image()
     X, Xf = gpim.utils.get_sparse_grid(R), gpim.utils.get_full_grid(R)

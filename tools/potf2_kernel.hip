@@ -1,4 +1,5 @@
-// potf2.hip -- the diagonal-block kernels of the blocked Cholesky (replaces
+// potf2_kernel.hip -- the diagonal-block factorisation (gpim_amd/csrc/potf2_body.hpp; in the product it is a role of
+// chol_step_kernel, cholstep.hip) as a kernel of its own, for tools/potf2_prof.hip.  The diagonal-block kernels of the blocked Cholesky (replaces
 // the diagonal steps of torch.linalg.cholesky, call sites gpim/gpreg/gpr.py:192,248).
 //
 //   potf2_kernel   one workgroup (8 waves) factors a 128x128 diagonal block that is resident in
@@ -13,7 +14,7 @@
 //   8 waves          : trailing update D -= P P^T on the lower 16x16 tiles, v_mfma_f64_16x16x4_f64
 // A lone wave can issue an fp64 MFMA only every ~140 cycles, so the MFMA phases need >= 2 waves per
 // SIMD: hence 512-thread workgroups.
-#include "potf2_body.hpp"
+#include "../gpim_amd/csrc/potf2_body.hpp"
 
 #ifndef POTF2_WAVES_PER_EU
 #define POTF2_WAVES_PER_EU 4
@@ -31,16 +32,3 @@ __global__ __launch_bounds__(NTH, POTF2_WAVES_PER_EU) void potf2_kernel(R* __res
 #endif
 }
 
-#ifndef POTF2_PROFILE
-int launch_potf2(gpimhip_ctx* h, double* A, int64_t ld, int kblk, int32_t* info) {
-    const int nb = (int)(h->np / NB);
-    if (h->fp32)
-        hipLaunchKernelGGL(potf2_kernel<float>, dim3(1, h->nbatch), dim3(NTH), 0, h->stream, reinterpret_cast<float*>(A), ld,
-                           kblk, reinterpret_cast<float*>(h->dinv), h->logdet_part, info, nb);
-    else
-        hipLaunchKernelGGL(potf2_kernel<double>, dim3(1, h->nbatch), dim3(NTH), 0, h->stream, A, ld, kblk, h->dinv,
-                           h->logdet_part, info, nb);
-    HIP_TRY(hipGetLastError());
-    return GPIMHIP_OK;
-}
-#endif

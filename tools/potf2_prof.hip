@@ -1,6 +1,6 @@
 // potf2_prof.hip -- phase-by-phase cycle counts of potf2_inv_kernel (development aid).
 #define POTF2_PROFILE
-#include "../gpim_amd/csrc/potf2.hip"
+#include "potf2_kernel.hip"
 #include <stdio.h>
 #include <vector>
 void gpim_set_error(const std::string&) {}
