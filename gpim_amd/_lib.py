@@ -102,6 +102,12 @@ _PROTOS = {
                                              ctypes.c_double, ctypes.c_double, c_dp, c_dp, c_dp, c_dp]),
     "gpimhip_thin_batch": (ctypes.c_int, [ctypes.c_void_p, c_dp, c_dp, ctypes.c_int32, ctypes.c_int32, c_dp,
                                           ctypes.c_double, ctypes.c_int32, c_dp, c_dp]),
+    "gpimhip_dist_vec_forward": (ctypes.c_int, [ctypes.c_void_p, c_dp, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
+                                                c_dp, c_dp, c_dp, c_dp]),
+    "gpimhip_dist_vec_backward": (ctypes.c_int, [ctypes.c_void_p, c_dp, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
+                                                 c_dp, c_dp, c_dp, c_dp]),
+    "gpimhip_matvec_t": (ctypes.c_int, [ctypes.c_void_p, c_dp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, c_dp,
+                                        c_dp]),
     "gpimhip_step_plan_host": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32),
                                               ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]),
 }
@@ -130,7 +136,9 @@ def load():
     return lib
 
 
-_live = None
+import weakref
+
+_live = weakref.WeakSet()      # every open Handle (created at import: no lazy-initialisation race between threads)
 
 
 def _shutdown():
@@ -138,7 +146,7 @@ def _shutdown():
     HIP runtime is still up (see gpimhip_shutdown)."""
     import gc
     gc.collect()
-    for h in list(_live or ()):
+    for h in list(_live):
         try:
             h.close()
         except Exception:
@@ -185,10 +193,6 @@ class Handle:
         check(lib.gpimhip_create(ctypes.byref(h), self.device.index, ctypes.c_void_p(stream)))
         self._h = h
         self.lib = lib
-        global _live
-        if _live is None:
-            import weakref
-            _live = weakref.WeakSet()
         _live.add(self)
         self.precision = precision
         if precision == "single":       # N x N matrices and the O(N^3) products in float (gpimhip_set_precision)

@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <algorithm>
 #include <chrono>
+#include <atomic>
 #include <mutex>
 #include "common.hpp"
 
@@ -358,8 +359,19 @@ struct SideStreams {
 };
 static std::mutex g_side_mutex;
 static SideStreams g_side[64];
+// gpimhip_shutdown destroys the shared streams; a handle that outlives it (a C-ABI host that shuts down and goes on)
+// must not use the pointers it cached: every shutdown starts a new generation, and a handle of an older one forgets them
+static std::atomic<int> g_side_generation{0};
+static void side_refresh(gpimhip_ctx* h) {
+    const int g = g_side_generation.load();
+    if (h->side_generation == g) return;
+    h->side_generation = g;
+    h->panel_stream = h->chain_stream = h->capture_stream = nullptr;
+    h->side_streams_tried = h->capture_stream_tried = false;
+}
 
 static void ensure_lookahead_streams(gpimhip_ctx* h) {
+    side_refresh(h);
     if (h->side_streams_tried) return;
     h->side_streams_tried = true;
     std::lock_guard<std::mutex> lock(g_side_mutex);
@@ -379,8 +391,8 @@ static void ensure_lookahead_streams(gpimhip_ctx* h) {
         // (CU mask), not with GPU_MAX_HW_QUEUES = 8 as long as the process stays below that many streams (which in
         // turn slows the concurrent batches of config C3 by 23 %).  A HIGH-PRIORITY driving stream was unaffected in
         // every situation measured (tools/r3_single_ctx.py: 75.0 - 75.2 / 44.1 - 44.2 ms in all of them; DESIGN
-        // section 6).  The mechanism inside the runtime is not known to us: this is an empirical remedy, and
-        // GPIMHIP_NO_CHAIN_STREAM=1 switches it off.
+        // section 6).  GPIMHIP_NO_CHAIN_STREAM=1 switches the hop off.  The stream is shared by the handles of a device:
+        // concurrent large-N fits from several handles serialise their launch chains on it (correct, not concurrent).
         if (hipStreamCreateWithPriority(&S.chain, hipStreamNonBlocking, hi) != hipSuccess) S.chain = nullptr;
     }
     h->panel_stream = S.panel;                       // null: the mat-vecs stay on the caller's stream
@@ -394,6 +406,7 @@ void capture_lock(gpimhip_ctx* h) { g_capture_mutex[h->device & 63].lock(); }
 void capture_unlock(gpimhip_ctx* h) { g_capture_mutex[h->device & 63].unlock(); }
 
 hipStream_t ensure_capture_stream(gpimhip_ctx* h) {
+    side_refresh(h);
     if (!h->capture_stream && !h->capture_stream_tried) {
         h->capture_stream_tried = true;
         std::lock_guard<std::mutex> lock(g_side_mutex);
@@ -659,6 +672,9 @@ int vfe_finish_and_check(gpimhip_ctx* h) { return finish_and_check(h); }
 void vfe_release(gpimhip_ctx* h);
 void kron_release(gpimhip_ctx* h);
 static void dist_plan_release(gpimhip_ctx* h);
+// the distributed entry points address the workspace (diagonal-block inverses, batch strides) through the plan's block
+// count: a handle whose workspace was re-sized after gpimhip_dist_setup must not be used with the stale plan
+static bool dist_plan_ok(const gpimhip_ctx* h) { return h && h->np && h->dplan.nb && h->np == (int64_t)h->dplan.nb * NB; }
 
 // ------------------------------------------------------------------------------------------
 // C ABI
@@ -678,6 +694,7 @@ int gpimhip_shutdown(void) {
         if (S.chain) (void)hipStreamDestroy(S.chain);
         S = SideStreams();
     }
+    g_side_generation.fetch_add(1);
     return GPIMHIP_OK;
 }
 int gpimhip_version(void) { return 100; }
@@ -1162,7 +1179,7 @@ int gpimhip_dist_begin(gpimhip_handle h, int64_t n) { return gpimhip_dist_setup(
 int gpimhip_dist_panel_factor(gpimhip_handle h, double* Aloc, int64_t ldloc, int32_t loc_blk0, int32_t glob_blk0,
                               double* logdet_out, int32_t* info) {
     FP64_ONLY(h);
-    if (!h || !Aloc || !info || loc_blk0 < 0 || glob_blk0 < 0 || !h->np || !h->dplan.nb) return GPIMHIP_E_BADARG;
+    if (!h || !Aloc || !info || loc_blk0 < 0 || glob_blk0 < 0 || !dist_plan_ok(h)) return GPIMHIP_E_BADARG;
     HIP_TRY(hipSetDevice(h->device));
     const int nb = (int)(h->np / NB);
     if (glob_blk0 >= nb || glob_blk0 % OUTER_W || ldloc < (int64_t)(loc_blk0 + std::min(OUTER_W, nb - glob_blk0)) * NB)
@@ -1179,10 +1196,58 @@ int gpimhip_dist_panel_factor(gpimhip_handle h, double* Aloc, int64_t ldloc, int
     return GPIMHIP_OK;
 }
 
+// The panel-wise vector solves of alpha = K^-1 y on the owner of panel [glob_blk0, glob_blk0 + 4) (distops.hip):
+//   forward : piece (512) = Lpp^-1 (y_p - t);  acc[rows below the panel] += L(below, p) piece
+//   backward: piece = Lpp^-T (z_p - L(below, p)^T a[below])
+// y_p / z_p / t / piece: the panel's 512 entries (device); acc / a: full-length (np) vectors.  Needs the inverses of the
+// panel's diagonal blocks, i.e. the handle that factored the panel (gpimhip_dist_panel_factor).
+int gpimhip_dist_vec_forward(gpimhip_handle h, const double* Aloc, int64_t ldloc, int32_t loc_blk0, int32_t glob_blk0,
+                             const double* y_p, const double* t, double* piece, double* acc) {
+    FP64_ONLY(h);
+    if (!h || !Aloc || !y_p || !piece || !acc || !dist_plan_ok(h) || glob_blk0 < 0 || loc_blk0 < 0 || glob_blk0 % OUTER_W)
+        return GPIMHIP_E_BADARG;
+    HIP_TRY(hipSetDevice(h->device));
+    const int nb = (int)(h->np / NB);
+    if (glob_blk0 >= nb) return GPIMHIP_E_BADARG;
+    const int nblk = std::min(OUTER_W, nb - glob_blk0), w = nblk * NB;
+    const int64_t r0 = (int64_t)glob_blk0 * NB;
+    const double* P = Aloc + r0 * ldloc + (int64_t)loc_blk0 * NB;
+    GP_TRY(launch_dist_trsv(h, P, ldloc, h->dinv + (int64_t)glob_blk0 * NB * NB, nblk, 0, y_p, t, piece));
+    return launch_dist_rows_acc(h, P + (int64_t)w * ldloc, ldloc, h->np - r0 - w, w, piece, acc + r0 + w);
+}
+int gpimhip_dist_vec_backward(gpimhip_handle h, const double* Aloc, int64_t ldloc, int32_t loc_blk0, int32_t glob_blk0,
+                              const double* z_p, const double* a, double* work, double* piece) {
+    FP64_ONLY(h);
+    if (!h || !Aloc || !z_p || !a || !work || !piece || !dist_plan_ok(h) || glob_blk0 < 0 || loc_blk0 < 0 ||
+        glob_blk0 % OUTER_W)
+        return GPIMHIP_E_BADARG;
+    HIP_TRY(hipSetDevice(h->device));
+    const int nb = (int)(h->np / NB);
+    if (glob_blk0 >= nb) return GPIMHIP_E_BADARG;
+    const int nblk = std::min(OUTER_W, nb - glob_blk0), w = nblk * NB;
+    const int64_t r0 = (int64_t)glob_blk0 * NB, below = h->np - r0 - w;
+    const double* P = Aloc + r0 * ldloc + (int64_t)loc_blk0 * NB;
+    h->nbatch = 1;
+    // work (512) = L(below, p)^T a[below]
+    if (below > 0) GP_TRY(launch_gemv_t(h, P + (int64_t)w * ldloc, ldloc, below, w, a + r0 + w, work, 0, 0, 0, 0));
+    else HIP_TRY(hipMemsetAsync(work, 0, (size_t)w * sizeof(double), h->stream));
+    return launch_dist_trsv(h, P, ldloc, h->dinv + (int64_t)glob_blk0 * NB * NB, nblk, 1, z_p, work, piece);
+}
+// out (ncols) = A^T x for a row-major nrows x ncols matrix (ncols a multiple of 64): the posterior mean K*^T alpha of
+// the distributed model (HBM-bound, fixed summation order)
+int gpimhip_matvec_t(gpimhip_handle h, const double* A, int64_t ld, int64_t nrows, int64_t ncols, const double* x,
+                     double* out) {
+    FP64_ONLY(h);
+    if (!h || !A || !x || !out || nrows < 1 || ncols < 64 || ncols % 64 || ld < ncols) return GPIMHIP_E_BADARG;
+    HIP_TRY(hipSetDevice(h->device));
+    h->nbatch = 1;
+    return launch_gemv_t(h, A, ld, nrows, ncols, x, out, 0, 0, 0, 0);
+}
+
 int gpimhip_dist_panel_pack(gpimhip_handle h, const double* Aloc, int64_t ldloc, int32_t loc_blk0, int32_t glob_blk0,
                             double* buf, int64_t ldbuf) {
     FP64_ONLY(h);
-    if (!h || !Aloc || !buf || !h->np || !h->dplan.nb || glob_blk0 < 0 || loc_blk0 < 0 || ldbuf < OUTER_W * NB)
+    if (!h || !Aloc || !buf || !dist_plan_ok(h) || glob_blk0 < 0 || loc_blk0 < 0 || ldbuf < OUTER_W * NB)
         return GPIMHIP_E_BADARG;
     HIP_TRY(hipSetDevice(h->device));
     const int nb = (int)(h->np / NB);
@@ -1195,7 +1260,7 @@ int gpimhip_dist_panel_pack(gpimhip_handle h, const double* Aloc, int64_t ldloc,
 int gpimhip_dist_update(gpimhip_handle h, const double* buf, int64_t ldbuf, int32_t panel_glob_blk0, double* Aloc,
                         int64_t ldloc, int32_t panel_first, int32_t panel_last) {
     FP64_ONLY(h);
-    if (!h || !buf || !Aloc || !h->np || !h->dplan.nb || panel_glob_blk0 < 0 || panel_glob_blk0 % OUTER_W)
+    if (!h || !buf || !Aloc || !dist_plan_ok(h) || panel_glob_blk0 < 0 || panel_glob_blk0 % OUTER_W)
         return GPIMHIP_E_BADARG;
     HIP_TRY(hipSetDevice(h->device));
     const DistPlan& D = h->dplan;
@@ -1244,7 +1309,7 @@ static int dist_rect_ensure(gpimhip_ctx* h, int cols) {
 int gpimhip_dist_solve_update(gpimhip_handle h, const double* buf, int64_t ldbuf, int32_t panel_glob_blk0, double* Bm,
                               int64_t ldb, int64_t mpad, double* Wt, int64_t ldw, double* q, int32_t col_tiles) {
     FP64_ONLY(h);
-    if (!h || !buf || !Bm || !Wt || !h->np || !h->dplan.nb || panel_glob_blk0 < 0 || panel_glob_blk0 % OUTER_W ||
+    if (!h || !buf || !Bm || !Wt || !dist_plan_ok(h) || panel_glob_blk0 < 0 || panel_glob_blk0 % OUTER_W ||
         mpad < NB || mpad % NB || ldb < mpad || ldw < mpad)
         return GPIMHIP_E_BADARG;
     HIP_TRY(hipSetDevice(h->device));
@@ -1306,7 +1371,7 @@ int gpimhip_dist_kmat_cols(gpimhip_handle h, const gpimhip_model_t* m, const dou
 int gpimhip_dist_kinv_update(gpimhip_handle h, const double* xbuf, int64_t ldx, int32_t panel_glob_blk0,
                              const double* Xloc, int64_t ldloc, double* Kinv, int64_t ldk) {
     FP64_ONLY(h);
-    if (!h || !xbuf || !Xloc || !Kinv || !h->np || !h->dplan.nb || panel_glob_blk0 < 0 || panel_glob_blk0 % OUTER_W ||
+    if (!h || !xbuf || !Xloc || !Kinv || !dist_plan_ok(h) || panel_glob_blk0 < 0 || panel_glob_blk0 % OUTER_W ||
         panel_glob_blk0 >= h->dplan.nb)
         return GPIMHIP_E_BADARG;
     HIP_TRY(hipSetDevice(h->device));
@@ -1326,7 +1391,7 @@ int gpimhip_dist_kinv_update(gpimhip_handle h, const double* xbuf, int64_t ldx, 
 int gpimhip_dist_grad_sums(gpimhip_handle h, const gpimhip_model_t* m, const double* X, int64_t N, const double* u,
                            const double* Kinv, int64_t ldk, const double* alpha, double* S_out) {
     FP64_ONLY(h);
-    if (!h || !X || !u || !Kinv || !alpha || !S_out || !h->np || !h->dplan.nb) return GPIMHIP_E_BADARG;
+    if (!h || !X || !u || !Kinv || !alpha || !S_out || !dist_plan_ok(h)) return GPIMHIP_E_BADARG;
     GP_TRY(check_model(m));
     HIP_TRY(hipSetDevice(h->device));
     h->nbatch = 1;

@@ -103,6 +103,7 @@ struct gpimhip_ctx {
     hipStream_t panel_stream = nullptr;   // high-priority side stream: the two mat-vecs over L^-1 beside the K^-1 product (large N)
     hipStream_t capture_stream = nullptr; // internal stream used only to capture one iteration into a hipGraph
     bool side_streams_tried = false, capture_stream_tried = false;   // side streams are created on first use
+    int side_generation = 0;              // generation of the process-wide side streams the pointers below belong to (api.hip)
     hipStream_t chain_stream = nullptr;   // high-priority stream that drives the large-N factorisation and inverse (api.hip)
     hipEvent_t ev_chain[2] = {nullptr, nullptr};   // hop onto the chain stream and back
     bool capturing = false;               // fit_impl is recording one iteration into a hipGraph
@@ -206,6 +207,9 @@ int launch_panel_chain(gpimhip_ctx* h, double* A, int64_t ld, int p0, int p1, in
 int launch_dist_pack(gpimhip_ctx* h, const double* P, int64_t ldp, int64_t r0, int64_t np, int w, const double* dinv,
                      int nblk, double* buf, int64_t ldb);
 int launch_colsumsq_acc(gpimhip_ctx* h, const double* W, int64_t ldw, int rows, int64_t m, double* q);
+int launch_dist_trsv(gpimhip_ctx* h, const double* P, int64_t ld, const double* D, int nblk, int backward, const double* r0,
+                     const double* r1, double* out);
+int launch_dist_rows_acc(gpimhip_ctx* h, const double* A, int64_t ld, int64_t rows, int w, const double* x, double* acc);
 // engine.hip (distributed training)
 int launch_grad_reduce_tiles(gpimhip_ctx* h, const gpimhip_model_t* m, const double* Kinv, int64_t ld, const double* X,
                              int64_t N, int64_t np, const double* alpha, const TileDesc* tiles, int ntile, double* part);

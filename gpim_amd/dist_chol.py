@@ -9,11 +9,11 @@ rank p mod P, the 1 x P case of a 2-D block-cyclic layout: every rank owns whole
 factored by its owner alone and ONE broadcast per panel (np x 512 doubles, 268 MB at N = 65536) is the
 only data-path collective.  Round p:
 
-    owner(p) : factor panel p in place              (C ABI: gpimhip_dist_panel_factor -- the potf2 /
-                                                      panel-solve / in-panel-update chain of csrc/potf2.hip)
+    owner(p) : factor panel p in place              (C ABI: gpimhip_dist_panel_factor -- the step launches of
+                                                      csrc/cholstep.hip restricted to the panel)
     all      : broadcast of the factored panel       (dist.broadcast, src = owner(p))
-    each     : trailing update of every owned panel right of p with the broadcast copy
-                                                     (gpimhip_dist_trailing_update -- the fp64 MFMA tile engine)
+    each     : trailing update of every owned panel right of p with the broadcast copy, ONE launch
+                                                     (gpimhip_dist_update -- the fp64 MFMA tile engine)
 
 Look-ahead: the owner of panel p+1 updates that panel FIRST, then factors it, packs it and starts its
 broadcast on a high-priority SIDE stream while the main stream goes on with the rest of round p's updates (all of a
@@ -23,12 +23,14 @@ rows, the inverses of its diagonal blocks (the forward substitutions of the othe
 Per-rank memory: N^2 / P doubles + two panel buffers.  Communication per rank: N^2 / 2 doubles received in
 total, about the time of the 1/P share of the N^3 / 3 flop at N = 65536, P = 8.
 
-What the distributed model offers: the factor, log det K, the negative log marginal likelihood at given
-hyper-parameters and the posterior mean and standard deviation (two distributed triangular solves for
-alpha, O(N^2); K*^T alpha sharded over test points; for the variance the factor is streamed through every
-rank once more while each rank forward-substitutes its own test columns on the MFMA tile engine:
-gpimhip_dist_solve_update).  Training gradients (the distributed K^-1) are not built: hyper-parameters come
-from a single-GPU fit on a sub-sample.
+What the distributed model offers: the factor, log det K, the negative log marginal likelihood, the posterior mean
+and standard deviation, and TRAINING (``exact_gp_fit``: distributed L^-1 and K^-1 = X^T X for the gradient, one
+all-reduce of 8 doubles per Adam iteration).  alpha = K^-1 y is two panel-wise triangular solves on the owners
+(gpimhip_dist_vec_forward / _backward: block substitution with the diagonal-block inverses + HBM-bound mat-vecs over
+the panel's rows, O(N^2)); K*^T alpha is sharded over test points (gpimhip_matvec_t); for the variance, the inverse
+and K^-1 the factor (or X) is streamed through the ranks once more -- the next panel's broadcast is in flight
+(``async_op=True``, two buffers) while the current one is consumed on the MFMA tile engine (gpimhip_dist_solve_update,
+gpimhip_dist_kinv_update).
 
 The tile arithmetic is behind a small engine interface so that the ownership / broadcast schedule can be
 tested on CPU ranks (gloo) with a stub (tests/test_dist_gloo.py); ``HipTileEngine`` is the product engine and
@@ -161,6 +163,31 @@ class HipTileEngine:
                                                      self._lib.ptr(Xloc), Xloc.stride(0), self._lib.ptr(Kinv),
                                                      Kinv.stride(0)))
 
+    # ---- O(N^2) vector solves on the owner of a panel: the side handle factored it and holds its diagonal-block inverses
+    def vec_forward(self, Aloc, p, y_p, t, piece, acc):
+        L, lib = self.layout, self.Hs.lib
+        self._lib.check(lib.gpimhip_dist_vec_forward(self.Hs.h, self._lib.ptr(Aloc), Aloc.stride(0), L.local_col0(p) // NB,
+                                                     p * PANEL, ctypes.c_void_p(y_p.data_ptr()),
+                                                     ctypes.c_void_p(t.data_ptr()), self._lib.ptr(piece), self._lib.ptr(acc)))
+
+    def vec_backward(self, Aloc, p, z_p, a, work, piece):
+        L, lib = self.layout, self.Hs.lib
+        self._lib.check(lib.gpimhip_dist_vec_backward(self.Hs.h, self._lib.ptr(Aloc), Aloc.stride(0), L.local_col0(p) // NB,
+                                                      p * PANEL, ctypes.c_void_p(z_p.data_ptr()), self._lib.ptr(a),
+                                                      self._lib.ptr(work), self._lib.ptr(piece)))
+
+    def matvec_t(self, A, x, out):
+        """out = A^T x (A: rows x cols view of a row-major matrix, cols a multiple of 64)"""
+        self._lib.check(self.H.lib.gpimhip_matvec_t(self.H.h, ctypes.c_void_p(A.data_ptr()), A.stride(0), A.shape[0],
+                                                    A.shape[1], ctypes.c_void_p(x.data_ptr()), self._lib.ptr(out)))
+
+    def half_logdet_owned(self):
+        """sum of log L_ii over the owned panels (the factorisation role's per-block partial sums; padding rows are
+        identity: log 1 = 0) as a 1-element device tensor"""
+        own = torch.tensor(self.layout.owned, dtype=torch.long, device=self.device)
+        return self.logdet[own].sum().reshape(1) if len(self.layout.owned) else torch.zeros((1,), dtype=torch.float64,
+                                                                                           device=self.device)
+
     def failed_column(self):
         return int(self.info[0].item())
 
@@ -243,59 +270,52 @@ class DistributedCholesky:
     # ------------------------------------------------------------------ what the factor is for
     def logdet(self):
         """log det of the matrix = 2 sum log L_ii (every rank returns the same number)."""
-        L = self.layout
-        s = torch.zeros((1,), dtype=torch.float64, device=self.local.device)
-        for p in L.owned:
-            l0 = L.local_col0(p)
-            w = L.width(p)
-            d = torch.diagonal(self.local[p * PW:p * PW + w, l0:l0 + w])
-            s += torch.log(d[:max(0, min(w, L.n - p * PW))]).sum()
-        if L.world > 1:
+        s = self.engine.half_logdet_owned().clone()
+        if self.layout.world > 1:
             dist.all_reduce(s, group=self.group)
         return 2.0 * float(s.item())
 
     def solve(self, y):
-        """alpha = (L L^T)^-1 y, replicated on every rank.  Two panel-by-panel triangular solves: O(N^2) work,
-        one 512-double broadcast per panel each way (host-orchestrated torch ops on the local panels -- not
-        part of the O(N^3) path)."""
-        L = self.layout
+        """alpha = (L L^T)^-1 y, replicated on every rank.  Two panel-by-panel triangular solves, O(N^2) work: the owner
+        of a panel solves with its diagonal triangle and multiplies the rows below (engine.vec_forward / vec_backward);
+        per panel one all-reduce of the 512 partial sums (forward only) and one broadcast of the 512 solved entries."""
+        L, eng = self.layout, self.engine
         dev = self.local.device
-        rhs_full = torch.zeros((L.np,), dtype=torch.float64, device=dev)
+        rhs_full = torch.zeros((L.npanel * PW,), dtype=torch.float64, device=dev)
         rhs_full[:L.n] = torch.as_tensor(y, dtype=torch.float64).to(dev)
         # forward, z = L^-1 y.  Every rank accumulates acc = sum over ITS panels q of L(:, q) z_q; the rows of
         # panel p need the contributions of all ranks: one all-reduce of 512 doubles, then the owner solves
         # with the diagonal triangle and broadcasts z_p.
-        z = torch.zeros((L.np,), dtype=torch.float64, device=dev)
-        acc = torch.zeros((L.np,), dtype=torch.float64, device=dev)
+        z = torch.zeros((L.npanel * PW,), dtype=torch.float64, device=dev)
+        acc = torch.zeros((L.npanel * PW,), dtype=torch.float64, device=dev)
         piece = torch.zeros((PW,), dtype=torch.float64, device=dev)
+        work = torch.zeros((PW,), dtype=torch.float64, device=dev)
+        t = torch.zeros((PW,), dtype=torch.float64, device=dev)
         for p in range(L.npanel):
-            w, r0 = L.width(p), p * PW
-            t = acc[r0:r0 + PW].clone() if r0 + PW <= L.np else torch.cat(
-                [acc[r0:], torch.zeros((r0 + PW - L.np,), dtype=torch.float64, device=dev)])
+            r0 = p * PW
+            t.copy_(acc[r0:r0 + PW])
             if L.world > 1:
                 dist.all_reduce(t, group=self.group)
             if L.owner(p) == L.rank:
-                l0 = L.local_col0(p)
-                Lpp = torch.tril(self.local[r0:r0 + w, l0:l0 + w])
-                piece[:w] = torch.linalg.solve_triangular(Lpp, (rhs_full[r0:r0 + w] - t[:w])[:, None], upper=False)[:, 0]
-                acc[r0 + w:] += self.local[r0 + w:, l0:l0 + w] @ piece[:w]
+                with self._side():
+                    eng.vec_forward(self.local, p, rhs_full[r0:r0 + PW], t, piece, acc)
+                self._side_done().wait()
             if L.world > 1:
                 dist.broadcast(piece, src=L.owner(p), group=self.group)
-            z[r0:r0 + w] = piece[:w]
+            z[r0:r0 + PW].copy_(piece)
         # backward, alpha = L^-T z: the owner of panel p holds L(rows below, panel p) and alpha of the rows
         # below is known to everybody by then
-        a = torch.zeros((L.np,), dtype=torch.float64, device=dev)
+        a = torch.zeros((L.npanel * PW,), dtype=torch.float64, device=dev)
         for p in reversed(range(L.npanel)):
-            w, r0 = L.width(p), p * PW
+            r0 = p * PW
             if L.owner(p) == L.rank:
-                l0 = L.local_col0(p)
-                Lpp = torch.tril(self.local[r0:r0 + w, l0:l0 + w])
-                rhs = z[r0:r0 + w] - self.local[r0 + w:, l0:l0 + w].T @ a[r0 + w:]
-                piece[:w] = torch.linalg.solve_triangular(Lpp.T, rhs[:, None], upper=True)[:, 0]
+                with self._side():
+                    eng.vec_backward(self.local, p, z[r0:r0 + PW], a, work, piece)
+                self._side_done().wait()
             if L.world > 1:
                 dist.broadcast(piece, src=L.owner(p), group=self.group)
-            a[r0:r0 + w] = piece[:w]
-        self._z = z
+            a[r0:r0 + PW].copy_(piece)
+        self._z = z[:L.np]
         return a[:L.n]
 
     def solve_colsumsq(self, B):
@@ -315,31 +335,39 @@ class DistributedCholesky:
             B = Bp
         Wt = eng.empty(PW, mpad)
         q = torch.zeros((mpad,), dtype=torch.float64, device=B.device)
-        for p in range(L.npanel):
-            buf = self._panel[p & 1]
-            if L.owner(p) == L.rank:
-                # pack() belongs to the engine's side handle: order it behind the main stream's earlier reads of
-                # `buf` and in front of the broadcast / the solve that follow on the main stream
-                with self._side():
-                    eng.pack(self.local, p, buf)
-                self._side_done().wait()
-            if L.world > 1:
-                dist.broadcast(buf, src=L.owner(p), group=self.group)
+        for p, buf in self._stream_factor():
             if m:
                 eng.solve_update(buf, p, B, Wt, q)
         return q[:m]
 
-    def _stream_panel(self, p):
-        """Pack (owner) and broadcast the factored panel p once more; returns the buffer."""
-        L, eng = self.layout, self.engine
+    def _start_panel(self, p, fill):
+        """Owner of panel p: fill(buf) -- on the engine's side stream, behind everything the main stream has been given
+        so far (the previous consumer of this buffer) -- and start the broadcast; others: post the receive.  Returns
+        something with .wait() that orders the caller's stream behind the arrival of the buffer."""
+        L = self.layout
         buf = self._panel[p & 1]
         if L.owner(p) == L.rank:
             with self._side():
-                eng.pack(self.local, p, buf)
-            self._side_done().wait()
-        if L.world > 1:
-            dist.broadcast(buf, src=L.owner(p), group=self.group)
-        return buf
+                fill(buf)
+                if L.world > 1:
+                    return dist.broadcast(buf, src=L.rank, group=self.group, async_op=True)
+            return self._side_done()
+        return dist.broadcast(buf, src=L.owner(p), group=self.group, async_op=True)
+
+    def _stream(self, fill_of):
+        """Yields (p, buffer) for every panel in order; the broadcast of panel p + 1 is in flight while the caller
+        consumes panel p (two buffers)."""
+        L = self.layout
+        work = self._start_panel(0, fill_of(0))
+        for p in range(L.npanel):
+            work.wait()
+            if p + 1 < L.npanel:
+                work = self._start_panel(p + 1, fill_of(p + 1))
+            yield p, self._panel[p & 1]
+
+    def _stream_factor(self):
+        """The factored panels once more (packed with the inverses of their diagonal blocks)."""
+        return self._stream(lambda p: (lambda buf: self.engine.pack(self.local, p, buf)))
 
     def inverse(self):
         """X = L^-1, distributed like L: this rank's block columns (np x 512 * owned panels), lower triangular.
@@ -352,8 +380,7 @@ class DistributedCholesky:
             idx = torch.arange(L.width(p), device=Bw.device)
             Bw[p * PW + idx, L.local_col0(p) + idx] = 1.0
         Xl = eng.empty(L.np, L.local_cols)
-        for p in range(L.npanel):
-            buf = self._stream_panel(p)
+        for p, buf in self._stream_factor():
             nown = sum(1 for c in L.owned if c <= p)
             if nown:
                 eng.solve_update(buf, p, Bw, Xl[p * PW:], None, nown * PANEL)
@@ -361,18 +388,17 @@ class DistributedCholesky:
 
     def kinv(self, Xl):
         """K^-1 = X^T X (lower tiles) for the owned block columns, np x 512 * owned panels: every owner broadcasts
-        its block columns of X in turn and each rank forms the rows of that panel against its own columns on the
-        MFMA tile engine (gpimhip_dist_kinv_update)."""
+        its block columns of X in turn (the next one in flight while the current one is consumed) and each rank forms
+        the rows of that panel against its own columns on the MFMA tile engine (gpimhip_dist_kinv_update)."""
         L, eng = self.layout, self.engine
         Kl = eng.empty(L.np, L.local_cols)
-        for c in range(L.npanel):
-            buf = self._panel[c & 1]
-            w = L.width(c)
-            if L.owner(c) == L.rank:
+
+        def fill_of(c):
+            def fill(buf):
                 l0 = L.local_col0(c)
-                buf[:L.np, :w] = Xl[:, l0:l0 + w]
-            if L.world > 1:
-                dist.broadcast(buf, src=L.owner(c), group=self.group)
+                buf[:L.np, :L.width(c)].copy_(Xl[:, l0:l0 + L.width(c)])
+            return fill
+        for c, buf in self._stream(fill_of):
             eng.kinv_update(buf, c, Xl, Kl)
         return Kl
 
@@ -449,7 +475,9 @@ def exact_gp_posterior(X, y, Xtest, kernel="Matern52", lengthscale=None, varianc
         Ks = torch.zeros((npd, wpad), dtype=torch.float64, device=dev)
         if s1 > s0:
             kmat(Xt[s0:s1].to(dev).contiguous(), Ks)
-            part[0, s0 - lo:s1 - lo] = (Ks[:N, :s1 - s0].T @ alpha)
+            mu = torch.empty((wpad,), dtype=torch.float64, device=dev)
+            chol.engine.matvec_t(Ks[:N], alpha, mu)
+            part[0, s0 - lo:s1 - lo] = mu[:s1 - s0]
         if with_sd:
             q = chol.solve_colsumsq(Ks)[:s1 - s0]
             part[1, s0 - lo:s1 - lo] = torch.sqrt(torch.clamp(variance - q, min=0.0) + noise)

@@ -306,6 +306,19 @@ int gpimhip_dist_solve_update(gpimhip_handle h, const double* buf, int64_t ldbuf
  *                             loss and gradient only.  Identical inputs on every rank -> identical u. */
 int gpimhip_dist_kmat_cols(gpimhip_handle h, const gpimhip_model_t* m, const double* X, int64_t N, const double* u,
                            int64_t col0, int64_t ncols_pad, double* out, int64_t ld);
+/* The O(N^2) vector solves of alpha = K^-1 y of the distributed model (torch.linalg.solve_triangular over the whole
+ * factor in the reference, gpr.py:192-193 through pyro), panel by panel on the OWNER of panel [glob_blk0, glob_blk0 + 4)
+ * with the handle that factored it (the inverses of its diagonal blocks live there):
+ *   gpimhip_dist_vec_forward   piece (<= 512) = Lpp^-1 (y_p - t)  (t may be NULL);  acc[rows below the panel] +=
+ *                              L(below, p) piece   (acc: full-length np vector of this rank's partial sums)
+ *   gpimhip_dist_vec_backward  piece = Lpp^-T (z_p - L(below, p)^T a[below])  (a: full-length np vector; work: 512 doubles)
+ *   gpimhip_matvec_t           out (ncols) = A^T x, A row-major nrows x ncols (ncols % 64 == 0): K*^T alpha */
+int gpimhip_dist_vec_forward(gpimhip_handle h, const double* Aloc, int64_t ldloc, int32_t loc_blk0, int32_t glob_blk0,
+                             const double* y_p, const double* t, double* piece, double* acc);
+int gpimhip_dist_vec_backward(gpimhip_handle h, const double* Aloc, int64_t ldloc, int32_t loc_blk0, int32_t glob_blk0,
+                              const double* z_p, const double* a, double* work, double* piece);
+int gpimhip_matvec_t(gpimhip_handle h, const double* A, int64_t ld, int64_t nrows, int64_t ncols, const double* x,
+                     double* out);
 int gpimhip_dist_kinv_update(gpimhip_handle h, const double* xbuf, int64_t ldx, int32_t panel_glob_blk0,
                              const double* Xloc, int64_t ldloc, double* Kinv, int64_t ldk);
 int gpimhip_dist_grad_sums(gpimhip_handle h, const gpimhip_model_t* m, const double* X, int64_t N, const double* u,

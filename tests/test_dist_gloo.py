@@ -113,6 +113,7 @@ class NumpyTileEngine:
     def panel_factor(self, Aloc, p):
         from gpim_amd.dist_chol import PW
         L = self.layout
+        self._Aloc = Aloc
         w, r0, l0 = L.width(p), p * PW, L.local_col0(p)
         A = Aloc[r0:r0 + w, l0:l0 + w]
         sym = torch.tril(A) + torch.tril(A, -1).T
@@ -159,6 +160,34 @@ class NumpyTileEngine:
             if p <= c:                                          # block columns left of / at the panel: tiles i >= j
                 l0 = L.local_col0(p)
                 Kinv[r0:r0 + w, l0:l0 + L.width(p)] = full[:, l0:l0 + L.width(p)]
+
+    def vec_forward(self, Aloc, p, y_p, t, piece, acc):
+        from gpim_amd.dist_chol import PW
+        L = self.layout
+        w, r0, l0 = L.width(p), p * PW, L.local_col0(p)
+        Lpp = torch.tril(Aloc[r0:r0 + w, l0:l0 + w])
+        piece[:w] = torch.linalg.solve_triangular(Lpp, (y_p[:w] - t[:w])[:, None], upper=False)[:, 0]
+        acc[r0 + w:L.np] += Aloc[r0 + w:, l0:l0 + w] @ piece[:w]
+
+    def vec_backward(self, Aloc, p, z_p, a, work, piece):
+        from gpim_amd.dist_chol import PW
+        L = self.layout
+        w, r0, l0 = L.width(p), p * PW, L.local_col0(p)
+        Lpp = torch.tril(Aloc[r0:r0 + w, l0:l0 + w])
+        rhs = z_p[:w] - Aloc[r0 + w:, l0:l0 + w].T @ a[r0 + w:L.np]
+        piece[:w] = torch.linalg.solve_triangular(Lpp.T, rhs[:, None], upper=True)[:, 0]
+
+    def matvec_t(self, A, x, out):
+        out[:A.shape[1]] = A.T @ x
+
+    def half_logdet_owned(self):
+        from gpim_amd.dist_chol import PW
+        L = self.layout
+        s = torch.zeros((1,), dtype=torch.float64)
+        for p in L.owned:
+            d = torch.diagonal(self._Aloc[p * PW:p * PW + L.width(p), L.local_col0(p):L.local_col0(p) + L.width(p)])
+            s += torch.log(d).sum()
+        return s
 
     def failed_column(self):
         return self.bad
