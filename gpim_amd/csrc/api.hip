@@ -22,7 +22,7 @@ int launch_pad_matrix_in(gpimhip_ctx* h, const double* src, int64_t n, int64_t l
 int launch_pad_matrix_out_lower(gpimhip_ctx* h, const double* src, int64_t np, double* dst, int64_t n, int64_t ld);
 int launch_trmv_lower(gpimhip_ctx* h, const double* L, int64_t ld, int64_t np, const double* y, double* z);
 int launch_gemv_t(gpimhip_ctx* h, const double* A, int64_t ld, int64_t nrows, int64_t ncols, const double* x,
-                  double* out, int tri, int64_t a_bs, int64_t x_bs, int64_t o_bs);
+                  double* out, int tri, int64_t a_bs, int64_t x_bs, int64_t o_bs, double* part = nullptr);
 int launch_grad_reduce(gpimhip_ctx* h, const gpimhip_model_t* m, const double* Kinv, int64_t ld,
                        const double* X, int64_t N, int nb, const double* alpha, int64_t x_bs);
 int launch_kres(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X, int64_t x_bs, int64_t N, double* scratch,
@@ -101,6 +101,7 @@ static void ws_release_matrix(gpimhip_ctx* h) {
     dev_free(h, &h->alpha, B * np);
     dev_free(h, &h->logdet_part, B * nb);
     dev_free(h, &h->grad_part, B * nb * (nb + 1) / 2 * 8);
+    dev_free(h, &h->gemv_part, B * 8 * np);
     dev_free(h, &h->theta, B);
     dev_free(h, &h->adam_m, B * MAXP);
     dev_free(h, &h->adam_v, B * MAXP);
@@ -137,7 +138,7 @@ static int ws_ensure_b(gpimhip_ctx* h, int64_t N, int B, int padded, bool matric
         (rc = dev_alloc(h, &h->dinvB, B * nb * NB * NB)) ||
         (rc = dev_alloc(h, &h->ypad, B * np)) || (rc = dev_alloc(h, &h->z, B * np)) ||
         (rc = dev_alloc(h, &h->alpha, B * np)) || (rc = dev_alloc(h, &h->logdet_part, B * nb)) ||
-        (rc = dev_alloc(h, &h->grad_part, B * nb * (nb + 1) / 2 * 8)) || (rc = dev_alloc(h, &h->theta, (int64_t)B)) ||
+        (rc = dev_alloc(h, &h->grad_part, B * nb * (nb + 1) / 2 * 8)) || (rc = dev_alloc(h, &h->gemv_part, B * 8 * np)) || (rc = dev_alloc(h, &h->theta, (int64_t)B)) ||
         (rc = dev_alloc(h, &h->adam_m, (int64_t)B * MAXP)) || (rc = dev_alloc(h, &h->adam_v, (int64_t)B * MAXP)) ||
         (rc = dev_alloc(h, &h->iter, (int64_t)B))) {
         ws_release_matrix(h);
@@ -493,7 +494,7 @@ static int refine_passes() {
 static int solve_vectors(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X, int64_t x_bs, int64_t N) {
     const int64_t np = h->np, ld = h->ld;
     GP_TRY(launch_trmv_lower(h, h->A, ld, np, h->ypad, h->z));
-    GP_TRY(launch_gemv_t(h, h->A, ld, np, np, h->z, h->alpha, 1, np * ld, np, np));
+    GP_TRY(launch_gemv_t(h, h->A, ld, np, np, h->z, h->alpha, 1, np * ld, np, np, h->gemv_part));
     if (!h->fp32) return GPIMHIP_OK;
     const int B = h->nbatch, nb = (int)(np / NB);
     const int S = std::max(1, std::min(8, 512 / std::max(1, nb * B)));        // >= ~512 workgroups per launch
@@ -501,7 +502,7 @@ static int solve_vectors(gpimhip_ctx* h, const gpimhip_model_t* m, const double*
     for (int pass = 0; pass < refine_passes(); ++pass) {
         GP_TRY(launch_kres(h, m, X, x_bs, N, scratch, S, res));
         GP_TRY(launch_trmv_lower(h, h->A, ld, np, res, h->z));
-        GP_TRY(launch_gemv_t(h, h->A, ld, np, np, h->z, delta, 1, np * ld, np, np));
+        GP_TRY(launch_gemv_t(h, h->A, ld, np, np, h->z, delta, 1, np * ld, np, np, h->gemv_part));
         GP_TRY(launch_axpy(h, h->alpha, delta, (int64_t)B * np));
     }
     return GPIMHIP_OK;

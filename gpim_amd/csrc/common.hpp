@@ -123,6 +123,7 @@ struct gpimhip_ctx {
     double* alpha = nullptr;        // np  (K^-1 y)
     double* logdet_part = nullptr;  // nb
     double* grad_part = nullptr;    // ntiles_lower x 8
+    double* gemv_part = nullptr;    // 8 x np: row-chunk partial sums of the mat-vec over L^-1 (engine.hip: launch_gemv_t)
     ThetaDev* theta = nullptr;      // [ws_batch]
     ThetaDev* theta1 = nullptr;     // single struct for the operator-level gpimhip_kmat
     int32_t* iter = nullptr;        // [ws_batch] device-side iteration counters

@@ -286,6 +286,9 @@ __global__ __launch_bounds__(256) void trmv_lower_kernel(const R* __restrict__ L
 // diagonal block of the column (A lower triangular), else at row 0.  HBM-bound (8 B per entry of
 // A): 16 waves per workgroup, each with four 512-byte row segments in flight; fixed summation order.
 #define GEMVT_WAVES 16
+// gridDim.z = S > 1: the rows of a column block are cut into S contiguous chunks, chunk s writes its sums to
+// part[s][.] (part: S x o_bs-strided vectors per problem) and gemv_t_sum_kernel adds the S rows in order -- a
+// mat-vec over a mid-size matrix has only ncols / 64 column blocks, far fewer than the chip has CUs.
 template <typename R>
 __global__ __launch_bounds__(GEMVT_WAVES * 64) void gemv_t_kernel(const R* __restrict__ A, int64_t ld,
                                                                  int64_t nrows, const double* __restrict__ x,
@@ -294,14 +297,20 @@ __global__ __launch_bounds__(GEMVT_WAVES * 64) void gemv_t_kernel(const R* __res
     __shared__ double red[GEMVT_WAVES][64];
     A += blockIdx.y * a_bs;
     x += blockIdx.y * x_bs;
-    out += blockIdx.y * o_bs;
+    const int S = gridDim.z;
+    out += (blockIdx.y * S + blockIdx.z) * o_bs;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t j = (int64_t)blockIdx.x * 64 + lane;
-    const int64_t i0 = tri ? ((int64_t)blockIdx.x * 64 / NB) * NB : 0;
+    int64_t i0 = tri ? ((int64_t)blockIdx.x * 64 / NB) * NB : 0, i1 = nrows;
+    if (S > 1) {
+        const int64_t chunk = ((i1 - i0 + S - 1) / S + GEMVT_WAVES - 1) / GEMVT_WAVES * GEMVT_WAVES;
+        i0 += blockIdx.z * chunk;
+        i1 = i0 + chunk < i1 ? i0 + chunk : i1;
+    }
     const R* col = A + j;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     int64_t i = i0 + wave;
-    for (; i + 3 * GEMVT_WAVES < nrows; i += 4 * GEMVT_WAVES) {
+    for (; i + 3 * GEMVT_WAVES < i1; i += 4 * GEMVT_WAVES) {
         const double a0 = (double)col[i * ld], a1 = (double)col[(i + GEMVT_WAVES) * ld];
         const double a2 = (double)col[(i + 2 * GEMVT_WAVES) * ld], a3 = (double)col[(i + 3 * GEMVT_WAVES) * ld];
         s0 = fma(a0, x[i], s0);
@@ -309,7 +318,7 @@ __global__ __launch_bounds__(GEMVT_WAVES * 64) void gemv_t_kernel(const R* __res
         s2 = fma(a2, x[i + 2 * GEMVT_WAVES], s2);
         s3 = fma(a3, x[i + 3 * GEMVT_WAVES], s3);
     }
-    for (; i < nrows; i += GEMVT_WAVES) s0 = fma((double)col[i * ld], x[i], s0);
+    for (; i < i1; i += GEMVT_WAVES) s0 = fma((double)col[i * ld], x[i], s0);
     red[wave][lane] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (wave == 0) {
@@ -318,6 +327,15 @@ __global__ __launch_bounds__(GEMVT_WAVES * 64) void gemv_t_kernel(const R* __res
         for (int w = 0; w < GEMVT_WAVES; ++w) t += red[w][lane];
         out[j] = t;
     }
+}
+__global__ __launch_bounds__(256) void gemv_t_sum_kernel(const double* __restrict__ part, int S, int64_t n, double* __restrict__ out,
+                                                         int64_t o_bs) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    part += (int64_t)blockIdx.y * S * o_bs;
+    double t = 0.0;
+    for (int s = 0; s < S; ++s) t += part[(int64_t)s * o_bs + j];
+    out[blockIdx.y * o_bs + j] = t;
 }
 
 int launch_trmv_lower(gpimhip_ctx* h, const double* L, int64_t ld, int64_t np, const double* y, double* z) {
@@ -330,15 +348,27 @@ int launch_trmv_lower(gpimhip_ctx* h, const double* L, int64_t ld, int64_t np, c
     HIP_TRY(hipGetLastError());
     return GPIMHIP_OK;
 }
+// part: optional scratch of 8 * o_bs doubles per problem (h->gemv_part); with it, a launch of few column blocks is
+// cut along the rows into up to 8 chunks (~512 workgroups) and summed in a fixed order by a second kernel
 int launch_gemv_t(gpimhip_ctx* h, const double* A, int64_t ld, int64_t nrows, int64_t ncols, const double* x,
-                  double* out, int tri, int64_t a_bs, int64_t x_bs, int64_t o_bs) {
+                  double* out, int tri, int64_t a_bs, int64_t x_bs, int64_t o_bs, double* part) {
+    const int64_t cb = ncols / 64;
+    int S = 1;
+    if (part && o_bs >= ncols && nrows >= 1024) S = (int)std::max<int64_t>(1, std::min<int64_t>(8, 512 / std::max<int64_t>(1, cb * h->nbatch)));
+    double* dst = S > 1 ? part : out;
+    const dim3 grid((unsigned)cb, h->nbatch, S);
     if (h->fp32)
-        hipLaunchKernelGGL(gemv_t_kernel<float>, dim3((unsigned)(ncols / 64), h->nbatch), dim3(GEMVT_WAVES * 64), 0, h->stream,
-                           reinterpret_cast<const float*>(A), ld, nrows, x, out, tri, a_bs, x_bs, o_bs);
+        hipLaunchKernelGGL(gemv_t_kernel<float>, grid, dim3(GEMVT_WAVES * 64), 0, h->stream,
+                           reinterpret_cast<const float*>(A), ld, nrows, x, dst, tri, a_bs, x_bs, o_bs);
     else
-        hipLaunchKernelGGL(gemv_t_kernel<double>, dim3((unsigned)(ncols / 64), h->nbatch), dim3(GEMVT_WAVES * 64), 0, h->stream, A, ld, nrows,
-                       x, out, tri, a_bs, x_bs, o_bs);
+        hipLaunchKernelGGL(gemv_t_kernel<double>, grid, dim3(GEMVT_WAVES * 64), 0, h->stream, A, ld, nrows,
+                       x, dst, tri, a_bs, x_bs, o_bs);
     HIP_TRY(hipGetLastError());
+    if (S > 1) {
+        hipLaunchKernelGGL(gemv_t_sum_kernel, dim3((unsigned)((ncols + 255) / 256), h->nbatch), dim3(256), 0, h->stream,
+                           (const double*)part, S, ncols, out, o_bs);
+        HIP_TRY(hipGetLastError());
+    }
     return GPIMHIP_OK;
 }
 
