@@ -64,9 +64,9 @@ for pre in sys.argv[1:]:
         R5 = ckpfm_cube()[..., 0]
         Xf5 = gpim.utils.get_full_grid(R5)
         gpim.reconstructor(Xf5, R5, Xf5, structured=True, verbose=0, kernel="RBF", learning_rate=0.05, iterations=20).run()
-    elif pre == "streams4":
-        # four extra torch streams, each touched once from the main thread: no library call involved
-        for _ in range(4):
+    elif pre.startswith("streams") and pre[7:].isdigit():
+        # k extra torch streams (streams4: four), each touched once from the main thread: no library call involved
+        for _ in range(int(pre[7:])):
             st = torch.cuda.Stream()
             with torch.cuda.stream(st):
                 torch.zeros(1024, device="cuda").add_(1.0)
