@@ -55,10 +55,9 @@ void gpim_set_error(const std::string& s) { g_err = s; }
 // panels) on one XCD's L2, but a list of a few hundred tiles dealt 64 at a time puts all the longest tiles on
 // XCD 0 (N = 4206: K^-1 product 0.92 -> 0.72 ms with single-tile dealing); grow the chunk with the list.
 static int deal_chunk(int ntiles = 1 << 30) { return std::max(1, std::min(64, ntiles / 512)); }
-// "large N": from 12 outer panels (6144 unknowns) on an iteration is enqueued launch by launch (below: one captured
-// iteration is replayed), its launch-chain stages are driven from the engine's high-priority stream and the two
-// mat-vecs over L^-1 run on a side stream beside the K^-1 product
-#define LOOKAHEAD_MIN_PANELS 12
+// "large N": from 12 outer panels (6144 unknowns) on an iteration is enqueued launch by launch on the caller's stream
+// (below: one captured iteration is replayed; its ~100 launches are then one host call)
+#define EAGER_MIN_PANELS 12
 #define OUTER_W 4    // outer Cholesky panel = 4 x 128 columns
 
 // ------------------------------------------------------------------------------------------
@@ -348,56 +347,29 @@ static GemmArgs gemm_args(const double* A, int64_t lda, const double* B, int64_t
     return g;
 }
 
-// Side streams are created on first use and then SHARED by every handle of the device for the life of the
-// process: HIP maps streams onto a few hardware queues (four by default), and which queue a new stream gets depends
-// on every stream the process has created and destroyed before -- a fixed set created once keeps the mapping, and the
-// speed, independent of the process's history.  Work of different handles on a shared stream only serialises (every
-// cross-stream dependency is an event of the handle that recorded it).  Handles that only ever run the fused
-// small-N trainer use none.
+// The one helper stream of the library: the stream an iteration is CAPTURED on (mid-size N).  It is created on first
+// use and shared by every handle of the device for the life of the process.  The training loop itself runs on the
+// caller's stream alone.  (Until round 4 large-N iterations ran their two mat-vecs on a high-priority side stream beside
+// the K^-1 product and drove the launch chains from a second one.  The side branch was the CAUSE of the "stream
+// population" slow-down recorded in DESIGN.md section 6: its wait on the next iteration's event sits in a hardware queue
+// of its own for the whole factorisation, and when that queue is the fifth or later the process has created, every
+// dependent launch of the main queue starts 30-45 us late -- profiles/r04_queue_sweep.txt.  On the caller's stream the
+// mat-vecs cost < 0.1 ms of a 74 ms iteration.)
 struct SideStreams {
-    hipStream_t panel = nullptr, capture = nullptr, chain = nullptr;
-    bool lookahead_tried = false, capture_tried = false;
+    hipStream_t capture = nullptr;
+    bool capture_tried = false;
 };
 static std::mutex g_side_mutex;
 static SideStreams g_side[64];
-// gpimhip_shutdown destroys the shared streams; a handle that outlives it (a C-ABI host that shuts down and goes on)
-// must not use the pointers it cached: every shutdown starts a new generation, and a handle of an older one forgets them
+// gpimhip_shutdown destroys the shared stream; a handle that outlives it (a C-ABI host that shuts down and goes on)
+// must not use the pointer it cached: every shutdown starts a new generation, and a handle of an older one forgets it
 static std::atomic<int> g_side_generation{0};
 static void side_refresh(gpimhip_ctx* h) {
     const int g = g_side_generation.load();
     if (h->side_generation == g) return;
     h->side_generation = g;
-    h->panel_stream = h->chain_stream = h->capture_stream = nullptr;
-    h->side_streams_tried = h->capture_stream_tried = false;
-}
-
-static void ensure_lookahead_streams(gpimhip_ctx* h) {
-    side_refresh(h);
-    if (h->side_streams_tried) return;
-    h->side_streams_tried = true;
-    std::lock_guard<std::mutex> lock(g_side_mutex);
-    SideStreams& S = g_side[h->device & 63];
-    if (!S.lookahead_tried) {
-        S.lookahead_tried = true;
-        int lo = 0, hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // hi = numerically lowest = highest priority
-        if (hipStreamCreateWithPriority(&S.panel, hipStreamNonBlocking, hi) != hipSuccess) S.panel = nullptr;
-        // The stream that DRIVES the large-N factorisation and triangular inverse (factor_at_u hops onto it and back).
-        // These two stages are chains of hundreds of short dependent launches, and how fast the runtime lets such a
-        // chain run on the CALLER's stream depends on the stream population of the whole process: after a mid-size fit
-        // and the first use of a few more streams (torch's pool; dist.reconstruct_slices' concurrent batches), every
-        // launch on the default stream and on torch's normal-priority streams came ~40 us later than it should
-        // for the rest of the process (N = 16384: Cholesky 29.0 -> 44.9 ms, iteration 74.6 -> 92.4 ms; float engine
-        // 43.5 -> 57.0 ms), also after those streams were destroyed, also on a stream with a queue of its own
-        // (CU mask), not with GPU_MAX_HW_QUEUES = 8 as long as the process stays below that many streams (which in
-        // turn slows the concurrent batches of config C3 by 23 %).  A HIGH-PRIORITY driving stream was unaffected in
-        // every situation measured (tools/r3_single_ctx.py: 75.0 - 75.2 / 44.1 - 44.2 ms in all of them; DESIGN
-        // section 6).  GPIMHIP_NO_CHAIN_STREAM=1 switches the hop off.  The stream is shared by the handles of a device:
-        // concurrent large-N fits from several handles serialise their launch chains on it (correct, not concurrent).
-        if (hipStreamCreateWithPriority(&S.chain, hipStreamNonBlocking, hi) != hipSuccess) S.chain = nullptr;
-    }
-    h->panel_stream = S.panel;                       // null: the mat-vecs stay on the caller's stream
-    h->chain_stream = S.chain;                       // null: the caller's stream drives every stage
+    h->capture_stream = nullptr;
+    h->capture_stream_tried = false;
 }
 // The capture stream is shared by every handle of a device: two threads fitting at the same time must not
 // interleave their Begin..EndCapture sections on it (the second BeginCapture would fail and that fit would
@@ -488,7 +460,7 @@ int check_model(const gpimhip_model_t* m) {
 // a second pass changes nothing -- what is left comes from log det and K^-1 themselves).  The loss then takes its
 // quadratic term as y^T alpha (launch_finalize).
 static int refine_passes() {
-    static const int v = getenv("GPIMHIP_REFINE") ? atoi(getenv("GPIMHIP_REFINE")) : 1;
+    static const int v = 1;
     return v;
 }
 static int solve_vectors(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X, int64_t x_bs, int64_t N) {
@@ -508,50 +480,14 @@ static int solve_vectors(gpimhip_ctx* h, const gpimhip_model_t* m, const double*
     return GPIMHIP_OK;
 }
 
-// K(u) -> L -> L^-1 (in h->A), and unless `defer_vectors` also z and alpha.
-// Large N, eager launches: the launch-chain stages (factorisation, triangular inverse) run on the engine's
-// high-priority chain stream (see ensure_lookahead_streams), two event hops per call; everything else stays on the
-// caller's stream, below the priority of the side branch that hides the mat-vecs behind the K^-1 product.
-struct ChainHop { hipStream_t caller = nullptr; bool on = false; };
-static int chain_hop_begin(gpimhip_ctx* h, int64_t np, ChainHop& c) {
-    c.caller = h->stream;
-    c.on = false;
-    if (h->capturing || (int)((np / NB + OUTER_W - 1) / OUTER_W) < LOOKAHEAD_MIN_PANELS || getenv("GPIMHIP_NO_CHAIN_STREAM"))
-        return GPIMHIP_OK;
-    ensure_lookahead_streams(h);
-    if (!h->chain_stream) return GPIMHIP_OK;
-    for (auto& e : h->ev_chain)
-        if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    HIP_TRY(hipEventRecord(h->ev_chain[0], c.caller));
-    HIP_TRY(hipStreamWaitEvent(h->chain_stream, h->ev_chain[0], 0));
-    h->stream = h->chain_stream;
-    c.on = true;
-    return GPIMHIP_OK;
-}
-// rc: what the hopped stages returned; joined on every path -- after a failed launch the caller's stream (the one a
-// handle synchronises before it frees anything) must still be behind whatever the chain stream was given
-static int chain_hop_end(gpimhip_ctx* h, ChainHop& c, int rc) {
-    if (c.on) {
-        h->stream = c.caller;
-        hipError_t je = hipEventRecord(h->ev_chain[1], h->chain_stream);
-        if (je == hipSuccess) je = hipStreamWaitEvent(c.caller, h->ev_chain[1], 0);
-        c.on = false;
-        if (rc == GPIMHIP_OK) HIP_TRY(je);
-    }
-    return rc;
-}
-
+// K(u) -> L -> L^-1 (in h->A), then z = L^-1 y and alpha = L^-T z
 static int factor_at_u(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X, int64_t x_bs, int64_t N,
-                       const double* u, bool defer_vectors = false) {
+                       const double* u) {
     const int64_t np = h->np, ld = h->ld;
     GP_TRY(launch_theta(h, m, u));
     GP_TRY(launch_kmat(h, m, X, N, nullptr, N, h->theta, 0.0, 1, h->A, ld, np, np, 1, 1, x_bs, x_bs, np * ld));
-    ChainHop hop;
-    GP_TRY(chain_hop_begin(h, np, hop));
-    const int rc = launch_potrf_inv(h, h->A, h->Tm, np, ld, h->info);
-    GP_TRY(chain_hop_end(h, hop, rc));
-    if (!defer_vectors) GP_TRY(solve_vectors(h, m, X, x_bs, N));
-    return GPIMHIP_OK;
+    GP_TRY(launch_potrf_inv(h, h->A, h->Tm, np, ld, h->info));
+    return solve_vectors(h, m, X, x_bs, N);
 }
 
 struct IterTable { int32_t* iter; const double* bc; int T; double* hist_base; double* loss_base; };
@@ -560,37 +496,8 @@ static int loss_grad_at_u(gpimhip_ctx* h, const gpimhip_model_t* m, const double
                           double* u, int do_adam, AdamStep st, double* loss_out, double* grad_out,
                           double* hist_row, const IterTable* tab = nullptr) {
     const int64_t np = h->np;
-    // Large N (never captured): the two HBM-bound mat-vecs over L^-1 run on the engine's side stream, next to the
-    // MFMA-bound K^-1 product (both only read L^-1).
-    bool side = !h->capturing && (int)((np / NB + OUTER_W - 1) / OUTER_W) >= LOOKAHEAD_MIN_PANELS;
-    hipStream_t side_s = nullptr;
-    if (side) {
-        ensure_lookahead_streams(h);
-        while (h->ev_pool.size() < 2) {
-            hipEvent_t e;
-            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            h->ev_pool.push_back(e);
-        }
-        side_s = h->panel_stream;
-        side = side_s != nullptr;
-    }
-    GP_TRY(factor_at_u(h, m, X, x_bs, N, u, side));
-    if (side) {
-        hipStream_t main_s = h->stream;
-        hipEvent_t ev_in = h->ev_pool[0], ev_out = h->ev_pool[1];
-        HIP_TRY(hipEventRecord(ev_in, main_s));
-        HIP_TRY(hipStreamWaitEvent(side_s, ev_in, 0));
-        h->stream = side_s;
-        const int rc = solve_vectors(h, m, X, x_bs, N);
-        h->stream = main_s;
-        GP_TRY(rc);
-        HIP_TRY(hipEventRecord(ev_out, side_s));
-        { StageTimer t(h, 2); GP_TRY(launch_lauum(h, h->A, h->B, np, h->ld)); }
-        HIP_TRY(hipStreamWaitEvent(main_s, ev_out, 0));
-    } else {
-        StageTimer t(h, 2);
-        GP_TRY(launch_lauum(h, h->A, h->B, np, h->ld));
-    }
+    GP_TRY(factor_at_u(h, m, X, x_bs, N, u));
+    { StageTimer t(h, 2); GP_TRY(launch_lauum(h, h->A, h->B, np, h->ld)); }
     GP_TRY(launch_grad_reduce(h, m, h->B, h->ld, X, N, (int)(np / NB), h->alpha, x_bs));
     if (tab)
         GP_TRY(launch_finalize(h, m, N, np, u, do_adam, st, nullptr, nullptr, nullptr, tab->iter, tab->bc, tab->T,
@@ -684,15 +591,12 @@ extern "C" {
 
 const char* gpimhip_last_error(void) { return g_err.c_str(); }
 
-// Destroys the process-wide side streams (ensure_lookahead_streams / ensure_capture_stream).  Called by the Python
-// binding at interpreter exit, while the HIP runtime is still up: a priority / CU-masked stream that is alive when
-// the process tears down makes rocprofv3's exit handler crash (segmentation fault after the CSVs are written).
+// Destroys the process-wide capture stream (ensure_capture_stream).  Called by the Python binding at interpreter exit,
+// while the HIP runtime is still up.
 int gpimhip_shutdown(void) {
     std::lock_guard<std::mutex> lock(g_side_mutex);
     for (auto& S : g_side) {
-        if (S.panel) (void)hipStreamDestroy(S.panel);
         if (S.capture) (void)hipStreamDestroy(S.capture);
-        if (S.chain) (void)hipStreamDestroy(S.chain);
         S = SideStreams();
     }
     g_side_generation.fetch_add(1);
@@ -746,13 +650,10 @@ int gpimhip_destroy(gpimhip_handle h) {
     if (h->plan.d_tiles) (void)hipFree(h->plan.d_tiles);
     step_plan_release(h);
     dist_plan_release(h);
-    for (auto e : h->ev_pool) (void)hipEventDestroy(e);
     for (auto e : h->ra_ev)
         if (e) (void)hipEventDestroy(e);
     if (h->pinned_info) (void)hipHostFree(h->pinned_info);
-    for (auto e : h->ev_chain)
-        if (e) (void)hipEventDestroy(e);
-    // the other side streams belong to the process (ensure_lookahead_streams), not to the handle
+    // (the capture stream belongs to the process, not to the handle)
     delete h;
     return GPIMHIP_OK;
 }
@@ -821,9 +722,7 @@ int gpimhip_potrf(gpimhip_handle h, double* A, int64_t n, int64_t ld, int32_t* i
     const int64_t np = h->np;
     HIP_TRY(hipMemsetAsync(info, 0, sizeof(int32_t), h->stream));
     GP_TRY(launch_pad_matrix_in(h, A, n, ld, h->A, np));
-    ChainHop hop;
-    GP_TRY(chain_hop_begin(h, np, hop));
-    GP_TRY(chain_hop_end(h, hop, launch_potrf(h, h->A, np, np, info)));
+    GP_TRY(launch_potrf(h, h->A, np, np, info));
     GP_TRY(launch_pad_matrix_out_lower(h, h->A, np, A, n, ld));
     return GPIMHIP_OK;
 }
@@ -856,7 +755,7 @@ static int fit_impl(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X, i
     // Large N: the launch cost no longer matters and the iteration is enqueued launch by launch, its launch-chain
     // stages on the engine's high-priority stream and the mat-vecs on a side stream (factor_at_u, loss_grad_at_u).
     const int npanel = (int)((h->np / NB + OUTER_W - 1) / OUTER_W);
-    const bool large = npanel >= LOOKAHEAD_MIN_PANELS;
+    const bool large = npanel >= EAGER_MIN_PANELS;
     const bool use_graph = T >= 8 && !h->timing && !getenv("GPIMHIP_NO_GRAPH") && !large && ensure_capture_stream(h);
     if (use_graph) {
         hipGraph_t graph = nullptr;

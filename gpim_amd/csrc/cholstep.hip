@@ -564,7 +564,7 @@ static int launch_step(gpimhip_ctx* h, StepArgs& a, bool potf2, int n, int q) {
     a.potf2 = potf2 ? 1 : 0;
     if (!potf2 && n == 0) return GPIMHIP_OK;
     const dim3 grid(n ? 8 + q * n : 1, B);
-    if (q == 4 && potf2 && B <= 4) hipLaunchKernelGGL((chol_step_kernel<64, 64, true>), grid, dim3(NTH), 0, h->stream, a);
+    if (q == 4 && potf2) hipLaunchKernelGGL((chol_step_kernel<64, 64, true>), grid, dim3(NTH), 0, h->stream, a);
     else if (q == 4) hipLaunchKernelGGL((chol_step_kernel<64, 64, false>), grid, dim3(NTH), 0, h->stream, a);
     else if (q == 2) hipLaunchKernelGGL((chol_step_kernel<128, 64, false>), grid, dim3(NTH), 0, h->stream, a);
     else hipLaunchKernelGGL((chol_step_kernel<128, 128, false>), grid, dim3(NTH), 0, h->stream, a);
@@ -586,7 +586,7 @@ int launch_potrf_steps(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_
     else GP_TRY(step_plan_ensure(h, nb));
     const StepPlan& P = Tm ? h->splan_inv : h->splan;
     const int B = h->nbatch;
-    static const int host_max_batch = getenv("GPIMHIP_HOST_MAX_BATCH") ? atoi(getenv("GPIMHIP_HOST_MAX_BATCH")) : 4;   // (experiment knob)
+    const int host_max_batch = 4;
     StepArgs a;
     a.A = A; a.ld = ld; a.nb = nb; a.Tm = Tm;
     a.dinv_all = h->dinv; a.dinvB_all = h->dinvB; a.logdet = h->logdet_part; a.info = info;

@@ -100,14 +100,10 @@ struct DistPlan {
 struct gpimhip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t panel_stream = nullptr;   // high-priority side stream: the two mat-vecs over L^-1 beside the K^-1 product (large N)
     hipStream_t capture_stream = nullptr; // internal stream used only to capture one iteration into a hipGraph
-    bool side_streams_tried = false, capture_stream_tried = false;   // side streams are created on first use
-    int side_generation = 0;              // generation of the process-wide side streams the pointers below belong to (api.hip)
-    hipStream_t chain_stream = nullptr;   // high-priority stream that drives the large-N factorisation and inverse (api.hip)
-    hipEvent_t ev_chain[2] = {nullptr, nullptr};   // hop onto the chain stream and back
+    bool capture_stream_tried = false;    // the capture stream is created on first use
+    int side_generation = 0;              // generation of the process-wide capture stream the pointer below belongs to (api.hip)
     bool capturing = false;               // fit_impl is recording one iteration into a hipGraph
-    std::vector<hipEvent_t> ev_pool;      // cross-stream ordering events (no timing)
     // workspace (sized for np = padded N)
     int64_t np = 0;                 // padded matrix order the buffers are sized for
     int64_t ld = 0;                 // leading dimension (doubles) of A, B, Tm: np, or np + 16 (see ws_ensure_b)

@@ -354,7 +354,8 @@ int launch_gemv_t(gpimhip_ctx* h, const double* A, int64_t ld, int64_t nrows, in
                   double* out, int tri, int64_t a_bs, int64_t x_bs, int64_t o_bs, double* part) {
     const int64_t cb = ncols / 64;
     int S = 1;
-    if (part && o_bs >= ncols && nrows >= 1024) S = (int)std::max<int64_t>(1, std::min<int64_t>(8, 512 / std::max<int64_t>(1, cb * h->nbatch)));
+    // (a function of the matrix size alone, not of the batch: a problem gives the same bits alone and in a lock-step batch)
+    if (part && o_bs >= ncols && nrows >= 1024) S = (int)std::max<int64_t>(1, std::min<int64_t>(8, 512 / std::max<int64_t>(1, cb)));
     double* dst = S > 1 ? part : out;
     const dim3 grid((unsigned)cb, h->nbatch, S);
     if (h->fp32)

@@ -36,7 +36,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_tiles_kernel(GemmArgs g) {
 // Up to this many tiles the 8-wave shape is launched with 24 KB of unused dynamic LDS on top of its 74 KB of
 // staging buffers, so that every tile has a CU to itself (K^-1 product at N = 4206: 0.71 -> 0.56 ms).
 static int mid_tiles() {
-    static const int v = getenv("GPIMHIP_MID_TILES") ? atoi(getenv("GPIMHIP_MID_TILES")) : 1100;   // (2048-tile levels of the inverse at N = 16384: 4-wave, two per CU, is 0.25 ms faster)
+    static const int v = 1100;   // (2048-tile levels of the inverse at N = 16384: 4-wave, two per CU, is 0.25 ms faster)
     return v;
 }
 
@@ -48,8 +48,8 @@ static int launch_one(gpimhip_ctx* h, const GemmArgs& g) {
     // k-ranges differ by an order of magnitude (triangular inverse, K^-1 product at N ~ 4000) lasts as long as its
     // longest tile; dealt longest-first over 4 x 256 slots, every CU gets a mix (N = 4206: inverse 0.92 -> 0.80 ms,
     // K^-1 product 0.57 -> 0.48; 1200 / 2400 measure the same)
-    static const int tile64_max = getenv("GPIMHIP_TILE64_MAX") ? atoi(getenv("GPIMHIP_TILE64_MAX")) : 640;
-    const bool small = total <= tile64_max && !getenv("GPIMHIP_NO_TILE64");
+    const int tile64_max = 640;
+    const bool small = total <= tile64_max;
     if (EPI == EPI_STORE && small && !g.inplace)
         // few tiles: spread each over four CUs (64x64 quadrants)
         hipLaunchKernelGGL((gemm_tiles_kernel<A_KM, B_KM, EPI_STORE, 4, 64, 64>), dim3(g.ntiles * 4, h->nbatch),
@@ -63,7 +63,7 @@ static int launch_one(gpimhip_ctx* h, const GemmArgs& g) {
         // follows the wave layout, and batched and stand-alone predictions must stay bit-identical.
         hipLaunchKernelGGL((gemm_tiles_kernel<A_KM, B_KM, EPI, 8, 128, 128>), dim3(g.ntiles, h->nbatch), dim3(512),
                            24 * 1024, h->stream, g);
-    else if (total <= 256 || (!A_KM && !B_KM && !getenv("GPIMHIP_NT_4WAVE")) || getenv("GPIMHIP_ALL_8WAVE"))
+    else if (total <= 256 || (!A_KM && !B_KM))
         // (also every SYRK-shaped update of the Cholesky: measured 8 % faster factorisation at N = 16384,
         // the 512-thread workgroups interleave better with the concurrent panel chain)
         // at most one tile per CU: 8-wave workgroup so every SIMD still holds two MFMA waves

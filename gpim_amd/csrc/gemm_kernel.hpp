@@ -352,7 +352,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_tiles_kernel_t(GemmArgs g) {
 // Up to this many tiles the 8-wave shape is launched with 24 KB of unused dynamic LDS on top of its 74 KB of
 // staging buffers, so that every tile has a CU to itself (K^-1 product at N = 4206: 0.71 -> 0.56 ms).
 static int mid_tiles() {
-    static const int v = getenv("GPIMHIP_MID_TILES") ? atoi(getenv("GPIMHIP_MID_TILES")) : 2048;
+    static const int v = 2048;
     return v;
 }
 
@@ -360,7 +360,7 @@ template <typename R, bool A_KM, bool B_KM, int EPI>
 static int launch_one(gpimhip_ctx* h, const GemmArgs& g) {
     if (g.ntiles <= 0) return GPIMHIP_OK;
     const int64_t total = (int64_t)g.ntiles * h->nbatch;
-    const bool small = total <= 256 && !getenv("GPIMHIP_NO_TILE64");
+    const bool small = total <= 256;
     if (EPI == EPI_STORE && small && !g.inplace)
         // few tiles: spread each over four CUs (64x64 quadrants)
         hipLaunchKernelGGL((gemm_tiles_kernel_t<R, A_KM, B_KM, EPI_STORE, 4, 64, 64>), dim3(g.ntiles * 4, h->nbatch),
@@ -374,7 +374,7 @@ static int launch_one(gpimhip_ctx* h, const GemmArgs& g) {
         // follows the wave layout, and batched and stand-alone predictions must stay bit-identical.
         hipLaunchKernelGGL((gemm_tiles_kernel_t<R, A_KM, B_KM, EPI, 8, 128, 128>), dim3(g.ntiles, h->nbatch), dim3(512),
                            24 * 1024, h->stream, g);
-    else if (total <= 256 || (!A_KM && !B_KM && !getenv("GPIMHIP_NT_4WAVE")) || getenv("GPIMHIP_ALL_8WAVE"))
+    else if (total <= 256 || (!A_KM && !B_KM))
         // (also every SYRK-shaped update of the Cholesky: measured 8 % faster factorisation at N = 16384,
         // the 512-thread workgroups interleave better with the concurrent panel chain)
         // at most one tile per CU: 8-wave workgroup so every SIMD still holds two MFMA waves

@@ -623,7 +623,7 @@ static int kron_plan_problems(gpimhip_ctx* h, KronWs& w) {
     HIP_TRY(hipStreamSynchronize(h->stream));
     KronDev& dv = w.dev;
     dv.nprob = 0;
-    const bool allow = !getenv("GPIMHIP_KRON_NO_SPLIT");
+    const bool allow = true;
     for (int i = 0; i < w.d; ++i) {
         const int n = w.n[i];
         const double* ci = c.data() + dv.off[i];

@@ -81,16 +81,9 @@ def torch_float32_run(kp, X, y, Xs, jitter):
 
 @pytest.mark.parametrize("kind,N,d,schedule", [("RBF", 300, 2, "steps"), ("Matern52", 700, 2, "steps"),
                                                ("RationalQuadratic", 260, 3, "steps"), ("Matern52", 1500, 2, "steps"),
-                                               ("RBF", 2300, 2, "steps"), ("Matern52", 1500, 2, "lookahead"),
-                                               ("RBF", 2300, 2, "lookahead")])
-def test_single_engine_vs_truth_and_float32_run(eng, kind, N, d, schedule, monkeypatch):
-    """schedule: the float step schedule of csrc/cholstep32.hip (default) or the two-stream look-ahead factorisation
-    single-precision handles ran until round 3 (GPIMHIP_F32_LOOKAHEAD=1) -- both held to the same bars (the schedules
-    differ from a few block columns on: the larger sizes run both)."""
-    if schedule == "lookahead":
-        monkeypatch.setenv("GPIMHIP_F32_LOOKAHEAD", "1")
-    else:
-        monkeypatch.delenv("GPIMHIP_F32_LOOKAHEAD", raising=False)
+                                               ("RBF", 2300, 2, "steps")])
+def test_single_engine_vs_truth_and_float32_run(eng, kind, N, d, schedule):
+    """The float step schedule of csrc/cholstep32.hip."""
     _lib, H32, H64 = eng
     X, y, kp, spec, u, Xs = problem(N, d, kind, seed=N)
     gp = O.ExactGP(torch.from_numpy(X), torch.from_numpy(y), kp, 1e-5)

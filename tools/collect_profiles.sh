@@ -5,7 +5,7 @@
 # tools/summarize_profiles.py regenerates the derived tables).
 cd /tmp; export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r03}
+TAG=${1:-r04}
 O=$R/gpurun_out/prof_$TAG
 rm -rf $O; mkdir -p $O
 # 1. kernel stats of the bench command itself (+ the JSON lines with and without the profiler)

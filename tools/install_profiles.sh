@@ -1,6 +1,6 @@
 #!/bin/bash
 # copies what tools/collect_profiles.sh left in gpurun_out/prof_<tag> into profiles/ and regenerates the derived tables
-TAG=${1:-r03}; O=gpurun_out/prof_$TAG
+TAG=${1:-r04}; O=gpurun_out/prof_$TAG
 # refuse to touch profiles/ unless the collection is complete: a failed or unscheduled gpurun call leaves nothing here,
 # and the redirects below would otherwise truncate the committed files
 set -e

@@ -1,7 +1,7 @@
 """Derives profiles/pmc_lauum.json and the tables of profiles/README.md from the rocprofv3 CSVs that
 tools/collect_profiles.sh produced (run on the dev box after copying them into profiles/)."""
 import csv, collections, json, os, re, sys
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r04"
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 P = os.path.join(ROOT, "profiles")
 N = 16384
