@@ -220,8 +220,9 @@ struct HostSim {
 static double wg_cost(int depth, int q) { return q == 4 ? 0.18 * depth + 0.24 : (q == 2 ? 0.34 * depth + 0.3 : depth + 0.5); }
 
 // ---- what the step launches host of the TRAILING UPDATE (double precision) -------------------------------------------
-// nb < 64: the chain of diagonal blocks bounds the factorisation; every launch hosts its column update and a quarter
-// of the previous panel's bulk update (k-depth 512) -- the round-3 lists, unchanged.
+// nb < 64: the chain of diagonal blocks bounds the factorisation; every launch hosts its column update (left-looking
+// inside a window of two panels, k-depth <= 7) and a quarter of the previous panel's bulk update (k-depth 4) -- the
+// round-3 lists, unchanged (same bits).
 // nb >= 64: everything is hosted as well (two workgroups per CU since the factorisation role fits 79 KB), and what a
 // launch hosts is chosen so that it ends on a full round of the 512 slots:
 //   * tile (i, jj) keeps the first block column it has not yet received (`pend`); a flush applies [pend, p0) in ONE
@@ -237,20 +238,15 @@ static void plan_updates(int nb, std::vector<std::vector<TileDesc>>& fill) {
     const int W = STEP_W, S = HOST_SLOTS;
     const int npanel = (nb + W - 1) / W;
     auto by_depth = [](const TileDesc& a, const TileDesc& b) { return (a.kb1 - a.kb0) > (b.kb1 - b.kb0); };
-    // Column update of block column j = p0 + t of panel [p0, p1) where the chain of diagonal blocks bounds the launch:
-    // every hosted tile at most 4 k-blocks deep, so that none outlasts the factorisation role.  The previous panel's
-    // contribution to column j (k-depth 4) is final one launch before the column's own panel contributes its last
-    // block, so it rides one launch earlier (columns p0, p0 + 1: in the panel's first launch) and the launch of
-    // column j itself only applies the panel's own t <= 3 blocks.
-    auto col_split = [&](std::vector<TileDesc>& tl, int p0, int p1, int j) {
-        const int t = j - p0;
-        if (t >= 1)
-            for (int i = j + 1; i < nb; ++i) tl.push_back({i, j, p0, j});
-        if (p0 == 0) return;
-        if (t == 0)
-            for (int i = j + 1; i < nb; ++i) tl.push_back({i, j, p0 - W, p0});
-        if (j + 1 < p1)
-            for (int i = j + 2; i < nb; ++i) tl.push_back({i, j + 1, p0 - W, p0});
+    // left-looking column update of block column j inside a window of two outer panels: ONE tile operation per tile,
+    // k-blocks [p0 - W, j).  (Round 4 also measured it split at the panel boundary -- every hosted tile <= 4 k-blocks
+    // deep, the previous panel's part one launch earlier: launches that host nothing else drop from 50 to 35 us, but
+    // the two passes over C and the smaller budget for the inverse's chunks give it back: N = 4212 835 vs 829 ms per
+    // 300 iterations, lock-step batches of config C3 3 % slower.)
+    auto col_update = [&](std::vector<TileDesc>& tl, int p0, int j) {
+        const int kb0 = std::max(0, p0 - W);
+        if (j > kb0)
+            for (int i = j + 1; i < nb; ++i) tl.push_back({i, j, kb0, j});
     };
     if (nb < 64) {
         for (int p = 0; p < npanel; ++p) {
@@ -260,7 +256,7 @@ static void plan_updates(int nb, std::vector<std::vector<TileDesc>>& fill) {
             const size_t per = (bulk.size() + ncol - 1) / ncol;
             size_t taken = 0;
             for (int j = p0; j < p1; ++j) {
-                col_split(fill[j], p0, p1, j);
+                col_update(fill[j], p0, j);
                 for (size_t q = 0; q < per && taken < bulk.size(); ++q) fill[j].push_back(bulk[taken++]);
             }
         }
@@ -296,10 +292,7 @@ static void plan_updates(int nb, std::vector<std::vector<TileDesc>>& fill) {
         for (int j = p0; j < p1; ++j) {
             const int left = p1 - j;
             std::vector<TileDesc>& tl = fill[j];
-            const int kb0 = std::max(0, p0 - W);
-            if (!bulk_regime) col_split(tl, p0, p1, j);
-            else if (j > kb0)
-                for (int i = j + 1; i < nb; ++i) tl.push_back({i, j, kb0, j});
+            col_update(tl, p0, j);
             const size_t nreq = (req.size() - rtaken + left - 1) / left;
             for (size_t q = 0; q < nreq; ++q) tl.push_back(req[rtaken++]);
             if (!bulk_regime) {
@@ -604,7 +597,7 @@ int launch_potrf_steps(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_
                 // large batches saturate the chip by themselves: the pending tiles run as their own launch in front of a
                 // factorisation-only step launch.  Same tile operations in the same order per output element as the
                 // hosted form, hence the same bits as a stand-alone problem.
-                GP_TRY(launch_step(h, a, false, nf, host_shape((int64_t)P.n_update[j])));
+                GP_TRY(launch_step(h, a, false, nf, q));
                 GP_TRY(launch_step(h, a, true, 0, 4));
             } else {
                 GP_TRY(launch_step(h, a, true, nf, q));
