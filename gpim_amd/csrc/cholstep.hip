@@ -355,7 +355,7 @@ static int tri_nodes(int lo, int hi, std::vector<TriNodeS>& nodes) {
         nodes.push_back(n);
         return (int)nodes.size() - 1;
     }
-    n.mid = lo + (hi - lo + 1) / 2;
+    n.mid = lo + (hi - lo + 1) / 2;      // (left-heavy splits, mid = lo + 0.6 ... 0.85 of the node, leave MORE of the inverse after the last step: 3.2K -> 3.2K / 3.6K / 4.6K / 6.1K k-blocks at nb = 33)
     n.left = tri_nodes(lo, n.mid, nodes);
     n.right = tri_nodes(n.mid, hi, nodes);
     n.height = 1 + std::max(nodes[n.left].height, nodes[n.right].height);
@@ -617,7 +617,10 @@ int launch_potrf_steps(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_
         for (const PlanRange& r : P.post) {
             a.g = nt_update(A, ld, P.d_tiles + r.off, r.n, h->np);
             a.g.chunk = std::max(1, std::min(64, r.n / 512));
-            GP_TRY(launch_step(h, a, false, r.n, r.n * B <= 128 ? 4 : (r.n * B <= 512 ? 2 : 1)));
+            // quadrants up to 320 tiles: these launches hold a node's deepest tiles (k-depth up to the node's size), and the
+            // launch lasts as long as its longest workgroup (N = 4212: 0.369 -> 0.330 ms against 128; N = 8192 unchanged)
+            const int64_t nt = (int64_t)r.n * B;
+            GP_TRY(launch_step(h, a, false, r.n, nt <= 320 ? 4 : (nt <= 1280 ? 2 : 1)));
         }
     }
     return GPIMHIP_OK;
