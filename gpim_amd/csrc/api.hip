@@ -143,6 +143,11 @@ static int ws_ensure_b(gpimhip_ctx* h, int64_t N, int B, int padded, bool matric
         ws_release_matrix(h);
         return rc;
     }
+    if (matrices) {
+        // Tm / B: a ragged last block (GemmArgs::rag) never writes the rows of its identity padding
+        HIP_TRY(hipMemsetAsync(h->Tm, 0, (size_t)mat_doubles(h, B * np * ld) * sizeof(double), h->stream));
+        HIP_TRY(hipMemsetAsync(h->B, 0, (size_t)mat_doubles(h, B * np * ld) * sizeof(double), h->stream));
+    }
     if (h->fp32 && h->refine_cap < 10 * (int64_t)B * np) {
         dev_free(h, &h->refine, h->refine_cap);
         h->refine_cap = 0;
@@ -420,21 +425,22 @@ int launch_trtri(gpimhip_ctx* h, double* A, double* Tm, int64_t np, int64_t ld) 
 // A <- L^-1 for the SPD matrix in A (Tm: np x np temporary).  Double precision: one pass -- the tile operations of the
 // inverse ride in the launches of the factorisation (cholstep.hip: plan_inverse); float matrices: factorisation, then
 // the level-by-level inverse above.
-int launch_potrf_inv(gpimhip_ctx* h, double* A, double* Tm, int64_t np, int64_t ld, int32_t* info) {
-    if (!h->fp32) return launch_potrf_steps(h, A, np, ld, info, Tm);
+int launch_potrf_inv(gpimhip_ctx* h, double* A, double* Tm, int64_t np, int64_t ld, int32_t* info, int rag) {
+    if (!h->fp32) return launch_potrf_steps(h, A, np, ld, info, Tm, rag);
     { StageTimer t(h, 0); GP_TRY(launch_potrf_steps(h, A, np, ld, info, nullptr)); }
     StageTimer t(h, 1);
     return launch_trtri(h, A, Tm, np, ld);
 }
 
 // B(lower) = A^T A for lower-triangular A (= L^-1): K^-1.
-int launch_lauum(gpimhip_ctx* h, const double* A, double* B, int64_t np, int64_t ld) {
+int launch_lauum(gpimhip_ctx* h, const double* A, double* B, int64_t np, int64_t ld, int rag) {
     const int nb = (int)(np / NB);
     GP_TRY(plan_ensure(h, nb));
     const LinalgPlan& P = h->plan;
     GemmArgs g = gemm_args(A, ld, A, ld, B, ld, 1.0, 0.0, P.d_tiles + P.lauum.off, P.lauum.n, h->np);
     g.chunk = deal_chunk(g.ntiles);
     g.krev = 1;                   // ranges [ci, nb) share their end
+    g.rag = h->fp32 ? 0 : rag;
     return launch_gemm(h, true, true, EPI_STORE, g);
 }
 
@@ -486,7 +492,7 @@ static int factor_at_u(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X
     const int64_t np = h->np, ld = h->ld;
     GP_TRY(launch_theta(h, m, u));
     GP_TRY(launch_kmat(h, m, X, N, nullptr, N, h->theta, 0.0, 1, h->A, ld, np, np, 1, 1, x_bs, x_bs, np * ld));
-    GP_TRY(launch_potrf_inv(h, h->A, h->Tm, np, ld, h->info));
+    GP_TRY(launch_potrf_inv(h, h->A, h->Tm, np, ld, h->info, rag_of(N, np)));
     return solve_vectors(h, m, X, x_bs, N);
 }
 
@@ -497,7 +503,7 @@ static int loss_grad_at_u(gpimhip_ctx* h, const gpimhip_model_t* m, const double
                           double* hist_row, const IterTable* tab = nullptr) {
     const int64_t np = h->np;
     GP_TRY(factor_at_u(h, m, X, x_bs, N, u));
-    { StageTimer t(h, 2); GP_TRY(launch_lauum(h, h->A, h->B, np, h->ld)); }
+    { StageTimer t(h, 2); GP_TRY(launch_lauum(h, h->A, h->B, np, h->ld, rag_of(N, np))); }
     GP_TRY(launch_grad_reduce(h, m, h->B, h->ld, X, N, (int)(np / NB), h->alpha, x_bs));
     if (tab)
         GP_TRY(launch_finalize(h, m, N, np, u, do_adam, st, nullptr, nullptr, nullptr, tab->iter, tab->bc, tab->T,
@@ -826,6 +832,7 @@ static int predict_cols(gpimhip_ctx* h, const gpimhip_model_t* m, const double* 
         // a ragged last chunk still sweeps all column tiles of the slab (stale columns are ignored)
         g.ntiles = (int)h->pred_ntiles;
         g.chunk = deal_chunk(g.ntiles);
+        g.rag = h->fp32 ? 0 : rag_of(N, np);
         { StageTimer t(h, 3); GP_TRY(launch_gemm(h, false, true, EPI_COLSUMSQ, g)); }
         GP_TRY(launch_predict_var(h, mcap, nb, m0, cnt, var_out, M));
     }

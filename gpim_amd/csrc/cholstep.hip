@@ -33,6 +33,11 @@ struct StepArgs {
     double* dinv_all; double* dinvB_all; double* logdet; int32_t* info;
     int col_off;                // global index of the sub-matrix's first column (non-PD reporting)
     int potf2;                  // 0: no factorisation role in this launch (hosted tiles only)
+    // lock-step batches: the factorisation role works on problems pb_off .. pb_off + pb_cnt - 1, the hosted tiles on
+    // problems hb_off .. hb_off + hb_cnt - 1 (two halves of a large batch take turns: launch_potrf_steps).  swap: the
+    // problem index is blockIdx.x and the block index blockIdx.y -- workgroups are dispatched x-fastest, so every
+    // problem's factorisation role starts before any hosted tile, and problem i stays on XCD i % 8.
+    int pb_off, pb_cnt, hb_off, hb_cnt, swap;
     double* Tm;                 // != nullptr: fused inverse -- temporary of the T phases; the factorisation role writes
                                 // the INVERSE of its block into A's diagonal block (a leaf of the inverse) instead of dinv_all
     GemmArgs g;                 // hosted tiles; trailing-update tiles are NT with alpha = -1, beta = 1
@@ -54,25 +59,28 @@ __global__ __launch_bounds__(NTH, 4) void chol_step_kernel(StepArgs a) {
     static_assert(SM0 * 8 <= 80 * 1024, "two workgroups per CU");
     constexpr int SM = ALONE ? 84 * 128 : SM0;
     __shared__ __attribute__((aligned(16))) double smem[SM];
-    const int b = blockIdx.x;
+    const int b = a.swap ? blockIdx.y : blockIdx.x;
+    const int by = a.swap ? blockIdx.x : blockIdx.y;
     if (b >= 8) {
+        if (by >= a.hb_cnt) return;
+        const int pb = by + a.hb_off;
         int quad;
         const int pos = gemm_tile_pos<FTM, FTN>(a.g.ntiles, a.g.chunk, b - 8, quad);
         TileDesc t = a.g.tiles[pos];
         const int kind = t.kb1 >> 16;
         t.kb1 &= 0xffff;
         if (kind == 0) {
-            gemm_tile_core<false, false, EPI_STORE, 8, FTM, FTN>(a.g, t, quad, (int)blockIdx.y, smem);
+            gemm_tile_core<false, false, EPI_STORE, 8, FTM, FTN>(a.g, t, quad, pb, smem);
         } else {
             GemmArgs g = a.g;
             if (kind <= 2) { g.C = a.Tm; g.alpha = 1.0; g.beta = kind == 2 ? 1.0 : 0.0; }
             else { g.B = a.Tm; g.alpha = -1.0; g.beta = kind == 4 ? 1.0 : 0.0; }
-            gemm_tile_core<false, true, EPI_STORE, 8, FTM, FTN>(g, t, quad, (int)blockIdx.y, smem);
+            gemm_tile_core<false, true, EPI_STORE, 8, FTM, FTN>(g, t, quad, pb, smem);
         }
         return;
     }
-    if (b != 0 || !a.potf2) return;
-    potf2_body<double>(smem, (int)blockIdx.y, a.A, a.ld, a.kblk, a.dinv_all, a.dinvB_all, a.logdet, a.info, a.nb, a.col_off,
+    if (b != 0 || !a.potf2 || by >= a.pb_cnt) return;
+    potf2_body<double>(smem, by + a.pb_off, a.A, a.ld, a.kblk, a.dinv_all, a.dinvB_all, a.logdet, a.info, a.nb, a.col_off,
                        a.Tm != nullptr);
 }
 
@@ -82,13 +90,14 @@ __global__ __launch_bounds__(NTH, 4) void chol_step_kernel(StepArgs a) {
 // (Strips of 16 and of 64 rows were measured in round 3: both slower than 32 -- potrf at N = 4212: 1.694 / 1.647 /
 // 1.783 ms, at 16384: 29.65 / 28.96 / 29.60 -- the launch is bound by its load latency and by re-reading the inverse.)
 __global__ __launch_bounds__(256) void panel_solve_kernel(double* __restrict__ A, int64_t ld, int kblk, int nb,
-                                                          const double* __restrict__ dinvB_all) {
+                                                          const double* __restrict__ dinvB_all, int b_off) {
     constexpr int LDS_LD = 130;             // 130 % 32 == 2: the A-fragment reads below are bank-conflict free
     constexpr int ROWS = 32, MTS = ROWS / 16;
     __shared__ __attribute__((aligned(16))) double S[ROWS * LDS_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    A += (int64_t)blockIdx.y * nb * NB * ld;
-    const d2* DB = reinterpret_cast<const d2*>(dinvB_all + ((int64_t)blockIdx.y * nb + kblk) * (NB * NB));
+    const int by = blockIdx.y + b_off;          // problem of a lock-step batch
+    A += (int64_t)by * nb * NB * ld;
+    const d2* DB = reinterpret_cast<const d2*>(dinvB_all + ((int64_t)by * nb + kblk) * (NB * NB));
     double* P = A + ((int64_t)(kblk + 1) * NB + (int64_t)blockIdx.x * ROWS) * ld + (int64_t)kblk * NB;
     // the strip: one 1 KB row per wave-wide load, global -> LDS directly
 #pragma unroll
@@ -143,11 +152,11 @@ __global__ __launch_bounds__(256) void panel_solve_kernel(double* __restrict__ A
 // Diagonal tiles (jj,jj), jj = kblk+1 .. kblk+ntile, -= L[jj,kblk] L[jj,kblk]^T, one workgroup (4 waves, one
 // 16x16 MFMA tile each) per 32x32 quadrant of the lower half; one-shot like the panel solve: both 32x128
 // operand strips go straight to LDS, the C values to registers, all loads in flight together.
-__global__ __launch_bounds__(256) void diag_update_kernel(double* __restrict__ A, int64_t ld, int kblk, int nb) {
+__global__ __launch_bounds__(256) void diag_update_kernel(double* __restrict__ A, int64_t ld, int kblk, int nb, int b_off) {
     constexpr int LDS_LD = 130;
     __shared__ __attribute__((aligned(16))) double S[64 * LDS_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    A += (int64_t)blockIdx.y * nb * NB * ld;
+    A += (int64_t)(blockIdx.y + b_off) * nb * NB * ld;
     const int jj = kblk + 1 + blockIdx.x / 10, q = blockIdx.x % 10;
     // q -> (a, b), a >= b, a, b in 0..3
     const int a = q < 1 ? 0 : q < 3 ? 1 : q < 6 ? 2 : 3, b = q - a * (a + 1) / 2;
@@ -480,6 +489,9 @@ static int step_plan_build(gpimhip_ctx* h, int nb, StepPlan& P, bool with_invers
     for (int j = 0; j < nb; ++j)
         for (auto& t : fill[j]) P.n_update[j] += t.kb1 - t.kb0;
     if (with_inverse) plan_inverse(nb, fill, post);
+    P.n_all.assign(nb, 0);
+    for (int j = 0; j < nb; ++j)
+        for (auto& t : fill[j]) P.n_all[j] += (t.kb1 & 0xffff) - t.kb0;
     std::vector<TileDesc> tl;
     auto put = [&](const std::vector<TileDesc>& v) {
         PlanRange r{(int64_t)tl.size(), (int32_t)v.size()};
@@ -551,17 +563,41 @@ static GemmArgs nt_update(double* A, int64_t ld, const TileDesc* tiles, int n, i
     return g;
 }
 
-// one launch of the step kernel: `potf2` = with the factorisation role for block a.kblk, n hosted tiles in shape q
-static int launch_step(gpimhip_ctx* h, StepArgs& a, bool potf2, int n, int q) {
+// one launch of the step kernel: `potf2` = with the factorisation role for block a.kblk, n hosted tiles in shape q.
+// Batches: both roles on all problems of the handle's batch, or (split != nullptr) the factorisation role on problems
+// split[0] .. +split[1] and the hosted tiles on problems split[2] .. +split[3], problem index in blockIdx.x.
+static int launch_step(gpimhip_ctx* h, StepArgs& a, bool potf2, int n, int q, const int* split = nullptr) {
     const int B = h->nbatch;
     a.potf2 = potf2 ? 1 : 0;
     if (!potf2 && n == 0) return GPIMHIP_OK;
-    const dim3 grid(n ? 8 + q * n : 1, B);
-    if (q == 4 && potf2) hipLaunchKernelGGL((chol_step_kernel<64, 64, true>), grid, dim3(NTH), 0, h->stream, a);
+    a.pb_off = a.hb_off = 0; a.pb_cnt = a.hb_cnt = B; a.swap = 0;
+    dim3 grid(n ? 8 + q * n : 1, B);
+    bool alone = potf2;
+    if (split) {
+        a.pb_off = split[0]; a.pb_cnt = potf2 ? split[1] : 0; a.hb_off = split[2]; a.hb_cnt = n ? split[3] : 0; a.swap = 1;
+        grid = dim3(std::max(a.pb_cnt, a.hb_cnt), n ? 8 + q * n : 1);
+        alone = false;          // the hosted half-batch fills the chip: two workgroups per CU
+        if (grid.x == 0) return GPIMHIP_OK;
+        if (grid.y > 65535) { gpim_set_error("step launch: tile list too long for a split batch"); return GPIMHIP_E_BADARG; }
+    }
+    if (q == 4 && alone) hipLaunchKernelGGL((chol_step_kernel<64, 64, true>), grid, dim3(NTH), 0, h->stream, a);
     else if (q == 4) hipLaunchKernelGGL((chol_step_kernel<64, 64, false>), grid, dim3(NTH), 0, h->stream, a);
     else if (q == 2) hipLaunchKernelGGL((chol_step_kernel<128, 64, false>), grid, dim3(NTH), 0, h->stream, a);
     else hipLaunchKernelGGL((chol_step_kernel<128, 128, false>), grid, dim3(NTH), 0, h->stream, a);
     HIP_TRY(hipGetLastError());
+    return GPIMHIP_OK;
+}
+
+// F_j and D_j for the problems b_off .. b_off + cnt - 1 of the batch
+static int launch_solve_diag(gpimhip_ctx* h, double* A, int64_t ld, int j, int nb, int ndiag, int b_off, int cnt) {
+    if (j + 1 >= nb || cnt <= 0) return GPIMHIP_OK;
+    hipLaunchKernelGGL(panel_solve_kernel, dim3(4 * (nb - j - 1), cnt), dim3(256), 0, h->stream, A, ld, j, nb,
+                       (const double*)h->dinvB, b_off);
+    HIP_TRY(hipGetLastError());
+    if (ndiag > 0) {
+        hipLaunchKernelGGL(diag_update_kernel, dim3(10 * ndiag, cnt), dim3(256), 0, h->stream, A, ld, j, nb, b_off);
+        HIP_TRY(hipGetLastError());
+    }
     return GPIMHIP_OK;
 }
 
@@ -572,7 +608,7 @@ static int launch_step(gpimhip_ctx* h, StepArgs& a, bool potf2, int n, int q) {
 //                the tile operations of the triangular inverse ride in the step launches (plan_inverse), Tm is the
 //                np x np temporary of its T phases.
 int launch_potrf_steps_f32(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_t* info);   // cholstep32.hip
-int launch_potrf_steps(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_t* info, double* Tm) {
+int launch_potrf_steps(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_t* info, double* Tm, int rag) {
     if (h->fp32) return launch_potrf_steps_f32(h, A, np, ld, info);
     const int nb = (int)(np / NB), W = STEP_W;
     if (Tm) GP_TRY(step_plan_ensure_inv(h, nb));
@@ -586,28 +622,45 @@ int launch_potrf_steps(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_
     a.col_off = 0;
     {
         StageTimer t(h, 0);
-        for (int j = 0; j < nb; ++j) {
-            a.kblk = j;
+        auto hosted_list = [&](int j, int problems, int& q) {
             const int nf = P.fill[j].n;
             a.g = nt_update(A, ld, P.d_tiles + P.fill[j].off, nf, h->np);
             // mixed k-ranges (column updates are up to 2W-1 blocks deep, bulk tiles W or 2W): deal the list to the XCDs in chunks
             a.g.chunk = std::max(1, std::min(64, nf / 512));
-            const int q = host_shape((int64_t)P.n_update[j] * B);
-            if (B > host_max_batch) {
-                // large batches saturate the chip by themselves: the pending tiles run as their own launch in front of a
-                // factorisation-only step launch.  Same tile operations in the same order per output element as the
-                // hosted form, hence the same bits as a stand-alone problem.
-                GP_TRY(launch_step(h, a, false, nf, q));
-                GP_TRY(launch_step(h, a, true, 0, 4));
-            } else {
-                GP_TRY(launch_step(h, a, true, nf, q));
+            a.g.rag = rag;
+            // a large batch is bound by throughput: every hosted k-block counts (P.n_all), not only the trailing update's
+            q = host_shape((int64_t)(B > host_max_batch ? P.n_all[j] : P.n_update[j]) * problems);
+            return nf;
+        };
+        if (B > host_max_batch) {
+            // Large batches saturate the chip by themselves, and a launch with the factorisation role alone (one workgroup
+            // per problem, 35-50 us) leaves most of it idle.  The two halves of the batch take turns: one launch holds the
+            // factorisation role of block column j for one half and the pending tile operations of the OTHER half, whose
+            // chain is half a step behind.  Same tile operations in the same order per output element as the hosted form
+            // of a stand-alone problem, hence the same bits.
+            const int c0 = (B + 1) / 2, c1 = B - c0;
+            int q;
+            int nf = hosted_list(0, c0, q);
+            const int first[4] = {0, 0, 0, c0};
+            GP_TRY(launch_step(h, a, false, nf, q, first));                    // (empty today: nothing is pending at step 0)
+            for (int j = 0; j < nb; ++j) {
+                a.kblk = j;
+                nf = hosted_list(j, c1, q);
+                const int sa[4] = {0, c0, c0, c1};                             // factor half 0 || pending tiles of half 1
+                GP_TRY(launch_step(h, a, true, nf, q, sa));
+                GP_TRY(launch_solve_diag(h, A, ld, j, nb, P.diag[j].n, 0, c0));
+                nf = j + 1 < nb ? hosted_list(j + 1, c0, q) : 0;
+                const int sb[4] = {c0, c1, 0, c0};                             // factor half 1 || pending tiles of half 0, next step
+                GP_TRY(launch_step(h, a, true, nf, q, sb));
+                GP_TRY(launch_solve_diag(h, A, ld, j, nb, P.diag[j].n, c0, c1));
             }
-            if (j + 1 < nb) {
-                hipLaunchKernelGGL(panel_solve_kernel, dim3(4 * (nb - j - 1), B), dim3(256), 0, h->stream, A, ld, j, nb,
-                                   (const double*)h->dinvB);
-                HIP_TRY(hipGetLastError());
-                hipLaunchKernelGGL(diag_update_kernel, dim3(10 * P.diag[j].n, B), dim3(256), 0, h->stream, A, ld, j, nb);
-                HIP_TRY(hipGetLastError());
+        } else {
+            for (int j = 0; j < nb; ++j) {
+                a.kblk = j;
+                int q;
+                const int nf = hosted_list(j, B, q);
+                GP_TRY(launch_step(h, a, true, nf, q));
+                GP_TRY(launch_solve_diag(h, A, ld, j, nb, P.diag[j].n, 0, B));
             }
         }
     }
@@ -617,6 +670,7 @@ int launch_potrf_steps(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_
         for (const PlanRange& r : P.post) {
             a.g = nt_update(A, ld, P.d_tiles + r.off, r.n, h->np);
             a.g.chunk = std::max(1, std::min(64, r.n / 512));
+            a.g.rag = rag;
             // quadrants up to 320 tiles: these launches hold a node's deepest tiles (k-depth up to the node's size), and the
             // launch lasts as long as its longest workgroup (N = 4212: 0.369 -> 0.330 ms against 128; N = 8192 unchanged)
             const int64_t nt = (int64_t)r.n * B;
@@ -643,15 +697,7 @@ int launch_panel_chain(gpimhip_ctx* h, double* A, int64_t ld, int p0, int p1, in
         a.g = nt_update(A, ld, tiles + f.off, f.n, h->np);
         a.g.chunk = 1;
         GP_TRY(launch_step(h, a, true, f.n, f.n <= 128 ? 4 : 2));
-        if (j + 1 < nb) {
-            hipLaunchKernelGGL(panel_solve_kernel, dim3(4 * (nb - j - 1), B), dim3(256), 0, h->stream, A, ld, j, nb,
-                               (const double*)h->dinvB);
-            HIP_TRY(hipGetLastError());
-        }
-        if (j + 1 < p1) {
-            hipLaunchKernelGGL(diag_update_kernel, dim3(10 * (p1 - j - 1), B), dim3(256), 0, h->stream, A, ld, j, nb);
-            HIP_TRY(hipGetLastError());
-        }
+        GP_TRY(launch_solve_diag(h, A, ld, j, nb, std::max(0, p1 - j - 1), 0, B));
     }
     return GPIMHIP_OK;
 }

@@ -81,6 +81,7 @@ struct StepPlan {
     std::vector<PlanRange> bulk_rest;   // per outer panel: bulk update launched before its first step (float handles)
     std::vector<PlanRange> post;        // fused inverse: what is left of it after the last step, launch by launch
     std::vector<int32_t> n_update;      // per block column: k-blocks of trailing update among fill[] (sets the hosted shape)
+    std::vector<int32_t> n_all;         // per block column: all hosted k-blocks (shape of the launches of a large batch)
 };
 
 // Launch plans of the distributed (block-column-cyclic, 1 x P) factorisation for one rank (api.hip: gpimhip_dist_*)
@@ -174,6 +175,11 @@ struct gpimhip_ctx {
     } while (0)
 
 static inline int64_t pad_to(int64_t n, int64_t m) { return (n + m - 1) / m * m; }
+// GemmArgs::rag for an exact-GP matrix of N valid rows padded to np with the identity
+static inline int rag_of(int64_t N, int64_t np) {
+    const int64_t last = N - (np - NB);
+    return (np >= 2 * NB && last > 0 && last <= 64) ? (int)(np / NB) : 0;
+}
 
 // stage timers (bench.py): 0 factorisation (with the part of the inverse its launches host), 1 rest of the triangular
 // inverse, 2 K^-1 product (one tile-engine launch), 3 predictive-variance product
@@ -194,7 +200,7 @@ int ws_ensure(gpimhip_ctx* h, int64_t N);
 int ws_ensure_predict(gpimhip_ctx* h, int64_t np, int64_t mc);
 int plan_ensure(gpimhip_ctx* h, int nb);
 // cholstep.hip
-int launch_potrf_steps(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_t* info, double* Tm = nullptr);
+int launch_potrf_steps(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_t* info, double* Tm = nullptr, int rag = 0);
 void step_plan_release(gpimhip_ctx* h);
 int step_plan_ensure(gpimhip_ctx* h, int nb);
 int step_plan_ensure_inv(gpimhip_ctx* h, int nb);
@@ -237,6 +243,10 @@ struct GemmArgs {
                                            // stored at local columns (distributed layouts); needs kfix0 / kfix1
     int chunk;                             // XCD dealing: 0 = contiguous slices, >0 = round-robin chunks
     int inplace;                           // C aliases an operand tile (panel solve): one workgroup must own the whole tile
+    int rag;                               // > 0: block rag - 1 (the LAST block of the matrix order) holds at most 64 valid
+                                           // rows / columns, the rest is identity padding: output rows >= 64 of block row
+                                           // rag - 1 and the k-steps >= 64 of a range ending with that block are structurally
+                                           // zero and skipped (exact GP with (N - 1) % 128 < 64: rag_of())
     int krev;                              // walk each tile's k-range from its end (ranges sharing their upper end)
     int kfix0, kfix1;                      // when kfix1 > kfix0: every tile uses this k-block range (its own is ignored)
     double* colpart; int64_t ld_colpart;   // EPI_COLSUMSQ: colpart[ci*ld + cj*128 + col]

@@ -182,8 +182,13 @@ __device__ __forceinline__ void gemm_tile_core(GemmArgs g, TileDesc t, const int
     if (g.cj_max > 0 && t.cj >= g.cj_max) return;   // (the whole workgroup: t is uniform)
     const int ccb = g.cmap ? t.kb0 : t.cj;          // block column of the output (see GemmArgs::cmap)
     if (g.kfix1 > g.kfix0) { t.kb0 = g.kfix0; t.kb1 = g.kfix1; }
-    const int nsteps = (t.kb1 - t.kb0) * (NB / GEMM_BK);
+    int nsteps = (t.kb1 - t.kb0) * (NB / GEMM_BK);
     const int qi = (quad / QN) * TSM, qj = (quad % QN) * TSN;
+    // ragged last block (GemmArgs::rag): its rows / columns >= 64 are identity padding
+    if (g.rag && t.kb1 == g.rag) nsteps -= 64 / GEMM_BK;
+    const bool rag_row = g.rag && t.ci == g.rag - 1;
+    if (TSM <= 64 && rag_row && qi >= 64) return;                   // (the whole workgroup)
+    const bool dead = rag_row && qi + wm * WROWS >= 64;             // this wave's rows: no MFMAs, nothing stored
     // batch: by selects the problem; operands advance by their per-problem strides
     g.A += by * g.sA;
     g.B += by * g.sB;
@@ -228,6 +233,7 @@ __device__ __forceinline__ void gemm_tile_core(GemmArgs g, TileDesc t, const int
             const double* As = smem + (s % NSTG) * 2 * STAGE;
             const double* Bs = As + STAGE;
             __builtin_amdgcn_s_setprio(3);
+            if (!dead) {
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 double a[MT], bb[NTL];
@@ -242,6 +248,7 @@ __device__ __forceinline__ void gemm_tile_core(GemmArgs g, TileDesc t, const int
 #pragma unroll
                     for (int j = 0; j < NTL; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bb[j], acc[i][j], 0, 0, 0);
+            }
             }
             __builtin_amdgcn_s_setprio(0);
         }
@@ -276,6 +283,7 @@ __device__ __forceinline__ void gemm_tile_core(GemmArgs g, TileDesc t, const int
             // fragment reads over the other resident wave's staging instructions, which otherwise steal
             // issue slots from the matrix pipe (tools/gemm_ablate.hip: 66.1 -> 71.2 TFLOP/s for this loop).
             __builtin_amdgcn_s_setprio(3);
+            if (!dead) {
     #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 double a[MT], bb[NTL];
@@ -293,6 +301,7 @@ __device__ __forceinline__ void gemm_tile_core(GemmArgs g, TileDesc t, const int
                     for (int j = 0; j < NTL; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bb[j], acc[i][j], 0, 0, 0);
             }
+            }
             __builtin_amdgcn_s_setprio(0);
             if (more) {
                 double* An = smem + ((s + 1) & 1) * 2 * STAGE;
@@ -306,6 +315,7 @@ __device__ __forceinline__ void gemm_tile_core(GemmArgs g, TileDesc t, const int
     }
 
     if (EPI == EPI_STORE) {
+        if (dead) return;                       // (no barrier after this point)
         const int64_t crow0 = (int64_t)(t.ci + g.c_roff) * NB + qi + wm * WROWS + (lane >> 4);
         const int64_t ccol0 = (int64_t)(ccb + g.c_coff) * NB + qj + wn * WCOLS + (lane & 15);
         const double alpha = g.alpha, beta = g.beta;

@@ -31,8 +31,8 @@ int launch_kmat(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X, int64
                 int64_t z_bs, int64_t out_bs);
 int launch_potrf(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_t* info);
 int launch_trtri(gpimhip_ctx* h, double* A, double* Tm, int64_t np, int64_t ld);
-int launch_potrf_inv(gpimhip_ctx* h, double* A, double* Tm, int64_t np, int64_t ld, int32_t* info);
-int launch_lauum(gpimhip_ctx* h, const double* A, double* B, int64_t np, int64_t ld);
+int launch_potrf_inv(gpimhip_ctx* h, double* A, double* Tm, int64_t np, int64_t ld, int32_t* info, int rag);
+int launch_lauum(gpimhip_ctx* h, const double* A, double* B, int64_t np, int64_t ld, int rag);
 int launch_trmv_lower(gpimhip_ctx* h, const double* L, int64_t ld, int64_t np, const double* y, double* z);
 hipStream_t ensure_capture_stream(gpimhip_ctx* h);
 void capture_lock(gpimhip_ctx* h);
@@ -523,7 +523,7 @@ static int vfe_forward(gpimhip_ctx* h, VfeWs& w, const gpimhip_model_t* m, const
     const double* Xu = u + P;
     GP_TRY(launch_theta(h, m, u));
     GP_TRY(launch_kmat(h, m, Xu, Mu, nullptr, Mu, h->theta, m->jitter, 0, h->A, mp, mp, mp, 1, 1, 0, 0, 0));
-    GP_TRY(launch_potrf_inv(h, h->A, h->Tm, mp, mp, h->info));
+    GP_TRY(launch_potrf_inv(h, h->A, h->Tm, mp, mp, h->info, 0));
     GP_TRY(launch_kmat(h, m, Xu, Mu, X, N, h->theta, 0.0, 0, w.Bm, nq, mp, nq, 0, 0, 0, 0, 0));
     {   // W = Luu^-1 B
         GemmArgs g = vg(h->A, mp, w.Bm, nq, w.Wm, nq, 1.0, 0.0, w.tiles + w.off_lowtri_rect, w.n_lowtri_rect);
@@ -535,7 +535,7 @@ static int vfe_forward(gpimhip_ctx* h, VfeWs& w, const gpimhip_model_t* m, const
         hipLaunchKernelGGL(vfe_cap_kernel, dim3((unsigned)((mp * mp + 255) / 256)), dim3(256), 0, h->stream, h->B, w.Cs,
                            mp, h->theta);
     }
-    GP_TRY(launch_potrf_inv(h, h->B, h->Tm, mp, mp, h->info));   // h->B = Lc^-1, logdet_part <- log diag Lc
+    GP_TRY(launch_potrf_inv(h, h->B, h->Tm, mp, mp, h->info, 0));   // h->B = Lc^-1, logdet_part <- log diag Lc
     // v = W y / s ; c1 = Lc^-1 v
     hipLaunchKernelGGL(gemv_n_kernel, dim3((unsigned)((mp + 3) / 4)), dim3(256), 0, h->stream, w.Wm, nq, mp, nq, w.yq, w.v);
     hipLaunchKernelGGL(vfe_scale_kernel, dim3((unsigned)((mp + 255) / 256)), dim3(256), 0, h->stream, w.v, mp, h->theta);
@@ -552,7 +552,7 @@ static int vfe_loss_grad(gpimhip_ctx* h, VfeWs& w, const gpimhip_model_t* m, con
     const int mb = (int)(mp / NB), nbq = (int)(nq / NB);
     const double* Xu = u + P;
     GP_TRY(vfe_forward(h, w, m, X, N, Mu, u, P));
-    GP_TRY(launch_lauum(h, h->B, w.Vc, mp, mp));              // Cc^-1 (lower)
+    GP_TRY(launch_lauum(h, h->B, w.Vc, mp, mp, 0));              // Cc^-1 (lower)
     GP_TRY(launch_gemv_t(h, h->B, mp, mp, mp, w.c1, w.beta, 1, 0, 0, 0));          // beta = Lc^-T c1
     GP_TRY(launch_gemv_t(h, w.Wm, nq, mp, nq, w.beta, w.wtb, 0, 0, 0, 0));         // W^T beta
     {   // Y1 = Lc^-1 W ; Y2 = Lc^-T Y1 = Cc^-1 W
