@@ -92,7 +92,7 @@ __global__ __launch_bounds__(NTH, 4) void chol_step_kernel(StepArgs a) {
 // tile t needs k-steps 0 .. 4t+3, so every wave runs 36 of them per 16 rows).
 // (Strips of 16 and of 64 rows were measured in round 3: both slower than 32 -- potrf at N = 4212: 1.694 / 1.647 /
 // 1.783 ms, at 16384: 29.65 / 28.96 / 29.60 -- the launch is bound by its load latency and by re-reading the inverse.)
-__global__ __launch_bounds__(256) void panel_solve_kernel(double* __restrict__ A, int64_t ld, int kblk, int nb,
+__global__ __launch_bounds__(256, 2) void panel_solve_kernel(double* __restrict__ A, int64_t ld, int kblk, int nb,
                                                           const double* __restrict__ dinvB_all, int b_off) {
     constexpr int LDS_LD = 130;             // 130 % 32 == 2: the A-fragment reads below are bank-conflict free
     constexpr int ROWS = 32, MTS = ROWS / 16;
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void panel_solve_kernel(double* __restrict__ A
 // Diagonal tiles (jj,jj), jj = kblk+1 .. kblk+ntile, -= L[jj,kblk] L[jj,kblk]^T, one workgroup (4 waves, one
 // 16x16 MFMA tile each) per 32x32 quadrant of the lower half; one-shot like the panel solve: both 32x128
 // operand strips go straight to LDS, the C values to registers, all loads in flight together.
-__global__ __launch_bounds__(256) void diag_update_kernel(double* __restrict__ A, int64_t ld, int kblk, int nb, int b_off) {
+__global__ __launch_bounds__(256, 2) void diag_update_kernel(double* __restrict__ A, int64_t ld, int kblk, int nb, int b_off) {
     constexpr int LDS_LD = 130;
     __shared__ __attribute__((aligned(16))) double S[64 * LDS_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

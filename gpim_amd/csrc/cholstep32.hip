@@ -50,7 +50,7 @@ __global__ __launch_bounds__(NTH, 4) void chol_step_kernel_f32(StepArgs32 a) {
 // S = P * Dinv^T in place.  Wave w owns the 16-column tiles w and 7 - w (36 k-steps per 16 rows for every wave).
 // LDS rows are 130 floats apart: 130 % 32 == 2 puts the 16 rows x 4 k of a fragment read on 64 distinct
 // (bank, half) slots; 8-byte row alignment, hence the strip is moved in 8-byte chunks.
-__global__ __launch_bounds__(256) void panel_solve_kernel_f32(float* __restrict__ A, int64_t ld, int kblk, int nb,
+__global__ __launch_bounds__(256, 2) void panel_solve_kernel_f32(float* __restrict__ A, int64_t ld, int kblk, int nb,
                                                               const double* __restrict__ dinvB_all) {
     constexpr int LDS_LD = 130;
     __shared__ __attribute__((aligned(16))) float S[32 * LDS_LD];
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void panel_solve_kernel_f32(float* __restrict_
 
 // Diagonal tiles (jj,jj), jj = kblk+1 .. kblk+ntile, -= L[jj,kblk] L[jj,kblk]^T: one workgroup (4 waves, one 16x16
 // MFMA tile each) per 32x32 quadrant of the lower half, one-shot like the panel solve.
-__global__ __launch_bounds__(256) void diag_update_kernel_f32(float* __restrict__ A, int64_t ld, int kblk, int nb) {
+__global__ __launch_bounds__(256, 2) void diag_update_kernel_f32(float* __restrict__ A, int64_t ld, int kblk, int nb) {
     constexpr int LDS_LD = 130;
     __shared__ __attribute__((aligned(16))) float S[64 * LDS_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

@@ -36,7 +36,7 @@ struct FusedPredictArgs {
 };
 
 template <int KIND>
-__global__ __launch_bounds__(256) void predict_fused_kernel(FusedPredictArgs a) {
+__global__ __launch_bounds__(256, 2) void predict_fused_kernel(FusedPredictArgs a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int np = (int)a.np;
     double* Ks = smem;                                  // [np][PF_LDK]
