@@ -53,7 +53,7 @@ struct StepArgs {
 // where the chain of diagonal blocks bounds the launch, a hosted workgroup on the factorisation role's CU stretches
 // the role from 35 to 50 us (its serial fp64 chain shares the SIMD's fp64 pipe with the neighbour's MFMAs), and what
 // such a launch hosts for free is one quadrant per CU anyway.
-template <int FTM, int FTN, bool ALONE>
+template <int FTM, int FTN, bool ALONE, bool RAG = false>
 __global__ __launch_bounds__(NTH, 4) void chol_step_kernel(StepArgs a) {
     constexpr int SM0 = POTF2_SMEM_DOUBLES > gemm_smem_doubles<FTM, FTN, 2>() ? POTF2_SMEM_DOUBLES : gemm_smem_doubles<FTM, FTN, 2>();
     static_assert(SM0 * 8 <= 80 * 1024, "two workgroups per CU");
@@ -70,12 +70,12 @@ __global__ __launch_bounds__(NTH, 4) void chol_step_kernel(StepArgs a) {
         const int kind = t.kb1 >> 16;
         t.kb1 &= 0xffff;
         if (kind == 0) {
-            gemm_tile_core<false, false, EPI_STORE, 8, FTM, FTN>(a.g, t, quad, pb, smem);
+            gemm_tile_core<false, false, EPI_STORE, 8, FTM, FTN, 2, RAG>(a.g, t, quad, pb, smem);
         } else {
             GemmArgs g = a.g;
             if (kind <= 2) { g.C = a.Tm; g.alpha = 1.0; g.beta = kind == 2 ? 1.0 : 0.0; }
             else { g.B = a.Tm; g.alpha = -1.0; g.beta = kind == 4 ? 1.0 : 0.0; }
-            gemm_tile_core<false, true, EPI_STORE, 8, FTM, FTN>(g, t, quad, pb, smem);
+            gemm_tile_core<false, true, EPI_STORE, 8, FTM, FTN, 2, RAG>(g, t, quad, pb, smem);
         }
         return;
     }
@@ -583,7 +583,12 @@ static int launch_step(gpimhip_ctx* h, StepArgs& a, bool potf2, int n, int q, co
         if (grid.x == 0) return GPIMHIP_OK;
         if (grid.y > 65535) { gpim_set_error("step launch: tile list too long for a split batch"); return GPIMHIP_E_BADARG; }
     }
-    if (q == 4 && alone) hipLaunchKernelGGL((chol_step_kernel<64, 64, true>), grid, dim3(NTH), 0, h->stream, a);
+    if (a.g.rag && n) {           // ragged last block (GemmArgs::rag): the instantiations whose hosted tiles skip its padding
+        if (q == 4 && alone) hipLaunchKernelGGL((chol_step_kernel<64, 64, true, true>), grid, dim3(NTH), 0, h->stream, a);
+        else if (q == 4) hipLaunchKernelGGL((chol_step_kernel<64, 64, false, true>), grid, dim3(NTH), 0, h->stream, a);
+        else if (q == 2) hipLaunchKernelGGL((chol_step_kernel<128, 64, false, true>), grid, dim3(NTH), 0, h->stream, a);
+        else hipLaunchKernelGGL((chol_step_kernel<128, 128, false, true>), grid, dim3(NTH), 0, h->stream, a);
+    } else if (q == 4 && alone) hipLaunchKernelGGL((chol_step_kernel<64, 64, true>), grid, dim3(NTH), 0, h->stream, a);
     else if (q == 4) hipLaunchKernelGGL((chol_step_kernel<64, 64, false>), grid, dim3(NTH), 0, h->stream, a);
     else if (q == 2) hipLaunchKernelGGL((chol_step_kernel<128, 64, false>), grid, dim3(NTH), 0, h->stream, a);
     else hipLaunchKernelGGL((chol_step_kernel<128, 128, false>), grid, dim3(NTH), 0, h->stream, a);

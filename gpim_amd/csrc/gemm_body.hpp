@@ -151,18 +151,21 @@ __device__ __forceinline__ int gemm_tile_pos(int n, int chunk, int bx, int& quad
     return b;
 }
 
-template <bool A_KM, bool B_KM, int EPI, int NW, int TSM, int TSN, int NSTG = 2>
+// RAG: the launch has a ragged last block (GemmArgs::rag != 0).  A template parameter so that the k-loop of every other
+// launch keeps its schedule (as a run-time test inside the loop it cost the K^-1 product at N = 16384 0.4 %).
+template <bool A_KM, bool B_KM, int EPI, int NW, int TSM, int TSN, int NSTG = 2, bool RAG = false>
 __device__ __forceinline__ void gemm_tile_core(GemmArgs g, TileDesc t, const int quad, const int by, double* __restrict__ smem);
 
 template <bool A_KM, bool B_KM, int EPI, int NW, int TSM, int TSN, int NSTG = 2>
 __device__ __forceinline__ void gemm_tile_body(GemmArgs g, const int bx, const int by, double* __restrict__ smem) {
     int quad;
     const int p = gemm_tile_pos<TSM, TSN>(g.ntiles, g.chunk, bx, quad);
-    gemm_tile_core<A_KM, B_KM, EPI, NW, TSM, TSN, NSTG>(g, g.tiles[p], quad, by, smem);
+    if (g.rag) gemm_tile_core<A_KM, B_KM, EPI, NW, TSM, TSN, NSTG, true>(g, g.tiles[p], quad, by, smem);
+    else gemm_tile_core<A_KM, B_KM, EPI, NW, TSM, TSN, NSTG, false>(g, g.tiles[p], quad, by, smem);
 }
 
 // one tile (or its quadrant / half `quad`) of a tile-engine launch
-template <bool A_KM, bool B_KM, int EPI, int NW, int TSM, int TSN, int NSTG>
+template <bool A_KM, bool B_KM, int EPI, int NW, int TSM, int TSN, int NSTG, bool RAG>
 __device__ __forceinline__ void gemm_tile_core(GemmArgs g, TileDesc t, const int quad, const int by, double* __restrict__ smem) {
     constexpr int NT = NW * 64;             // threads
     constexpr int WGM = NW / 2;             // waves along m (2 along n)
@@ -185,10 +188,10 @@ __device__ __forceinline__ void gemm_tile_core(GemmArgs g, TileDesc t, const int
     int nsteps = (t.kb1 - t.kb0) * (NB / GEMM_BK);
     const int qi = (quad / QN) * TSM, qj = (quad % QN) * TSN;
     // ragged last block (GemmArgs::rag): its rows / columns >= 64 are identity padding
-    if (g.rag && t.kb1 == g.rag) nsteps -= 64 / GEMM_BK;
-    const bool rag_row = g.rag && t.ci == g.rag - 1;
-    if (TSM <= 64 && rag_row && qi >= 64) return;                   // (the whole workgroup)
-    const bool dead = rag_row && qi + wm * WROWS >= 64;             // this wave's rows: no MFMAs, nothing stored
+    if (RAG && t.kb1 == g.rag) nsteps -= 64 / GEMM_BK;
+    const bool rag_row = RAG && t.ci == g.rag - 1;
+    if (RAG && TSM <= 64 && rag_row && qi >= 64) return;            // (the whole workgroup)
+    const bool dead = RAG && rag_row && qi + wm * WROWS >= 64;      // this wave's rows: no MFMAs, nothing stored
     // batch: by selects the problem; operands advance by their per-problem strides
     g.A += by * g.sA;
     g.B += by * g.sB;
@@ -233,7 +236,7 @@ __device__ __forceinline__ void gemm_tile_core(GemmArgs g, TileDesc t, const int
             const double* As = smem + (s % NSTG) * 2 * STAGE;
             const double* Bs = As + STAGE;
             __builtin_amdgcn_s_setprio(3);
-            if (!dead) {
+            if (!RAG || !dead) {
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 double a[MT], bb[NTL];
@@ -283,7 +286,7 @@ __device__ __forceinline__ void gemm_tile_core(GemmArgs g, TileDesc t, const int
             // fragment reads over the other resident wave's staging instructions, which otherwise steal
             // issue slots from the matrix pipe (tools/gemm_ablate.hip: 66.1 -> 71.2 TFLOP/s for this loop).
             __builtin_amdgcn_s_setprio(3);
-            if (!dead) {
+            if (!RAG || !dead) {
     #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 double a[MT], bb[NTL];
@@ -315,7 +318,7 @@ __device__ __forceinline__ void gemm_tile_core(GemmArgs g, TileDesc t, const int
     }
 
     if (EPI == EPI_STORE) {
-        if (dead) return;                       // (no barrier after this point)
+        if (RAG && dead) return;                // (no barrier after this point)
         const int64_t crow0 = (int64_t)(t.ci + g.c_roff) * NB + qi + wm * WROWS + (lane >> 4);
         const int64_t ccol0 = (int64_t)(ccb + g.c_coff) * NB + qj + wn * WCOLS + (lane & 15);
         const double alpha = g.alpha, beta = g.beta;

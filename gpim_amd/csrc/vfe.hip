@@ -49,6 +49,8 @@ int vfe_finish_and_check(gpimhip_ctx* h);
 struct VfeWs {
     int64_t mp = 0, nq = 0;       // padded Mu, padded N
     double *Vc = nullptr, *Cs = nullptr, *Mm = nullptr, *T1 = nullptr, *GA = nullptr;     // mp x mp
+    double* Pp = nullptr;         // ksplit x mp x mp: partial sums of P = W W^T over k-chunks (vfe_forward)
+    int ksplit = 1;               // number of k-chunks (a divisor of nbq)
     double *Bm = nullptr, *Wm = nullptr, *Y1 = nullptr, *Y2 = nullptr;                      // mp x nq
     double *yq = nullptr, *wtb = nullptr;                                                   // nq
     double *v = nullptr, *c1 = nullptr, *beta = nullptr;                                    // mp
@@ -81,7 +83,7 @@ static int valloc(T** p, int64_t n) {
     return GPIMHIP_OK;
 }
 static void vfe_free(VfeWs& w) {
-    void* ps[] = {w.Vc, w.Cs, w.Mm, w.T1, w.GA, w.Bm, w.Wm, w.Y1, w.Y2, w.yq, w.wtb, w.v, w.c1, w.beta,
+    void* ps[] = {w.Pp, w.Vc, w.Cs, w.Mm, w.T1, w.GA, w.Bm, w.Wm, w.Y1, w.Y2, w.yq, w.wtb, w.v, w.c1, w.beta,
                   w.part_rect, w.part_sym, w.xu_rect, w.xu_sym, w.adam_m, w.adam_v, w.tiles, w.Ks, w.Ws, w.LW,
                   w.ptiles};
     for (void* p : ps)
@@ -108,6 +110,13 @@ static int vfe_ensure(gpimhip_ctx* h, int64_t Mu, int64_t N, int d, int P, VfeWs
     const int mb = (int)(mp / NB), nbq = (int)(nq / NB);
     GP_TRY(valloc(&w.Vc, mp * mp)); GP_TRY(valloc(&w.Cs, mp * mp)); GP_TRY(valloc(&w.Mm, mp * mp));
     GP_TRY(valloc(&w.T1, mp * mp)); GP_TRY(valloc(&w.GA, mp * mp));
+    // P = W W^T has few output tiles (15 at Mu = 534) and a long k-range (N / 128 blocks): the k-range is cut into
+    // `ksplit` equal chunks that run as the batch dimension of ONE launch (each into its own partial), summed in a fixed
+    // order by vfe_cap_kernel.  302 -> x us per iteration at N = 6400 (config C5).
+    w.ksplit = 1;
+    for (int sdiv = 2; sdiv <= 16; ++sdiv)
+        if (nbq % sdiv == 0 && nbq / sdiv >= 2) w.ksplit = sdiv;
+    if (w.ksplit > 1) GP_TRY(valloc(&w.Pp, (int64_t)w.ksplit * mp * mp));
     GP_TRY(valloc(&w.Bm, mp * nq)); GP_TRY(valloc(&w.Wm, mp * nq));
     GP_TRY(valloc(&w.Y1, mp * nq)); GP_TRY(valloc(&w.Y2, mp * nq));
     GP_TRY(valloc(&w.yq, nq)); GP_TRY(valloc(&w.wtb, nq));
@@ -123,7 +132,7 @@ static int vfe_ensure(gpimhip_ctx* h, int64_t Mu, int64_t N, int d, int P, VfeWs
     mark(w.off_lowtri_rect, w.n_lowtri_rect, s);
     s = tl.size();
     for (int ci = 0; ci < mb; ++ci)
-        for (int cj = 0; cj <= ci; ++cj) tl.push_back({ci, cj, 0, nbq});
+        for (int cj = 0; cj <= ci; ++cj) tl.push_back({ci, cj, 0, nbq / w.ksplit});
     mark(w.off_syrk, w.n_syrk, s);
     s = tl.size();
     for (int ci = 0; ci < mb; ++ci)
@@ -158,14 +167,22 @@ static GemmArgs vg(const double* A, int64_t lda, const double* B, int64_t ldb, d
 // ------------------------------------------------------------------------------------------
 // small kernels
 // ------------------------------------------------------------------------------------------
-// Cc = I + P/s on the lower triangle (in place in Pm) and as a full symmetric copy in Cs
+// Cc = I + P/s on the lower triangle (into Pm) and as a full symmetric copy in Cs; P = the sum of `nsplit` partials
+// Pp[c] (fixed order; nsplit == 1: P is in Pm already)
 __global__ void vfe_cap_kernel(double* __restrict__ Pm, double* __restrict__ Cs, int64_t mp,
-                               const ThetaDev* __restrict__ th) {
+                               const ThetaDev* __restrict__ th, const double* __restrict__ Pp, int nsplit) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= mp * mp) return;
     const int64_t i = idx / mp, j = idx % mp;
     if (j > i) return;
-    const double c = ((i == j) ? 1.0 : 0.0) + Pm[i * mp + j] / th->noise;
+    double pv;
+    if (nsplit > 1) {
+        pv = Pp[idx];
+        for (int c = 1; c < nsplit; ++c) pv += Pp[(int64_t)c * mp * mp + idx];
+    } else {
+        pv = Pm[idx];
+    }
+    const double c = ((i == j) ? 1.0 : 0.0) + pv / th->noise;
     Pm[i * mp + j] = c;
     Cs[i * mp + j] = c;
     Cs[j * mp + i] = c;
@@ -453,28 +470,51 @@ __global__ __launch_bounds__(256) void vfe_finalize_kernel(VfeFinalArgs a) {
         sst = st;
         s_it = it;
     }
-    __syncthreads();
-    // inducing inputs: g_xu[m][k] = -(s2 / l_k) * ( Xq[m][k] + Xr[m][k] / s )
-    const AdamStep st = sst;
-    for (int64_t e = tid; e < a.Mu * d; e += 256) {
-        const int64_t mrow = e / d;
-        const int k = (int)(e % d);
-        double xr = 0.0, xq = 0.0;
-        for (int cj = 0; cj < a.nbq; ++cj) xr += a.xu_rect[((int64_t)cj * a.mp + mrow) * 4 + k];
-        for (int cj = 0; cj < a.mb; ++cj) xq += a.xu_sym[((int64_t)cj * a.mp + mrow) * 4 + k];
-        const double gx = -(t.var / t.ls[k]) * (xq + xr / s);
-        if (a.grad_out) a.grad_out[P + e] = gx;
-        if (a.do_adam) {
-            double mm = a.adam_m[P + e], vv = a.adam_v[P + e];
-            mm = mm + (gx - mm) * (1.0 - st.beta1);
-            vv = vv * st.beta2 + (1.0 - st.beta2) * gx * gx;
-            const double denom = sqrt(vv) / st.bc2_sqrt + st.eps;
-            const double xn = a.u[P + e] + (-st.lr_over_bc1) * (mm / denom);
-            a.u[P + e] = xn;
-            a.adam_m[P + e] = mm;
-            a.adam_v[P + e] = vv;
-            if (a.hist_xu) a.hist_xu[(int64_t)s_it * a.Mu * d + e] = xn;
-        }
+}
+
+// inducing inputs: g_xu[m][k] = -(s2 / l_k) * ( Xq[m][k] + Xr[m][k] / s ), Adam step and history row; one thread per
+// coordinate (inside the single workgroup of vfe_finalize_kernel this loop was 100 of the kernel's 133 us at Mu = 534).
+// Launched BEFORE vfe_finalize_kernel, which advances the iteration counter.
+struct VfeXuArgs {
+    int d, P, mb, nbq;
+    int64_t Mu, mp;
+    const double *xu_rect, *xu_sym;
+    const ThetaDev* th;
+    double* u;
+    double *adam_m, *adam_v;
+    int do_adam;
+    const int32_t* iter; const double* bc; int32_t T;
+    double *hist_xu, *grad_out;
+    const int32_t* info;
+};
+__global__ __launch_bounds__(256) void vfe_xu_kernel(VfeXuArgs a) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= a.Mu * a.d) return;
+    if (a.iter && *a.info != 0) return;         // a factorisation of this loop failed: everything stays frozen
+    const ThetaDev t = *a.th;
+    const double s = t.noise;
+    const int64_t mrow = e / a.d;
+    const int k = (int)(e % a.d);
+    double xr = 0.0, xq = 0.0;
+#pragma unroll 10
+    for (int cj = 0; cj < a.nbq; ++cj) xr += a.xu_rect[((int64_t)cj * a.mp + mrow) * 4 + k];
+    for (int cj = 0; cj < a.mb; ++cj) xq += a.xu_sym[((int64_t)cj * a.mp + mrow) * 4 + k];
+    const double gx = -(t.var / t.ls[k]) * (xq + xr / s);
+    if (a.grad_out) a.grad_out[a.P + e] = gx;
+    if (a.do_adam) {
+        const double beta1 = 0.9, beta2 = 0.999, eps = 1e-8;
+        int it = 0;
+        double lr_over_bc1 = 0.0, bc2_sqrt = 1.0;
+        if (a.iter) { it = *a.iter; lr_over_bc1 = a.bc[it]; bc2_sqrt = a.bc[a.T + it]; }
+        double mm = a.adam_m[a.P + e], vv = a.adam_v[a.P + e];
+        mm = mm + (gx - mm) * (1.0 - beta1);
+        vv = vv * beta2 + (1.0 - beta2) * gx * gx;
+        const double denom = sqrt(vv) / bc2_sqrt + eps;
+        const double xn = a.u[a.P + e] + (-lr_over_bc1) * (mm / denom);
+        a.u[a.P + e] = xn;
+        a.adam_m[a.P + e] = mm;
+        a.adam_v[a.P + e] = vv;
+        if (a.hist_xu) a.hist_xu[(int64_t)it * a.Mu * a.d + e] = xn;
     }
 }
 
@@ -530,10 +570,18 @@ static int vfe_forward(gpimhip_ctx* h, VfeWs& w, const gpimhip_model_t* m, const
         GP_TRY(launch_gemm(h, false, true, EPI_STORE, g));
     }
     {   // P = W W^T (lower) -> h->B, then Cc = I + P/s
-        GemmArgs g = vg(w.Wm, nq, w.Wm, nq, h->B, mp, 1.0, 0.0, w.tiles + w.off_syrk, w.n_syrk);
-        GP_TRY(launch_gemm(h, false, false, EPI_STORE, g));
+        GemmArgs g = vg(w.Wm, nq, w.Wm, nq, w.ksplit > 1 ? w.Pp : h->B, mp, 1.0, 0.0, w.tiles + w.off_syrk, w.n_syrk);
+        const int S = w.ksplit;
+        if (S > 1) {            // k-chunk c = "problem" c of the launch: operands advance by one chunk of columns
+            g.sA = g.sB = (nq / NB / S) * NB;
+            g.sC = mp * mp;
+        }
+        h->nbatch = S;
+        const int rc = launch_gemm(h, false, false, EPI_STORE, g);
+        h->nbatch = 1;
+        GP_TRY(rc);
         hipLaunchKernelGGL(vfe_cap_kernel, dim3((unsigned)((mp * mp + 255) / 256)), dim3(256), 0, h->stream, h->B, w.Cs,
-                           mp, h->theta);
+                           mp, h->theta, (const double*)w.Pp, S);
     }
     GP_TRY(launch_potrf_inv(h, h->B, h->Tm, mp, mp, h->info, 0));   // h->B = Lc^-1, logdet_part <- log diag Lc
     // v = W y / s ; c1 = Lc^-1 v
@@ -587,6 +635,13 @@ static int vfe_loss_grad(gpimhip_ctx* h, VfeWs& w, const gpimhip_model_t* m, con
     a.info = h->info;
     if (it) { a.iter = it->iter; a.bc = it->bc; a.T = it->T; a.hist_theta = it->hist_theta; a.hist_xu = it->hist_xu; a.loss_out = it->loss; }
     else { a.loss_out = loss_out; a.grad_out = grad_out; }
+    VfeXuArgs x;
+    memset(&x, 0, sizeof(x));
+    x.d = m->dim; x.P = P; x.mb = mb; x.nbq = nbq; x.Mu = Mu; x.mp = mp;
+    x.xu_rect = w.xu_rect; x.xu_sym = w.xu_sym; x.th = h->theta; x.u = u; x.adam_m = w.adam_m; x.adam_v = w.adam_v;
+    x.do_adam = do_adam; x.iter = a.iter; x.bc = a.bc; x.T = a.T; x.hist_xu = a.hist_xu; x.grad_out = a.grad_out;
+    x.info = h->info;
+    hipLaunchKernelGGL(vfe_xu_kernel, dim3((unsigned)((Mu * m->dim + 255) / 256)), dim3(256), 0, h->stream, x);
     hipLaunchKernelGGL(vfe_finalize_kernel, dim3(1), dim3(256), 0, h->stream, a);
     HIP_TRY(hipGetLastError());
     return GPIMHIP_OK;
