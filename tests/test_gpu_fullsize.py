@@ -146,6 +146,22 @@ def test_c3_batched_equals_single_on_samples(gpim):
         np.testing.assert_array_equal(sd[..., k], s1)
 
 
+def test_split_batch_odd_sizes_and_ragged_block_equal_single(gpim):
+    """Lock-step batches of more than four problems run as two halves taking turns (factorisation role of one half
+    beside the pending tile operations of the other: csrc/cholstep.hip launch_potrf_steps); odd sizes give halves of
+    different length.  N = 305 per slice: the last 128-block holds 49 valid rows, so the ragged-block skipping of the
+    tile engine (GemmArgs::rag) is active in every launch.  Same bits as one problem at a time."""
+    from gpim_amd import dist as gd
+    cube, _ = hyperspectral_cube(size=32, nspec=7)
+    kw = dict(kernel="RBF", lengthscale=[[1., 1.], [10., 10.]], learning_rate=0.1, iterations=12)
+    n_obs = int(np.isfinite(cube[..., 0]).sum())
+    assert (n_obs - 1) % 128 < 64, n_obs
+    m1, s1 = gd.reconstruct_slices(cube, axis=-1, batch=1, **kw)
+    for batch in (7, 5):
+        m2, s2 = gd.reconstruct_slices(cube, axis=-1, batch=batch, **kw)
+        assert np.array_equal(m1, m2) and np.array_equal(s1, s2), batch
+
+
 def test_concurrent_batches_and_sparse_slices_equal_sequential(gpim):
     """reconstruct_slices with several lock-step batches (exact GPs) or several sparse slices in flight at a time --
     host threads, one HIP stream and library handle each -- returns the bits of the sequential run."""
