@@ -13,7 +13,9 @@
 //   F_j  (panel_solve_kernel) L[i,j] = A[i,j] * inv(L[j,j])^T for all rows i > j, one-shot: the whole strip and the
 //                             inverse (in MFMA operand order, written by potf2) are fetched with every load in
 //                             flight at once -- no k-loop of load/barrier/compute rounds
-//   D_j  (tile engine)        the next diagonal tiles (jj,jj), j < jj < p1(j)+W:  A[jj,jj] -= L[jj,j] L[jj,j]^T
+//   D_j  (diag_update_kernel) the next diagonal tile:  A[j+1,j+1] -= L[j+1,j] L[j+1,j]^T  (its older window columns came
+//                             with H_j's hosted tiles; the distributed panel chain and float handles update every
+//                             diagonal tile of the window eagerly)
 //
 // P = outer panel of W = 4 block columns, p0/p1 its first / one-past-last column.  Per block column the chain is
 // H_j -> F_j -> D_j; nothing else is ever on it.  Every tile receives each k-block exactly once: columns of the
@@ -255,10 +257,18 @@ static void plan_updates(int nb, std::vector<std::vector<TileDesc>>& fill) {
     // deep, the previous panel's part one launch earlier: launches that host nothing else drop from 50 to 35 us, but
     // the two passes over C and the smaller budget for the inverse's chunks give it back: N = 4212 835 vs 829 ms per
     // 300 iterations, lock-step batches of config C3 3 % slower.)
+    // The NEXT diagonal tile (j+1, j+1) rides along: its window columns [kb0', j) are final when H_j starts; D_j adds
+    // column j, the only one on the critical path.  (Rounds 3-4 had D_j update the next <= 7 diagonal tiles eagerly,
+    // k = 128 each: the same flop as 10 quadrant workgroups per tile and step -- 2240 latency-shaped workgroups per launch
+    // for a lock-step batch of 32, 28 us where the chip does 0.6 GFLOP.)
     auto col_update = [&](std::vector<TileDesc>& tl, int p0, int j) {
         const int kb0 = std::max(0, p0 - W);
         if (j > kb0)
             for (int i = j + 1; i < nb; ++i) tl.push_back({i, j, kb0, j});
+        if (j + 1 < nb) {
+            const int kd = std::max(0, ((j + 1) / W) * W - W);
+            if (j > kd) tl.push_back({j + 1, j + 1, kd, j});
+        }
     };
     if (nb < 64) {
         for (int p = 0; p < npanel; ++p) {
@@ -508,7 +518,9 @@ static int step_plan_build(gpimhip_ctx* h, int nb, StepPlan& P, bool with_invers
     for (int j = 0; j < nb; ++j) {
         P.fill[j] = put(fill[j]);
         const int p1 = std::min((j / W) * W + W, nb);
-        P.diag[j] = PlanRange{0, std::max(0, std::min(nb, p1 + W) - (j + 1))};     // the next diagonal tiles (count only)
+        // diagonal tiles D_j updates (count): double precision the next one only (the others receive column j through
+        // the hosted window update of their own step, plan_updates); float handles every tile of the window, eagerly
+        P.diag[j] = PlanRange{0, fp32 ? std::max(0, std::min(nb, p1 + W) - (j + 1)) : (j + 1 < nb ? 1 : 0)};
     }
     for (int p = 0; p < npanel; ++p) P.bulk_rest[p] = put(rest[p]);
     for (auto& v : post) P.post.push_back(put(v));

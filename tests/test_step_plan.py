@@ -86,9 +86,9 @@ def replay(nb, bs, with_inverse, seed=0):
         # panel solve, then the next diagonal tiles
         for i in range(j + 1, nb):
             blk(A, i, j)[...] = blk(A, i, j) @ Dinv.T
-        p1 = min((j // W) * W + W, nb)
-        for jj in range(j + 1, min(nb, p1 + W)):
-            blk(A, jj, jj)[...] -= blk(A, jj, j) @ blk(A, jj, j).T
+        # D_j: the NEXT diagonal tile only (its older window columns are hosted tile operations of launch j)
+        if j + 1 < nb:
+            blk(A, j + 1, j + 1)[...] -= blk(A, j + 1, j) @ blk(A, j + 1, j).T
     for l in sorted(k for k in by_launch if k >= nb):
         hosted(by_launch[l], A, Tm)
     want = np.linalg.inv(Lref) if with_inverse else Lref
