@@ -630,7 +630,7 @@ static int launch_solve_diag(gpimhip_ctx* h, double* A, int64_t ld, int j, int n
 int launch_potrf_steps_f32(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_t* info);   // cholstep32.hip
 int launch_potrf_steps(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_t* info, double* Tm, int rag) {
     if (h->fp32) return launch_potrf_steps_f32(h, A, np, ld, info);
-    const int nb = (int)(np / NB), W = STEP_W;
+    const int nb = (int)(np / NB);
     if (Tm) GP_TRY(step_plan_ensure_inv(h, nb));
     else GP_TRY(step_plan_ensure(h, nb));
     const StepPlan& P = Tm ? h->splan_inv : h->splan;

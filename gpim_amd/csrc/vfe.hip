@@ -373,8 +373,6 @@ __device__ double vfe_block_sum(double v, double* red) {
 __global__ __launch_bounds__(256) void vfe_finalize_kernel(VfeFinalArgs a) {
     __shared__ double red[256];
     __shared__ double R[8], Q[8];
-    __shared__ AdamStep sst;
-    __shared__ int s_it;
     const int tid = threadIdx.x;
     const int d = a.m.dim;
     const int P = 2 + a.m.n_ls + (a.m.kernel == GPIMHIP_KERNEL_RQ ? 1 : 0);
@@ -467,8 +465,6 @@ __global__ __launch_bounds__(256) void vfe_finalize_kernel(VfeFinalArgs a) {
                 if (a.m.kernel == GPIMHIP_KERNEL_RQ) hist_row[2 + a.m.n_ls] = tn.alpha;
             }
         }
-        sst = st;
-        s_it = it;
     }
 }
 
