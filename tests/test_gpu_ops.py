@@ -109,7 +109,10 @@ def test_potrf_ill_conditioned_kernel_matrix(eng, n, noise):
 
 CASES = [("RBF", 7, 2, False), ("RBF", 130, 3, False), ("RBF", 300, 2, True),
          ("Matern52", 40, 2, False), ("Matern52", 257, 4, False), ("Matern52", 300, 2, True),
-         ("RationalQuadratic", 34, 2, False), ("RationalQuadratic", 200, 3, False)]
+         ("RationalQuadratic", 34, 2, False), ("RationalQuadratic", 200, 3, False),
+         # beyond the fused predictor (np > 384: K* slab + variance product on the tile engine) with a ragged last block
+         # (GemmArgs::rag): 448 = 3 x 128 + 64 valid rows (the boundary), 530 = 4 x 128 + 18
+         ("RBF", 448, 2, False), ("Matern52", 530, 3, False)]
 
 
 @pytest.mark.parametrize("kind,N,d,iso", CASES)
