@@ -273,6 +273,22 @@ __device__ __forceinline__ void gemm_tile_core(GemmArgs g, TileDesc t, const int
             const double* As = smem + (s & 1) * 2 * STAGE;
             const double* Bs = As + STAGE;
             const bool more = (s + 1 < nsteps);
+            // 4-wave shapes: the fragments of the first MFMA group are requested BEFORE the next stage's global loads are
+            // issued, so their LDS latency passes behind those ~80 cycles of address arithmetic and load issue (K^-1
+            // product at N = 16384: 21.68 -> 21.51 ms; the 8-wave workgroups hosted by the Cholesky step kernel lose 2 %
+            // with it -- they run at the 128-register limit)
+            constexpr bool HOIST = NW == 4;
+            double a0[MT], b0[NTL];
+            if constexpr (HOIST) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+                    a0[i] = (ADIR && !A_KM) ? frag_mk_swz(As, wm * WROWS + i * 16, 0, lane)
+                                            : frag<A_KM, TSM>(As, wm * WROWS + i * 16, 0, lane);
+#pragma unroll
+                for (int j = 0; j < NTL; ++j)
+                    b0[j] = (BDIR && !B_KM) ? frag_mk_swz(Bs, wn * WCOLS + j * 16, 0, lane)
+                                            : frag<B_KM, TSN>(Bs, wn * WCOLS + j * 16, 0, lane);
+            }
             if (more) {
                 // the other stage buffer was last read in step s-1: every wave is past that barrier
                 double* An = smem + ((s + 1) & 1) * 2 * STAGE;
@@ -298,6 +314,12 @@ __device__ __forceinline__ void gemm_tile_core(GemmArgs g, TileDesc t, const int
                 for (int j = 0; j < NTL; ++j)
                     bb[j] = (BDIR && !B_KM) ? frag_mk_swz(Bs, wn * WCOLS + j * 16, kk, lane)
                                             : frag<B_KM, TSN>(Bs, wn * WCOLS + j * 16, kk, lane);
+                if (HOIST && kk == 0) {
+    #pragma unroll
+                    for (int i = 0; i < MT; ++i) a[i] = a0[i];
+    #pragma unroll
+                    for (int j = 0; j < NTL; ++j) bb[j] = b0[j];
+                }
     #pragma unroll
                 for (int i = 0; i < MT; ++i)
     #pragma unroll
