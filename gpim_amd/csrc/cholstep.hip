@@ -581,13 +581,18 @@ static GemmArgs nt_update(double* A, int64_t ld, const TileDesc* tiles, int n, i
 // one launch of the step kernel: `potf2` = with the factorisation role for block a.kblk, n hosted tiles in shape q.
 // Batches: both roles on all problems of the handle's batch, or (split != nullptr) the factorisation role on problems
 // split[0] .. +split[1] and the hosted tiles on problems split[2] .. +split[3], problem index in blockIdx.x.
-static int launch_step(gpimhip_ctx* h, StepArgs& a, bool potf2, int n, int q, const int* split = nullptr) {
+static int launch_step(gpimhip_ctx* h, StepArgs& a, bool potf2, int n, int q, const int* split = nullptr, int kblocks = 0) {
     const int B = h->nbatch;
     a.potf2 = potf2 ? 1 : 0;
     if (!potf2 && n == 0) return GPIMHIP_OK;
     a.pb_off = a.hb_off = 0; a.pb_cnt = a.hb_cnt = B; a.swap = 0;
     dim3 grid(n ? 8 + q * n : 1, B);
     bool alone = potf2;
+    // A launch whose hosted quadrants need two rounds of the chip at one workgroup per CU AND are deep (the second and
+    // third panel of a mid-size matrix: ~110 column-update quadrants of depth 4-7 + ~330 of the bulk share, 50-66 us) is
+    // shorter at two per CU with the factorisation role stretched to ~48 us (N = 4212: 2.72 -> 2.70 ms per iteration;
+    // with a lower threshold, or for shallow lists, the stretched role costs more than the second round: 2.76).
+    if (q == 4 && q * n >= 420 && 10 * kblocks >= 35 * n) alone = false;
     if (split) {
         a.pb_off = split[0]; a.pb_cnt = potf2 ? split[1] : 0; a.hb_off = split[2]; a.hb_cnt = n ? split[3] : 0; a.swap = 1;
         grid = dim3(std::max(a.pb_cnt, a.hb_cnt), n ? 8 + q * n : 1);
@@ -679,7 +684,7 @@ int launch_potrf_steps(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_
                 a.kblk = j;
                 int q;
                 const int nf = hosted_list(j, B, q);
-                GP_TRY(launch_step(h, a, true, nf, q));
+                GP_TRY(launch_step(h, a, true, nf, q, nullptr, P.n_all[j]));
                 GP_TRY(launch_solve_diag(h, A, ld, j, nb, P.diag[j].n, 0, B));
             }
         }
