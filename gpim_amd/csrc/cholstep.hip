@@ -227,6 +227,22 @@ struct HostSim {
         makespan = std::max(makespan, slot.back());
         std::push_heap(slot.begin(), slot.end(), std::greater<double>());
     }
+    // q workgroups of cost c each, on the q earliest slots, only if ALL of them end by `limit` (a tile operation is q
+    // workgroups: testing the earliest slot alone let the last one or two spill into a second round of the chip, +10-14 us
+    // on a 36 us launch)
+    bool try_add(double c, int q, double limit) {
+        double t[4];
+        for (int w = 0; w < q; ++w) {
+            std::pop_heap(slot.begin(), slot.end() - w, std::greater<double>());
+            t[w] = slot[slot.size() - 1 - w];
+        }
+        const bool ok = t[q - 1] + c <= limit;       // t[] ascends: the q-th earliest slot is the latest of them
+        for (int w = q - 1; w >= 0; --w) {
+            if (ok) { slot[slot.size() - 1 - w] = t[w] + c; makespan = std::max(makespan, t[w] + c); }
+            std::push_heap(slot.begin(), slot.end() - w, std::greater<double>());
+        }
+        return ok;
+    }
 };
 #define HOST_SLOTS 512
 // one hosted workgroup of a tile operation `depth` k-blocks deep in shape q (4: 64x64 quadrant, 2: 128x64 half, 1: whole
@@ -435,13 +451,13 @@ static void plan_inverse(int nb, std::vector<std::vector<TileDesc>>& fill, std::
                 if (o.kp >= o.k1) continue;
                 int depth = std::min(o.k1 - o.kp, cd);
                 if (hosted) {
-                    // the deepest chunk that still ends with the launch
-                    while (depth >= 1 && sim.peek() + wg_cost(depth, q) > target + 0.02) --depth;
+                    // the deepest chunk ALL of whose workgroups still end with the launch
+                    while (depth >= 1 && !sim.try_add(wg_cost(depth, q), q, target + 0.02)) --depth;
                     if (depth < 1) { full = true; break; }
+                } else {
+                    for (int w = 0; w < q; ++w) sim.add(wg_cost(depth, q));
                 }
                 const int k1 = o.kp + depth;
-                const double c = wg_cost(depth, q);
-                for (int w = 0; w < q; ++w) sim.add(c);
                 const int kind = t_phase ? (o.kp == o.k0 ? TK_T_FIRST : TK_T_ACC) : (o.kp == o.k0 ? TK_X_FIRST : TK_X_ACC);
                 out.push_back({o.ci, o.cj, o.kp, k1 | (kind << 16)});
                 o.kp = k1;
@@ -451,6 +467,12 @@ static void plan_inverse(int nb, std::vector<std::vector<TileDesc>>& fill, std::
                 }
             }
         }
+        // dispatch order = list order: the deepest workgroups first.  A launch of more workgroups than the chip has slots
+        // packs two shallow chunks into a slot -- as the simulation above assumed -- only if the deep ones are not left
+        // for the end (chunks of the last node handled used to be: launches of 260-290 quadrants lasted 49 us, not 36-39)
+        std::stable_sort(out.begin(), out.end(), [](const TileDesc& a, const TileDesc& b) {
+            return ((a.kb1 & 0xffff) - a.kb0) > ((b.kb1 & 0xffff) - b.kb0);
+        });
         if (!hosted && out.empty()) post.pop_back();      // (dependencies only resolve across launches)
         if (L > nb + 4 * 64) break;                        // cannot happen: every launch completes at least one phase
     }
