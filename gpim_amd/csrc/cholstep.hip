@@ -247,7 +247,10 @@ struct HostSim {
 #define HOST_SLOTS 512
 // one hosted workgroup of a tile operation `depth` k-blocks deep in shape q (4: 64x64 quadrant, 2: 128x64 half, 1: whole
 // tile), from kernel traces at two workgroups per CU: quadrants 8 + 6 depth us, whole tiles 34 us per k-block
-static double wg_cost(int depth, int q) { return q == 4 ? 0.18 * depth + 0.24 : (q == 2 ? 0.34 * depth + 0.3 : depth + 0.5); }
+// (quadrants re-measured in round 4 on launches whose lists are dispatched deepest-first: depth 7 lasts 41 us, depth 4
+// 27 -- 0.14 units per k-block, not 0.18; with it and chunks of up to 6 k-blocks N = 4212 runs 2.63 -> 2.59 ms per Adam
+// iteration, N = 8192 11.75 -> 11.59; 0.13 / 0.15, chunks of 5 / 7 and a budget of 1.05 / 1.2 units are all slower)
+static double wg_cost(int depth, int q) { return q == 4 ? 0.14 * depth + 0.24 : (q == 2 ? 0.34 * depth + 0.3 : depth + 0.5); }
 
 // ---- what the step launches host of the TRAILING UPDATE (double precision) -------------------------------------------
 // nb < 64: the chain of diagonal blocks bounds the factorisation; every launch hosts its column update (left-looking
@@ -373,7 +376,7 @@ static void plan_updates(int nb, std::vector<std::vector<TileDesc>>& fill) {
 //   T phase of a node: block columns < mid factored and solved (launch index >= mid) and the left child inverted;
 //   X phase: T phase complete, the right child inverted, block rows < hi dead for the factorisation (index >= hi).
 // A step launch that the chain of diagonal blocks bounds (most of them at mid-size N, the last third at N = 16384)
-// has idle workgroup slots for about the length of the factorisation role: it hosts chunks of <= 4 k-blocks (one chunk
+// has idle workgroup slots for about the length of the factorisation role: it hosts chunks of <= 6 k-blocks (one chunk
 // of a tile per launch, accumulated into the output across launches) up to that length.  What is left when the
 // factorisation ends -- the X phases of the nodes that contain the last block column, and most of the root's work at
 // large N -- runs as a few launches of the same kernel without the factorisation role.
@@ -428,7 +431,7 @@ static void plan_inverse(int nb, std::vector<std::vector<TileDesc>>& fill, std::
         int64_t upd = 0;
         for (auto& t : out) upd += t.kb1 - t.kb0;
         const int q = hosted ? host_shape(upd) : 1;
-        const int cd = !hosted ? (1 << 20) : 4;
+        const int cd = !hosted ? (1 << 20) : 6;
         // quadrants / halves: what a chain-bound launch hosts for free is about ONE workgroup per CU (traces at
         // N = 4212: up to ~250 quadrant workgroups leave the launch at the factorisation role's 35 us, 400 make it 50)
         HostSim sim(q == 1 ? HOST_SLOTS : HOST_SLOTS / 2);
