@@ -724,7 +724,9 @@ int launch_potrf_steps(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_
             // quadrants up to 320 tiles: these launches hold a node's deepest tiles (k-depth up to the node's size), and the
             // launch lasts as long as its longest workgroup (N = 4212: 0.369 -> 0.330 ms against 128; N = 8192 unchanged)
             const int64_t nt = (int64_t)r.n * B;
-            GP_TRY(launch_step(h, a, false, r.n, nt <= 320 ? 4 : (nt <= 1280 ? 2 : 1)));
+            // (halves up to 1000 tiles: the two 1024-tile launches of 32-deep tiles at N = 16384 are exactly two rounds of
+            // whole tiles -- 1.18 -> 1.09 ms each)
+            GP_TRY(launch_step(h, a, false, r.n, nt <= 320 ? 4 : (nt <= 1000 ? 2 : 1)));
         }
     }
     return GPIMHIP_OK;
