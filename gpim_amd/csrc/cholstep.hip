@@ -413,7 +413,9 @@ static int tri_nodes(int lo, int hi, std::vector<TriNodeS>& nodes) {
 // shape of a step launch's hosted workgroups by the k-blocks of trailing update it hosts (times the batch):
 // 4 = 64x64 quadrants (the work of a chain-bound launch spread over the chip), 2 = 128x64 halves, 1 = whole tiles.
 // (Round 3 drew the lines at 128 / 512 tiles of average depth 5; tools/r3_exp*.sh.)
-static int host_shape(int64_t update_kblocks) { return update_kblocks <= 700 ? 4 : (update_kblocks <= 2800 ? 2 : 1); }
+// (Round 4 re-measured the first line with deepest-first lists: 2000 instead of 700 -- N = 6000 5.50 -> 5.43 ms per Adam
+// iteration, 8192 11.57 -> 11.43, 12288 33.27 -> 32.97, 16384 72.56 -> 72.28; 1100 / 1500 / 2400 / 2800 lie between.)
+static int host_shape(int64_t update_kblocks, int quad_max = 2000) { return update_kblocks <= quad_max ? 4 : (update_kblocks <= 2800 ? 2 : 1); }
 
 static void plan_inverse(int nb, std::vector<std::vector<TileDesc>>& fill, std::vector<std::vector<TileDesc>>& post) {
     std::vector<TriNodeS> nodes;
@@ -679,7 +681,7 @@ int launch_potrf_steps(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_
             a.g.chunk = std::max(1, std::min(64, nf / 512));
             a.g.rag = rag;
             // a large batch is bound by throughput: every hosted k-block counts (P.n_all), not only the trailing update's
-            q = host_shape((int64_t)(B > host_max_batch ? P.n_all[j] : P.n_update[j]) * problems);
+            q = B > host_max_batch ? host_shape((int64_t)P.n_all[j] * problems, 700) : host_shape((int64_t)P.n_update[j] * problems);
             return nf;
         };
         if (B > host_max_batch) {
