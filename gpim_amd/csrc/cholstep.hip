@@ -94,8 +94,11 @@ __global__ __launch_bounds__(NTH, 4) void chol_step_kernel(StepArgs a) {
 // tile t needs k-steps 0 .. 4t+3, so every wave runs 36 of them per 16 rows).
 // (Strips of 16 and of 64 rows were measured in round 3: both slower than 32 -- potrf at N = 4212: 1.694 / 1.647 /
 // 1.783 ms, at 16384: 29.65 / 28.96 / 29.60 -- the launch is bound by its load latency and by re-reading the inverse.)
-__global__ __launch_bounds__(256, 2) void panel_solve_kernel(double* __restrict__ A, int64_t ld, int kblk, int nb,
-                                                          const double* __restrict__ dinvB_all, int b_off) {
+// WPE = waves per SIMD the register allocation aims at: 2 for a single problem (the launch is latency-bound and well
+// under one workgroup per CU), 4 for lock-step batches (> 1000 workgroups per launch: 129 registers allowed three per CU)
+template <int WPE>
+__global__ __launch_bounds__(256, WPE) void panel_solve_kernel(double* __restrict__ A, int64_t ld, int kblk, int nb,
+                                                            const double* __restrict__ dinvB_all, int b_off) {
     constexpr int LDS_LD = 130;             // 130 % 32 == 2: the A-fragment reads below are bank-conflict free
     constexpr int ROWS = 32, MTS = ROWS / 16;
     __shared__ __attribute__((aligned(16))) double S[ROWS * LDS_LD];
@@ -643,8 +646,12 @@ static int launch_step(gpimhip_ctx* h, StepArgs& a, bool potf2, int n, int q, co
 // F_j and D_j for the problems b_off .. b_off + cnt - 1 of the batch
 static int launch_solve_diag(gpimhip_ctx* h, double* A, int64_t ld, int j, int nb, int ndiag, int b_off, int cnt) {
     if (j + 1 >= nb || cnt <= 0) return GPIMHIP_OK;
-    hipLaunchKernelGGL(panel_solve_kernel, dim3(4 * (nb - j - 1), cnt), dim3(256), 0, h->stream, A, ld, j, nb,
-                       (const double*)h->dinvB, b_off);
+    if (cnt > 4)        // (C3, four concurrent batches of 16: 0.924 -> 0.912 s; same bits)
+        hipLaunchKernelGGL(panel_solve_kernel<4>, dim3(4 * (nb - j - 1), cnt), dim3(256), 0, h->stream, A, ld, j, nb,
+                           (const double*)h->dinvB, b_off);
+    else
+        hipLaunchKernelGGL(panel_solve_kernel<2>, dim3(4 * (nb - j - 1), cnt), dim3(256), 0, h->stream, A, ld, j, nb,
+                           (const double*)h->dinvB, b_off);
     HIP_TRY(hipGetLastError());
     if (ndiag > 0) {
         hipLaunchKernelGGL(diag_update_kernel, dim3(10 * ndiag, cnt), dim3(256), 0, h->stream, A, ld, j, nb, b_off);
