@@ -420,7 +420,11 @@ static int tri_nodes(int lo, int hi, std::vector<TriNodeS>& nodes) {
 // iteration, 8192 11.57 -> 11.43, 12288 33.27 -> 32.97, 16384 72.56 -> 72.28; 1100 / 1500 / 2400 / 2800 lie between.)
 static int host_shape(int64_t update_kblocks, int quad_max = 2000) { return update_kblocks <= quad_max ? 4 : (update_kblocks <= 2800 ? 2 : 1); }
 
-static void plan_inverse(int nb, std::vector<std::vector<TileDesc>>& fill, std::vector<std::vector<TileDesc>>& post) {
+// pair[L] (out): the step launch L runs its hosted quadrants two per CU (launch_step) -- decided here from the update
+// tiles alone, so that the budget for the inverse's chunks is the one of the launch as it will run.
+static bool pair_rule(size_t ntiles, int64_t kblocks) { return 4 * ntiles >= 420 && 10 * kblocks >= 35 * (int64_t)ntiles; }
+static void plan_inverse(int nb, std::vector<std::vector<TileDesc>>& fill, std::vector<std::vector<TileDesc>>& post,
+                         std::vector<uint8_t>& pair) {
     std::vector<TriNodeS> nodes;
     tri_nodes(0, nb, nodes);
     std::vector<int> order(nodes.size());
@@ -439,13 +443,20 @@ static void plan_inverse(int nb, std::vector<std::vector<TileDesc>>& fill, std::
         const int cd = !hosted ? (1 << 20) : 6;
         // quadrants / halves: what a chain-bound launch hosts for free is about ONE workgroup per CU (traces at
         // N = 4212: up to ~250 quadrant workgroups leave the launch at the factorisation role's 35 us, 400 make it 50)
-        HostSim sim(q == 1 ? HOST_SLOTS : HOST_SLOTS / 2);
+        // ... unless the update tiles alone need two rounds of deep quadrants: that launch runs two workgroups per CU
+        // (twice the slots, every workgroup ~1.7x as long, the factorisation role stretched to ~48 us)
+        // (N = 8192: 11.48 -> 11.37 ms per iteration with the budget of those launches modelled this way; the two
+        // constants matter little: 1.5 ... 2.0 and 1.3 ... 1.6 measure the same)
+        const bool two = hosted && q == 4 && pair_rule(out.size(), upd);
+        if (hosted) pair[L] = two;
+        const double slow = two ? 1.7 : 1.0, chain = two ? 1.4 : CHAIN;
+        HostSim sim(q == 1 || two ? HOST_SLOTS : HOST_SLOTS / 2);
         double target = 1e30;
         if (hosted) {
-            sim.add(CHAIN);
+            sim.add(chain);
             for (auto& t : out)
-                for (int w = 0; w < q; ++w) sim.add(wg_cost(t.kb1 - t.kb0, q));
-            target = std::max(sim.makespan, CHAIN);
+                for (int w = 0; w < q; ++w) sim.add(slow * wg_cost(t.kb1 - t.kb0, q));
+            target = std::max(sim.makespan, chain);
         }
         bool full = false;
         for (int idx : order) {
@@ -460,7 +471,7 @@ static void plan_inverse(int nb, std::vector<std::vector<TileDesc>>& fill, std::
                 int depth = std::min(o.k1 - o.kp, cd);
                 if (hosted) {
                     // the deepest chunk ALL of whose workgroups still end with the launch
-                    while (depth >= 1 && !sim.try_add(wg_cost(depth, q), q, target + 0.02)) --depth;
+                    while (depth >= 1 && !sim.try_add(slow * wg_cost(depth, q), q, target + 0.02)) --depth;
                     if (depth < 1) { full = true; break; }
                 } else {
                     for (int w = 0; w < q; ++w) sim.add(wg_cost(depth, q));
@@ -531,7 +542,10 @@ static int step_plan_build(gpimhip_ctx* h, int nb, StepPlan& P, bool with_invers
     P.n_update.assign(nb, 0);
     for (int j = 0; j < nb; ++j)
         for (auto& t : fill[j]) P.n_update[j] += t.kb1 - t.kb0;
-    if (with_inverse) plan_inverse(nb, fill, post);
+    P.pair.assign(nb, 0);
+    if (with_inverse) plan_inverse(nb, fill, post, P.pair);
+    else
+        for (int j = 0; j < nb; ++j) P.pair[j] = host_shape(P.n_update[j]) == 4 && pair_rule(fill[j].size(), P.n_update[j]);
     P.n_all.assign(nb, 0);
     for (int j = 0; j < nb; ++j)
         for (auto& t : fill[j]) P.n_all[j] += (t.kb1 & 0xffff) - t.kb0;
@@ -571,7 +585,8 @@ extern "C" int gpimhip_step_plan_host(int32_t nb, int32_t with_inverse, int32_t*
     if (nb < 1 || nb > 4096 || !n_out) return GPIMHIP_E_BADARG;
     std::vector<std::vector<TileDesc>> fill(nb), post;
     plan_updates(nb, fill);
-    if (with_inverse) plan_inverse(nb, fill, post);
+    std::vector<uint8_t> pair(nb, 0);
+    if (with_inverse) plan_inverse(nb, fill, post, pair);
     int64_t n = 0;
     auto emit = [&](int launch, const std::vector<TileDesc>& v) {
         for (const TileDesc& t : v) {
@@ -611,18 +626,17 @@ static GemmArgs nt_update(double* A, int64_t ld, const TileDesc* tiles, int n, i
 // one launch of the step kernel: `potf2` = with the factorisation role for block a.kblk, n hosted tiles in shape q.
 // Batches: both roles on all problems of the handle's batch, or (split != nullptr) the factorisation role on problems
 // split[0] .. +split[1] and the hosted tiles on problems split[2] .. +split[3], problem index in blockIdx.x.
-static int launch_step(gpimhip_ctx* h, StepArgs& a, bool potf2, int n, int q, const int* split = nullptr, int kblocks = 0) {
+static int launch_step(gpimhip_ctx* h, StepArgs& a, bool potf2, int n, int q, const int* split = nullptr, bool two_per_cu = false) {
     const int B = h->nbatch;
     a.potf2 = potf2 ? 1 : 0;
     if (!potf2 && n == 0) return GPIMHIP_OK;
     a.pb_off = a.hb_off = 0; a.pb_cnt = a.hb_cnt = B; a.swap = 0;
     dim3 grid(n ? 8 + q * n : 1, B);
     bool alone = potf2;
-    // A launch whose hosted quadrants need two rounds of the chip at one workgroup per CU AND are deep (the second and
-    // third panel of a mid-size matrix: ~110 column-update quadrants of depth 4-7 + ~330 of the bulk share, 50-66 us) is
-    // shorter at two per CU with the factorisation role stretched to ~48 us (N = 4212: 2.72 -> 2.70 ms per iteration;
-    // with a lower threshold, or for shallow lists, the stretched role costs more than the second round: 2.76).
-    if (q == 4 && q * n >= 420 && 10 * kblocks >= 35 * n) alone = false;
+    // A launch whose UPDATE quadrants need two rounds of the chip at one workgroup per CU and are deep (pair_rule: the
+    // second and third panel of a mid-size matrix, most launches around N = 6000) is shorter at two per CU with the
+    // factorisation role stretched to ~48 us (N = 4212: 2.72 -> 2.70 ms per iteration); the planner knows (StepPlan::pair).
+    if (q == 4 && two_per_cu) alone = false;
     if (split) {
         a.pb_off = split[0]; a.pb_cnt = potf2 ? split[1] : 0; a.hb_off = split[2]; a.hb_cnt = n ? split[3] : 0; a.swap = 1;
         grid = dim3(std::max(a.pb_cnt, a.hb_cnt), n ? 8 + q * n : 1);
@@ -719,7 +733,7 @@ int launch_potrf_steps(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_
                 a.kblk = j;
                 int q;
                 const int nf = hosted_list(j, B, q);
-                GP_TRY(launch_step(h, a, true, nf, q, nullptr, P.n_all[j]));
+                GP_TRY(launch_step(h, a, true, nf, q, nullptr, P.pair[j] != 0));
                 GP_TRY(launch_solve_diag(h, A, ld, j, nb, P.diag[j].n, 0, B));
             }
         }

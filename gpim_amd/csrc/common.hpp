@@ -82,6 +82,7 @@ struct StepPlan {
     std::vector<PlanRange> post;        // fused inverse: what is left of it after the last step, launch by launch
     std::vector<int32_t> n_update;      // per block column: k-blocks of trailing update among fill[] (sets the hosted shape)
     std::vector<int32_t> n_all;         // per block column: all hosted k-blocks (shape of the launches of a large batch)
+    std::vector<uint8_t> pair;          // per block column: its step launch runs hosted quadrants two per CU (cholstep.hip)
 };
 
 // Launch plans of the distributed (block-column-cyclic, 1 x P) factorisation for one rank (api.hip: gpimhip_dist_*)
