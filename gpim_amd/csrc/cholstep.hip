@@ -422,7 +422,9 @@ static int host_shape(int64_t update_kblocks, int quad_max = 2000) { return upda
 
 // pair[L] (out): the step launch L runs its hosted quadrants two per CU (launch_step) -- decided here from the update
 // tiles alone, so that the budget for the inverse's chunks is the one of the launch as it will run.
-static bool pair_rule(size_t ntiles, int64_t kblocks) { return 4 * ntiles >= 420 && 10 * kblocks >= 35 * (int64_t)ntiles; }
+// (>= 300 update quadrants of average depth >= 3; 420 / 3.5 before the planner knew: N = 8192 11.42 -> 11.31 ms per
+// iteration; 240 / 2.5, depth 2 and never pairing -- 12.15 ms -- are slower)
+static bool pair_rule(size_t ntiles, int64_t kblocks) { return 4 * ntiles >= 300 && 10 * kblocks >= 30 * (int64_t)ntiles; }
 static void plan_inverse(int nb, std::vector<std::vector<TileDesc>>& fill, std::vector<std::vector<TileDesc>>& post,
                          std::vector<uint8_t>& pair) {
     std::vector<TriNodeS> nodes;
