@@ -690,7 +690,7 @@ int launch_potrf_steps(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_
     else GP_TRY(step_plan_ensure(h, nb));
     const StepPlan& P = Tm ? h->splan_inv : h->splan;
     const int B = h->nbatch;
-    const int host_max_batch = 4;
+    const int host_max_batch = 4;      // (2 / 8 measure the same on C3; 16, i.e. batches of 16 un-split: 0.998 vs 0.907 s)
     StepArgs a;
     a.A = A; a.ld = ld; a.nb = nb; a.Tm = Tm;
     a.dinv_all = h->dinv; a.dinvB_all = h->dinvB; a.logdet = h->logdet_part; a.info = info;
