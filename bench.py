@@ -593,10 +593,14 @@ def main():
                 # in a child process: the other configs launch the same kernel instantiations at other sizes,
                 # and would blur the per-kernel averages of a `rocprofv3 --stats` run of this command
                 import subprocess
-                child = subprocess.run([sys.executable, os.path.abspath(__file__), "--extras-only"],
-                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+                # (bounded: the headline line must not depend on the extras -- they take ~25 s; the concurrent C3 / C5 steps
+                # run on several host threads and streams)
                 try:
+                    child = subprocess.run([sys.executable, os.path.abspath(__file__), "--extras-only"],
+                                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
                     out.update(json.loads(child.stdout.strip().splitlines()[-1]))
+                except subprocess.TimeoutExpired:
+                    out["extra"] = {"error": "extras child did not finish within 600 s"}
                 except Exception:
                     out["extra"] = {"error": (child.stderr or child.stdout)[-400:]}
         print(json.dumps(out))
