@@ -112,7 +112,7 @@ static int vfe_ensure(gpimhip_ctx* h, int64_t Mu, int64_t N, int d, int P, VfeWs
     GP_TRY(valloc(&w.T1, mp * mp)); GP_TRY(valloc(&w.GA, mp * mp));
     // P = W W^T has few output tiles (15 at Mu = 534) and a long k-range (N / 128 blocks): the k-range is cut into
     // `ksplit` equal chunks that run as the batch dimension of ONE launch (each into its own partial), summed in a fixed
-    // order by vfe_cap_kernel.  302 -> x us per iteration at N = 6400 (config C5).
+    // order by vfe_cap_kernel.  302 -> 74 us per iteration at N = 6400 (config C5).
     w.ksplit = 1;
     for (int sdiv = 2; sdiv <= 16; ++sdiv)
         if (nbq % sdiv == 0 && nbq / sdiv >= 2) w.ksplit = sdiv;
