@@ -121,3 +121,15 @@ def test_plan_large(ensure_built, nb, with_inverse):
     if with_inverse:
         hosted_inv = rec[(rec[:, 5] > 0) & (rec[:, 0] < nb)]
         assert len(hosted_inv) > 0                        # part of the inverse rides in the step launches
+
+
+@pytest.mark.parametrize("nb", [10, 33, 47, 128])
+def test_lists_are_dispatched_deepest_first(ensure_built, nb):
+    """Dispatch order = list order.  A launch of more workgroups than the chip has slots packs two shallow chunks into one
+    slot only if the deep ones go first: the list of every launch (trailing updates and the inverse's chunks together)
+    is sorted by k-depth, deepest first (N = 4212: launches of 260-290 quadrants 49 -> 38 us when this was fixed)."""
+    rec = plan(nb, 1)
+    for launch in np.unique(rec[:, 0]):
+        r = rec[rec[:, 0] == launch]
+        depth = r[:, 4] - r[:, 3]
+        assert (np.diff(depth) <= 0).all(), int(launch)
