@@ -4,12 +4,14 @@
 // the blocked Cholesky) and smalln.hip (fused trainer for N <= 128).  512-thread workgroups.
 #pragma once
 #include "common.hpp"
+#include "chol16lp.hpp"
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
 
 #define LDD 130   // row stride of the LDS block: 130 % 32 == 2 keeps MK fragment reads conflict free
 #define NTH 512
+#define XS_LD 18   // row stride of the scratch tiles that hold the inverse of a diagonal 16x16 tile (lds_factor_inv)
 
 // Where element (16 ti + rr, 16 tj + cc) of the block lives in LDS: D[Lay::tile(ti, tj) + Lay::in(rr, cc)].
 //   LayPad  the full square, row-major with stride LDD (133 KB for 128 x 128): the fused small-N trainer, whose other
@@ -308,9 +310,7 @@ __device__ __forceinline__ void load_block_chol0(double* D, double* invd, int* s
     *reinterpret_cast<d2*>(D + off[0]) = r[0];
     __syncthreads();
     if (tid < 64) {
-        d4 x0;
-        const int bad = chol16<LayTri>(D, invd, tid, &x0);
-        xs_write(Xs, x0, tid);
+        const int bad = chol16_lp<LayTri, false>(D, invd, tid, Xs, XS_LD);
         if (tid == 0 && bad && *s_bad == 0) *s_bad = bad;
     }
 #pragma unroll
@@ -343,10 +343,12 @@ __device__ __forceinline__ void load_block_chol0(double* D, double* invd, int* s
 #ifdef POTF2_PROFILE
 __device__ long long g_fprof[128];       // tools/potf2_prof.hip: wave 0's clock at the marks below, 8 per 16-column step
 #define FSTAMP(i) do { if (threadIdx.x == 0) g_fprof[i] = clock64(); } while (0)
+__device__ long long g_wprof[8 * 8 * 4];  // every wave's clock: [wave][step][after export | after row of the inverse | after trailing tiles | after the step's barrier]
+#define WSTAMP(p, k) do { if ((threadIdx.x & 63) == 0) g_wprof[((threadIdx.x >> 6) * 8 + (p)) * 4 + (k)] = clock64(); } while (0)
 #else
 #define FSTAMP(i) do { } while (0)
+#define WSTAMP(p, k) do { } while (0)
 #endif
-#define XS_LD 18
 // sink(i, t) exports block row i of L; it is called in the UPDATE phase of step i by the six waves that are neither
 // the factorising wave 0 nor its SIMD partner wave 4: t = 0..383.  (Until late in round 3 all 512 threads exported in
 // the panel-solve phase, on wave 0's critical path: 1.3K -> 0.6K cycles of that phase per step.)
@@ -365,9 +367,7 @@ __device__ __forceinline__ void lds_factor_inv(double* D, double* invd, double* 
     const int widx7 = worker ? widx : 5 + wave;             // last step: waves 2,3,5,6,7,0,1 -> 0..6
     if (!FIRST_DONE) {
         if (wave == 0) {
-            d4 x0;
-            const int bad = chol16<Lay>(D, invd, lane, &x0);
-            xs_write(Xs, x0, lane);
+            const int bad = chol16_lp<Lay, false>(D, invd, lane, Xs, XS_LD);
             if (lane == 0 && bad && *s_bad == 0) *s_bad = bad;
         }
         __syncthreads();
@@ -413,6 +413,7 @@ __device__ __forceinline__ void lds_factor_inv(double* D, double* invd, double* 
         // block row p of L (final since the end of step p-1; the inverse overwrites it in the solve phase of step p+1)
         // goes back to HBM from the waves off the critical path
         if (wave != 0 && wave != 4) sink(p, ((wave < 4) ? wave - 1 : wave - 2) * 64 + lane);
+        WSTAMP(p, 0);
         // row p of the inverse: the five workers, two tiles each -- or, in the LAST step (no 16x16 factorisation left
         // to hide behind), seven waves with one tile each
         const bool lastp = (p == npan - 1);
@@ -437,6 +438,7 @@ __device__ __forceinline__ void lds_factor_inv(double* D, double* invd, double* 
                 keep[cnt] = x;
             }
         }
+        WSTAMP(p, 1);
         // trailing update of the lower tiles (rt >= ct > p); tile q = 0 is (p+1, p+1)
         const int m = npan - 1 - p;
         const int ntile = m * (m + 1) / 2;
@@ -473,11 +475,10 @@ __device__ __forceinline__ void lds_factor_inv(double* D, double* invd, double* 
             tile_write<Lay>(C, acc, lane);
         }
         FSTAMP(8 * p + 3);
+        WSTAMP(p, 2);
         if (wave == 0 && p + 1 < npan) {
             const int c1 = c0 + 16;
-            d4 xn;
-            const int bad = chol16<Lay>(D + Lay::tile(p + 1, p + 1), invd + c1, lane, &xn);
-            xs_write(Xs + ((p + 1) & 1) * 16 * XS_LD, xn, lane);
+            const int bad = chol16_lp<Lay, false>(D + Lay::tile(p + 1, p + 1), invd + c1, lane, Xs + ((p + 1) & 1) * 16 * XS_LD, XS_LD);
             if (lane == 0 && bad && *s_bad == 0) *s_bad = c1 + bad;
             // wave 0 carries no row of the inverse out of a step that has a 16x16 factorisation (it holds one only after
             // the LAST step): redefining `keep` here ends its live range at the top of this block, so that the register
@@ -488,5 +489,6 @@ __device__ __forceinline__ void lds_factor_inv(double* D, double* invd, double* 
         FSTAMP(8 * p + 4);
         __syncthreads();
         FSTAMP(8 * p + 5);
+        WSTAMP(p, 3);
     }
 }

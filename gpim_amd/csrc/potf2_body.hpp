@@ -49,12 +49,17 @@ __device__ __forceinline__ void potf2_body(double* __restrict__ smem, const int 
     // column pair e & 7 -- one wave-wide access covers 8 rows x 128 bytes of ONE tile, which is conflict-free in the
     // packed layout (a matrix row across tiles would put all 64 lanes on the same 32 banks) and whole 128-byte lines
     // in HBM.  Elements above the diagonal are 0; tiles right of the diagonal tile do not exist in LDS.
-    auto lower_chunk = [&](int i, int e, int& r, int& c) {
+    // factor_diag: the diagonal tile holds the factor as chol16_lp<.., false> leaves it, column j still times L_jj
+    auto lower_chunk = [&](int i, int e, int& r, int& c, bool factor_diag) {
         const int tj = e >> 7, rr = (e >> 3) & 15, c2 = (e & 7) * 2;
         r = i * 16 + rr;
         c = tj * 16 + c2;
         d2 v = (d2){0.0, 0.0};
         if (tj <= i) v = *reinterpret_cast<const d2*>(D + PL::tile(i, tj) + PL::in(rr, c2));
+        if (factor_diag && tj == i) {
+            v[0] *= invd[c];
+            v[1] *= invd[c + 1];
+        }
         if (c > r) v[0] = 0.0;
         if (c + 1 > r) v[1] = 0.0;
         return v;
@@ -62,7 +67,7 @@ __device__ __forceinline__ void potf2_body(double* __restrict__ smem, const int 
     auto export_row = [&](int i, int t) {
         for (int e = t; e < 16 * 64; e += SINK_THREADS) {
             int r, c;
-            const d2 w = lower_chunk(i, e, r, c);
+            const d2 w = lower_chunk(i, e, r, c, true);
             RV2 v;
             v[0] = (R)w[0];
             v[1] = (R)w[1];
@@ -88,7 +93,7 @@ __device__ __forceinline__ void potf2_body(double* __restrict__ smem, const int 
     const int64_t ldinv = inv_to_A ? ld : NB;
     for (int e = tid; e < NB * NB / 2; e += NTH) {
         int r, c;
-        const d2 w = lower_chunk(e >> 10, e & 1023, r, c);
+        const d2 w = lower_chunk(e >> 10, e & 1023, r, c, false);
         RV2 v;
         v[0] = (R)w[0];
         v[1] = (R)w[1];

@@ -19,7 +19,7 @@ __global__ __launch_bounds__(NTH, 1) void k(const double* A, double* Lout, doubl
     lds_factor_inv(D, invd, Xs, npan, &s_bad, tid, [&](int i, int t) {
         for (int e = t; e < 16 * ns; e += SINK_THREADS) {
             const int r = i * 16 + e / ns, c = e % ns;
-            Lout[r * ns + c] = (c <= r) ? D[r * LDD + c] : 0.0;
+            Lout[r * ns + c] = (c <= r) ? D[r * LDD + c] * ((c >> 4) == i ? invd[c] : 1.0) : 0.0;      // (diagonal tile: column c still times L_cc, chol16lp.hpp)
         }
     });
     const long long t1 = clock64();

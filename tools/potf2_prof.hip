@@ -31,6 +31,20 @@ int main() {
             printf("  step %d: %5lld | %5lld | %5lld | %5lld | %5lld   (step total %lld)\n", p, fp[8 * p + 1] - fp[8 * p], fp[8 * p + 2] - fp[8 * p + 1],
                    fp[8 * p + 3] - fp[8 * p + 2], fp[8 * p + 4] - fp[8 * p + 3], fp[8 * p + 5] - fp[8 * p + 4], fp[8 * p + 5] - fp[8 * p]);
     }
+    {
+        long long wp[256], fp[128];
+        hipMemcpyFromSymbol(wp, HIP_SYMBOL(g_wprof), sizeof(wp));
+        hipMemcpyFromSymbol(fp, HIP_SYMBOL(g_fprof), sizeof(fp));
+        printf("every wave, cycles since the barrier that opened the step's update phase: [export of block row p | row p of the inverse | trailing tiles | leaves the step's closing barrier]\n");
+        for (int p = 0; p < 8; ++p) {
+            printf("  step %d:", p);
+            for (int w = 0; w < 8; ++w) {
+                const long long t0 = fp[8 * p + 2];
+                printf("  w%d %5lld %5lld %5lld %5lld |", w, wp[(w * 8 + p) * 4] - t0, wp[(w * 8 + p) * 4 + 1] - t0, wp[(w * 8 + p) * 4 + 2] - t0, wp[(w * 8 + p) * 4 + 3] - t0);
+            }
+            printf("\n");
+        }
+    }
     std::vector<double> L(n * n);
     hipMemcpy(L.data(), dA, n * n * 8, hipMemcpyDeviceToHost);
     // residual check L L^T - A
