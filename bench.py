@@ -209,6 +209,37 @@ def rmse_vs_oracle(gpim, iterations=5):
                                        rel(hyper["variance"], ho["variance"]))}
 
 
+def rmse_vs_oracle_c3(cube, iterations=5, slices=(0, 31, 63)):
+    """Config C3 at its own size (64x64x64 twin: N = 1207 per slice -- ragged last block, nb = 10 -- M = 4096, RBF):
+    three slices out of dist.reconstruct_slices (lock-step batch of 64 AND batch='auto') against the oracle's
+    per-slice reconstructor, `iterations` Adam steps."""
+    from oracle import gpim_oracle as O
+    from gpim_amd import dist as gdist
+    import gpim_amd as gpim
+    kw = dict(C3, iterations=iterations)
+    res = {"config": "C3: 64x64x64 cube twin, slices %s, N=%d, M=%d, RBF, %d Adam its, fp64"
+                     % (list(slices), int(np.isfinite(cube[..., 0]).sum()), cube[..., 0].size, iterations)}
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    orc = {}
+    for k in slices:
+        R = cube[..., k]
+        orc[k] = O.reconstructor(gpim.utils.get_sparse_grid(R), R, gpim.utils.get_full_grid(R), verbose=0, **kw).run()
+    for name, bkw in (("batch64", dict(batch=64)), ("auto", dict(batch="auto"))):
+        mean, sd, hyper = gdist.reconstruct_slices(cube, axis=-1, return_hyperparams=True, **bkw, **kw)
+        em = np.concatenate([(mean[..., k] - orc[k][0]).ravel() for k in slices])
+        es = np.concatenate([(sd[..., k] - orc[k][1]).ravel() for k in slices])
+        hrel = 0.0
+        for k in slices:
+            ho = orc[k][2]
+            href = np.column_stack([np.reshape(ho["variance"], (iterations, -1)), np.reshape(ho["lengthscale"], (iterations, -1)),
+                                    np.reshape(ho["noise"], (iterations, -1))])
+            hrel = max(hrel, float(np.max(np.abs(hyper[k] - href) / np.abs(href))))
+        res[name] = {"rmse_mean": float(np.sqrt(np.mean(em ** 2))), "rmse_sd": float(np.sqrt(np.mean(es ** 2))),
+                     "max_abs_mean": float(np.max(np.abs(em))), "max_abs_sd": float(np.max(np.abs(es))),
+                     "hyperparams_max_rel": hrel}
+    return res
+
+
 # ------------------------------------------------------------------------------------------------
 # the other single-GPU configs (driver-verified throughputs for DESIGN.md section 4)
 # ------------------------------------------------------------------------------------------------
@@ -238,6 +269,18 @@ def extra_configs(gpim):
     out["C3"] = {"workload": "64x64x64 cube twin, 64 per-slice GPs (N=%d, M=4096), RBF, T=250, "
                              "dist.reconstruct_slices(batch=16, batch_concurrency=4) on one GPU" % int(np.isfinite(cube[..., 0]).sum()),
                  "seconds": dt, "grid_points_per_s": cube.size / dt}
+    # the per-rank share of C3 on an 8-GPU node: 8 of the 64 slices (round-robin shard of rank 0) on ONE GPU, the
+    # batch split dist.reconstruct_slices picks by itself
+    sub = cube[..., 0::8]
+    gdist.reconstruct_slices(sub, axis=-1, batch="auto", **dict(C3, iterations=3))
+    sync(); t0 = time.perf_counter()
+    gdist.reconstruct_slices(sub, axis=-1, batch="auto", **C3)
+    sync(); dt = time.perf_counter() - t0
+    out["C3_per_rank_8"] = {"workload": "rank 0's share of C3 at world size 8: slices 0, 8, ..., 56 of the cube twin on one GPU, "
+                                        "RBF, T=250, dist.reconstruct_slices(batch='auto')",
+                            "seconds": dt, "grid_points_per_s": sub.size / dt,
+                            "projected_8gpu_speedup_over_1gpu": out["C3"]["seconds"] / dt}
+    out["rmse_vs_oracle_c3"] = rmse_vs_oracle_c3(cube)
     # C4: BO on 25x25, EI, 30 exploration steps x 1000 Adam iterations (README.md:71-106 of the reference)
     tmp = tempfile.mkdtemp()
     for rep in range(2):                                                               # first pass = warm-up

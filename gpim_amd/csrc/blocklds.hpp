@@ -321,23 +321,29 @@ __device__ __forceinline__ void load_block_chol0(double* D, double* invd, int* s
 
 // Cholesky AND inverse of the leading npan*16 rows/cols of the block in D, in place: on return D holds
 // X = L^-1 (lower; the diagonal 16x16 tiles with zeros above the diagonal), invd[j] = 1/L_jj.
-// Right-looking factorisation in 16-column panels.  The serial part is wave 0: own tile update -> 16x16 register
-// Cholesky of the next diagonal tile (chol16, which also yields that tile's INVERSE) -- overlapped with the trailing
-// update by the other waves.  The panel solve of the rows below a diagonal tile is a product with that inverse, one
-// 16x16 tile per wave on MFMA (4 dependent MFMAs: ~0.6K cycles; the substitution it replaces, one thread per row, was
-// 2.5K cycles of wave 0's 8.8K per panel).  The inverse of the whole block is built block row by block row in the
+// Right-looking factorisation in 16-column panels.  The serial part is wave 0: own tile update -> 16x16 factorisation
+// of the next diagonal tile by ONE wave (chol16_lp, which also yields that tile's INVERSE; 2.3K cycles) -- overlapped
+// with the trailing update by the other waves.  The panel solve of the rows below a diagonal tile is a product with that
+// inverse, one 16x16 tile per wave on MFMA.  The inverse of the whole block is built block row by block row in the
 // shadow of the factorisation instead of afterwards:
 //   X(i,i) = L(i,i)^-1,   X(i,j) = -X(i,i) * sum_{k=j}^{i-1} L(i,k) X(k,j)      (j < i)
 // Block row i of L is final once step i-1 is over.  During step i
-//   panel-solve phase : every wave but wave 4 solves one tile below the diagonal tile; wave 4 stores X(i-1,i-1)
-//                       (from the scratch tile) over L(i-1,i-1); the five worker waves store block row i-1 of
-//                       X (held in registers since the previous step) over L(i-1,.);
-//   update phase      : waves 1-3 and 5-7 export block row i of L (sink(i, t)); next to their trailing tiles,
-//                       the workers form T(i,j) = sum_k L(i,k) X(k,j) on
-//                       MFMA and multiply by -X(i,i) (T is already in B-operand layout); the results
-//                       stay in registers until the next step so that no wave overwrites an L(i,k)
-//                       another one still reads.  The row-inverse work grows as the trailing
-//                       update shrinks, and both hide behind wave 0's 16x16 factorisation.
+//   panel-solve phase : every wave but wave 4 solves one tile below the diagonal tile (and hands it to sink.tile() from its
+//                       registers); wave 0 solves its tile TRANSPOSED -- X(i,i) A^T lands in the accumulator as the
+//                       A-operand fragments of the solved tile -- and updates the next diagonal tile with it at once,
+//                       without a round trip through LDS; wave 4 stores X(i-1,i-1) (from the scratch tile) over
+//                       L(i-1,i-1); the workers store the tiles of block row i-1 of X they hold in registers since the
+//                       previous step over L(i-1,.);
+//   update phase      : wave 4 (the SIMD partner of wave 0: no matrix work beside the serial chain) exports what is left
+//                       of block row i of L (sink.row(i, lane)); the six workers (waves 1-3, 5-7) share the trailing tiles and the tiles
+//                       of row i of the inverse -- T(i,j) = sum_k L(i,k) X(k,j), times -X(i,i) -- by a static
+//                       longest-first assignment (FiPlan below); the inverse's results stay in registers until the next
+//                       step so that no wave overwrites an L(i,k) another one still reads.  The inverse's work grows as
+//                       the trailing update shrinks (88 ... 140 MFMAs per step for eight panels), and both hide behind
+//                       wave 0's 16x16 factorisation.  In the LAST step wave 0 has no factorisation left and works too.
+// An fp64 MFMA occupies its SIMD's matrix pipe for 64 cycles -- which is also when a dependent one can issue
+// (tools/r5_lat_probe.hip, tools/mfma_peak.hip) -- so one accumulation chain per tile product is as fast as two, and what
+// the update phase costs is its MFMA count per SIMD: 896 MFMAs in all for eight panels.
 // Xs: TWO scratch tiles (2 x 16 x XS_LD doubles): the inverse of diagonal tile i lives in Xs + (i & 1) * 16 * XS_LD,
 // row-major, from the end of step i-1 to the panel-solve phase of step i+1.
 #ifdef POTF2_PROFILE
@@ -349,10 +355,128 @@ __device__ long long g_wprof[8 * 8 * 4];  // every wave's clock: [wave][step][af
 #define FSTAMP(i) do { } while (0)
 #define WSTAMP(p, k) do { } while (0)
 #endif
-// sink(i, t) exports block row i of L; it is called in the UPDATE phase of step i by the six waves that are neither
-// the factorising wave 0 nor its SIMD partner wave 4: t = 0..383.  (Until late in round 3 all 512 threads exported in
-// the panel-solve phase, on wave 0's critical path: 1.3K -> 0.6K cycles of that phase per step.)
-#define SINK_THREADS 384
+// The factor leaves through `sink` (the inverse overwrites it in LDS):
+//   sink.tile(t, p, acc, lane)  tile (t, p), t > p + 1, from the registers of the wave that solved it, in the panel-solve
+//                               phase of step p: acc[g] = L[16 t + (lane >> 4) + 4 g][16 p + (lane & 15)];
+//   sink.row(i, lane)           by wave 4 in the update phase of step i: the rest of block row i -- tile (i, i-1) (solved
+//                               by wave 0, which has no time for stores), the diagonal tile (column j still times L_jj:
+//                               chol16lp.hpp) and the zeros right of it.
+// (Round 3: all 512 threads exported whole block rows in the panel-solve phase, on wave 0's critical path; round 4: the six
+// workers, 1.0-1.2K cycles each in front of their tiles; one wave alone needs 3.6K per row.)
+struct FiNoSink {
+    __device__ __forceinline__ void tile(int, int, d4, int) const {}
+    __device__ __forceinline__ void row(int, int) const {}
+};
+
+// Who does what in the update phase of step p of an npan-panel block: w[npan][p][worker] packs
+//   bits 0-3 / 4-7   the tiles j of row p of the inverse this worker forms (15 = none),
+//   bits 8-11        its number of trailing tiles, then 6 bits each: (rt << 3) | ct.
+// Workers 0-5 are waves 1, 2, 3, 5, 6, 7; worker 6 is wave 0, which takes part in the last step only.  An fp64 MFMA
+// occupies its SIMD for 64 cycles whichever wave issued it, so the load is balanced per SIMD first (workers w and w + 3
+// share SIMD w + 1; worker 6 has SIMD 0 to itself) and between the two waves of a SIMD second: longest item first; an
+// inverse tile costs its k-range + 1 (the product with -X(p,p)), a trailing tile 1.
+struct FiPlan {
+    unsigned long long w[9][8][7];
+};
+constexpr FiPlan make_fi_plan() {
+    FiPlan P{};
+    for (int npan = 1; npan <= 8; ++npan)
+        for (int p = 0; p < npan; ++p) {
+            const bool lastp = (p == npan - 1);
+            int load[7] = {0, 0, 0, 0, 0, 0, 0}, ninv[7] = {0, 0, 0, 0, 0, 0, 0}, ntr[7] = {0, 0, 0, 0, 0, 0, 0};
+            unsigned long long word[7] = {0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF};
+            auto pick = [&](bool inverse) {
+                // least-loaded SIMD, then its less loaded wave (an inverse tile: a wave that holds fewer than two)
+                int best = -1, best_simd = 0, best_wave = 0;
+                for (int w = 0; w < (lastp ? 7 : 6); ++w) {
+                    if (inverse && ninv[w] >= 2) continue;
+                    if (!inverse && ntr[w] >= 8) continue;
+                    const int simd = (w == 6) ? load[6] : load[w % 3] + load[w % 3 + 3];
+                    if (best < 0 || simd < best_simd || (simd == best_simd && load[w] < best_wave)) {
+                        best = w;
+                        best_simd = simd;
+                        best_wave = load[w];
+                    }
+                }
+                return best;
+            };
+            for (int j = 0; j < p; ++j) {
+                const int w = pick(true);
+                word[w] = (word[w] & ~(0xFull << (4 * ninv[w]))) | ((unsigned long long)j << (4 * ninv[w]));
+                ++ninv[w];
+                load[w] += (p - j) + 1;
+            }
+            if (!lastp)
+                for (int rt = p + 1; rt < npan; ++rt)
+                    for (int ct = p + 1; ct <= rt; ++ct) {
+                        if (rt == p + 1 && ct == p + 1) continue;        // wave 0's own tile
+                        const int w = pick(false);
+                        word[w] |= (unsigned long long)((rt << 3) | ct) << (12 + 6 * ntr[w]);
+                        ++ntr[w];
+                        load[w] += 1;
+                    }
+            for (int w = 0; w < 7; ++w) P.w[npan][p][w] = word[w] | ((unsigned long long)ntr[w] << 8);
+        }
+    return P;
+}
+static __constant__ FiPlan c_fi_plan = make_fi_plan();
+
+// A-operand fragments of a tile: f[s] = T[r][4 s + kq]
+template <class Lay>
+__device__ __forceinline__ d4 fi_frag(const double* T, int r, int kq) {
+    d4 f;
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) f[s4] = T[Lay::in(r, 4 * s4 + kq)];
+    return f;
+}
+// C(rt, ct) -= L(rt, p) L(ct, p)^T for one tile
+template <class Lay>
+__device__ __forceinline__ void fi_trail1(double* D, int p, int rt, int ct, int lane) {
+    const int r = lane & 15, kq = lane >> 4;
+    const d4 a = fi_frag<Lay>(D + Lay::tile(rt, p), r, kq), b = fi_frag<Lay>(D + Lay::tile(ct, p), r, kq);
+    double* C = D + Lay::tile(rt, ct);
+    d4 c = tile_read<Lay>(C, lane);
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) c = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[s4], b[s4], c, 0, 0, 0);
+    tile_write<Lay>(C, c, lane);
+}
+// the operands of one trailing tile: fragments of L(rt, p) and L(ct, p), the tile itself
+template <class Lay>
+struct FiTrailOps {
+    d4 a, b, c;
+    __device__ __forceinline__ void load(const double* D, int p, int rt, int ct, int lane) {
+        const int r = lane & 15, kq = lane >> 4;
+        a = fi_frag<Lay>(D + Lay::tile(rt, p), r, kq);
+        b = fi_frag<Lay>(D + Lay::tile(ct, p), r, kq);
+        c = tile_read<Lay>(D + Lay::tile(rt, ct), lane);
+    }
+};
+// X(p, j) = -X(p, p) * sum_{k = j}^{p-1} L(p, k) X(k, j), the operands of the next k in flight
+template <class Lay>
+__device__ __forceinline__ d4 fi_inv_tile(const double* D, const double* Xp, int p, int j, int lane) {
+    const int r = lane & 15, kq = lane >> 4;
+    d4 t = (d4){0.0, 0.0, 0.0, 0.0};
+    d4 a = fi_frag<Lay>(D + Lay::tile(p, j), r, kq), b;
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) b[s4] = D[Lay::tile(j, j) + Lay::in(4 * s4 + kq, r)];
+    for (int k = j; k < p; ++k) {
+        d4 an = a, bn = b;
+        if (k + 1 < p) {
+            an = fi_frag<Lay>(D + Lay::tile(p, k + 1), r, kq);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) bn[s4] = D[Lay::tile(k + 1, j) + Lay::in(4 * s4 + kq, r)];
+        }
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) t = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s4], b[s4], t, 0, 0, 0);
+        a = an;
+        b = bn;
+    }
+    d4 x = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) x = __builtin_amdgcn_mfma_f64_16x16x4f64(-Xp[r * XS_LD + 4 * s4 + kq], t[s4], x, 0, 0, 0);
+    return x;
+}
+
 // FIRST_DONE: the caller has already factored the first diagonal tile (load_block_chol0).
 template <typename Sink, bool FIRST_DONE = false, class Lay = LayPad>
 __device__ __forceinline__ void lds_factor_inv(double* D, double* invd, double* Xs, int npan, int* s_bad, int tid,
@@ -360,11 +484,8 @@ __device__ __forceinline__ void lds_factor_inv(double* D, double* invd, double* 
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (scalar: tile-base arithmetic on the SALU)
     const int r = lane & 15, kq = lane >> 4;
     const d4 zero = (d4){0.0, 0.0, 0.0, 0.0};
-    // row-inverse workers: waves 2, 3, 5, 6, 7; wave 4 moves finished diagonal inverses into D
-    const int widx = (wave >= 5) ? wave - 3 : wave - 2;      // 0..4 for the workers
-    const bool worker = wave >= 2 && wave != 4;
-    const int slot = (wave < 4) ? wave : wave - 1;           // panel-solve tile of this wave (wave 4 has none)
-    const int widx7 = worker ? widx : 5 + wave;             // last step: waves 2,3,5,6,7,0,1 -> 0..6
+    const int wid = (wave == 0) ? 6 : (wave < 4) ? wave - 1 : wave - 2;      // worker number (wave 4: unused)
+    const int slot = (wave < 4) ? wave : wave - 1;                           // panel-solve tile of this wave (wave 4 has none)
     if (!FIRST_DONE) {
         if (wave == 0) {
             const int bad = chol16_lp<Lay, false>(D, invd, lane, Xs, XS_LD);
@@ -372,30 +493,47 @@ __device__ __forceinline__ void lds_factor_inv(double* D, double* invd, double* 
         }
         __syncthreads();
     }
-    d4 keep[2] = {zero, zero};       // block row p-1 of X, carried into step p
+    d4 keep[2] = {zero, zero};       // tiles of block row p-1 of X, carried into step p
+    unsigned long long held = 0xFF;  // which ones (the two low fields of the plan word of the step that formed them)
     for (int p = 0; p <= npan; ++p) {
         const int c0 = p * 16;
         const double* Xp = Xs + (p & 1) * 16 * XS_LD;       // inverse of diagonal tile p
+        const unsigned long long plan = (p < npan && wave != 4) ? c_fi_plan.w[npan][p][wid] : 0xFFull;
         FSTAMP(8 * p + 0);
         if (wave != 4) {
             // panel solve of tile (p + 1 + slot, p):  S = A X_p^T
             const int t = p + 1 + slot;
             if (p < npan && t < npan) {
                 double* C = D + Lay::tile(t, p);
+                const d4 a = fi_frag<Lay>(C, r, kq);
+                d4 x;
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) x[s4] = Xp[r * XS_LD + 4 * s4 + kq];
                 d4 acc = zero;
+                if (wave != 0) {
 #pragma unroll
-                for (int sft = 0; sft < 16; sft += 4)
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(C[Lay::in(r, sft + kq)], Xp[r * XS_LD + sft + kq], acc, 0, 0, 0);
-                tile_write<Lay>(C, acc, lane);
-            }
-            // block row p-1 of X, held in registers since the previous step (by seven waves if that was the last one)
-            if ((p == npan) ? true : worker) {
-                const int hw = (p == npan) ? widx7 : widx, hs = (p == npan) ? 7 : 5;
+                    for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s4], x[s4], acc, 0, 0, 0);
+                    tile_write<Lay>(C, acc, lane);
+                    sink.tile(t, p, acc, lane);
+                } else {
+                    // operands swapped: acc = X_p A^T = S^T, i.e. acc[g] = S[r][4 g + kq] -- the A-operand fragment g of the
+                    // solved tile.  The tile the next 16x16 factorisation waits for is updated from these registers
+                    // (wave 0 waits for the other waves' solves only before chol16_lp)
+                    d4 c = tile_read<Lay>(D + Lay::tile(t, t), lane);
 #pragma unroll
-                for (int cnt = 0; cnt < 2; ++cnt) {
-                    const int j = hw + hs * cnt;
-                    if (j < p - 1) tile_write<Lay>(D + Lay::tile(p - 1, j), keep[cnt], lane);
+                    for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x[s4], a[s4], acc, 0, 0, 0);
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) c = __builtin_amdgcn_mfma_f64_16x16x4f64(-acc[s4], acc[s4], c, 0, 0, 0);
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) C[Lay::in(r, 4 * s4 + kq)] = acc[s4];
+                    tile_write<Lay>(D + Lay::tile(t, t), c, lane);
                 }
+            }
+            // the tiles of block row p-1 of X held in registers since the previous step
+#pragma unroll
+            for (int cnt = 0; cnt < 2; ++cnt) {
+                const int j = (int)(held >> (4 * cnt)) & 15;
+                if (j != 15) tile_write<Lay>(D + Lay::tile(p - 1, j), keep[cnt], lane);
             }
         } else {
             if (p > 0) {
@@ -410,79 +548,50 @@ __device__ __forceinline__ void lds_factor_inv(double* D, double* invd, double* 
         __syncthreads();
         FSTAMP(8 * p + 2);
         if (p == npan) break;
-        // block row p of L (final since the end of step p-1; the inverse overwrites it in the solve phase of step p+1)
-        // goes back to HBM from the waves off the critical path
-        if (wave != 0 && wave != 4) sink(p, ((wave < 4) ? wave - 1 : wave - 2) * 64 + lane);
-        WSTAMP(p, 0);
-        // row p of the inverse: the five workers, two tiles each -- or, in the LAST step (no 16x16 factorisation left
-        // to hide behind), seven waves with one tile each
         const bool lastp = (p == npan - 1);
-        if (lastp ? (wave != 4) : worker) {
-            const int ww = lastp ? widx7 : widx, ws = lastp ? 7 : 5;
+        held = 0xFF;
+        if (wave == 4) {
+            // block row p of L (final since the end of step p-1; the inverse overwrites it in the solve phase of step p+1)
+            // goes back to HBM
+            sink.row(p, lane);
+            WSTAMP(p, 0);
+        } else if (wave != 0 || lastp) {
+            // row p of the inverse: this worker's tiles
+            held = plan & 0xFF;
 #pragma unroll
             for (int cnt = 0; cnt < 2; ++cnt) {
-                const int j = ww + ws * cnt;
-                if (j >= p) continue;
-                d4 t = zero;
-                for (int k = j; k < p; ++k)
-#pragma unroll
-                    for (int sft = 0; sft < 16; sft += 4) {
-                        const double a = D[Lay::tile(p, k) + Lay::in(r, sft + kq)];
-                        const double b = D[Lay::tile(k, j) + Lay::in(sft + kq, r)];
-                        t = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, t, 0, 0, 0);
-                    }
-                d4 x = zero;
-#pragma unroll
-                for (int sft = 0; sft < 4; ++sft)
-                    x = __builtin_amdgcn_mfma_f64_16x16x4f64(-Xp[r * XS_LD + 4 * sft + kq], t[sft], x, 0, 0, 0);
-                keep[cnt] = x;
+                const int j = (int)(plan >> (4 * cnt)) & 15;
+                if (j != 15) keep[cnt] = fi_inv_tile<Lay>(D, Xp, p, j, lane);
             }
-        }
-        WSTAMP(p, 1);
-        // trailing update of the lower tiles (rt >= ct > p); tile q = 0 is (p+1, p+1)
-        const int m = npan - 1 - p;
-        const int ntile = m * (m + 1) / 2;
-        const int nworkers = NTH / 64 - 1;
-        if (wave == 0 && ntile > 0) {
-            // the tile the next 16x16 factorisation waits for: two accumulation chains instead of four dependent MFMAs
-            double* C = D + Lay::tile(p + 1, p + 1);
-            d4 acc = tile_read<Lay>(C, lane), acc2 = zero;
-            const double* Pr = D + Lay::tile(p + 1, p);
-            const double p0v = Pr[Lay::in(r, kq)], p1v = Pr[Lay::in(r, kq + 4)], p2v = Pr[Lay::in(r, kq + 8)],
-                         p3v = Pr[Lay::in(r, kq + 12)];
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-p0v, p0v, acc, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-p1v, p1v, acc2, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-p2v, p2v, acc, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-p3v, p3v, acc2, 0, 0, 0);
-            tile_write<Lay>(C, acc + acc2, lane);
-        }
-        // (wave 4 shares its SIMD with wave 0, whose 16x16 factorisation is the critical path: it takes no tiles)
-        const int widx6 = (wave < 4) ? wave - 1 : wave - 2;
-        for (int q = (wave == 0 || wave == 4) ? ntile : 1 + widx6; q < ntile; q += nworkers - 1) {
-            int i = (int)((sqrtf(8.0f * q + 1.0f) - 1.0f) * 0.5f);
-            while (i * (i + 1) / 2 > q) --i;
-            while ((i + 1) * (i + 2) / 2 <= q) ++i;
-            const int j = q - i * (i + 1) / 2;
-            const int rt = p + 1 + i, ct = p + 1 + j;
-            double* C = D + Lay::tile(rt, ct);
-            d4 acc = tile_read<Lay>(C, lane);
+            WSTAMP(p, 1);
+            // its trailing tiles (rt >= ct > p), the operands of the next one in flight
+            const int ntr = (int)(plan >> 8) & 15;
+            if (ntr > 0) {
+                FiTrailOps<Lay> cur, nxt;
+                int t0 = (int)(plan >> 12) & 63;
+                cur.load(D, p, t0 >> 3, t0 & 7, lane);
+                for (int n = 0; n < ntr; ++n) {
+                    const int t1 = (int)(plan >> (18 + 6 * n)) & 63;
+                    nxt = cur;
+                    if (n + 1 < ntr) nxt.load(D, p, t1 >> 3, t1 & 7, lane);
+                    d4 c = cur.c;
 #pragma unroll
-            for (int sft = 0; sft < 16; sft += 4) {
-                const double a = -D[Lay::tile(rt, p) + Lay::in(r, sft + kq)];
-                const double b = D[Lay::tile(ct, p) + Lay::in(r, sft + kq)];
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+                    for (int s4 = 0; s4 < 4; ++s4) c = __builtin_amdgcn_mfma_f64_16x16x4f64(-cur.a[s4], cur.b[s4], c, 0, 0, 0);
+                    tile_write<Lay>(D + Lay::tile(t0 >> 3, t0 & 7), c, lane);
+                    cur = nxt;
+                    t0 = t1;
+                }
             }
-            tile_write<Lay>(C, acc, lane);
+            WSTAMP(p, 2);
         }
-        FSTAMP(8 * p + 3);
-        WSTAMP(p, 2);
-        if (wave == 0 && p + 1 < npan) {
+        if (wave == 0 && !lastp) {
+            FSTAMP(8 * p + 3);
             const int c1 = c0 + 16;
             const int bad = chol16_lp<Lay, false>(D + Lay::tile(p + 1, p + 1), invd + c1, lane, Xs + ((p + 1) & 1) * 16 * XS_LD, XS_LD);
             if (lane == 0 && bad && *s_bad == 0) *s_bad = c1 + bad;
-            // wave 0 carries no row of the inverse out of a step that has a 16x16 factorisation (it holds one only after
+            // wave 0 carries no tile of the inverse out of a step that has a 16x16 factorisation (it holds one only after
             // the LAST step): redefining `keep` here ends its live range at the top of this block, so that the register
-            // allocator does not hold 16 registers across chol16 for the one wave that runs it
+            // allocator does not hold 16 registers across chol16_lp for the one wave that runs it
             keep[0] = zero;
             keep[1] = zero;
         }

@@ -40,7 +40,12 @@ __device__ __forceinline__ double lp_rsqrt(double d) {
 #define LP_DECL16(P) double P##0, P##1, P##2, P##3, P##4, P##5, P##6, P##7, P##8, P##9, P##10, P##11, P##12, P##13, P##14, P##15
 template <class Lay, bool SCALED = true>
 __device__ __forceinline__ int chol16_lp(double* D, double* invd_out, int lane, double* Xout, int ldx) {
-    const int i = lane & 15, q = lane >> 4;
+    int i = lane & 15;
+    const int q = lane >> 4;
+    // (the caller runs this in a loop over diagonal tiles: everything that depends on the lane only -- eight swizzled LDS
+    // addresses, the start values of M -- is loop-invariant, and kept in registers across the loop it pushes the kernel
+    // over its register budget: the compiler then spills it and reloads it here, on the critical path.  Recomputed instead.)
+    asm volatile("" : "+v"(i));
     LP_DECL16(A);
 #define LP_LOAD2(K0, K1)                                                                  \
     {                                                                                     \

@@ -20,6 +20,9 @@
 // so that a wave fetches the fragments of two k-steps of one 16-column tile with ONE coalesced 16-byte load per lane.
 // smem: POTF2_SMEM_DOUBLES doubles of LDS -- the 36 lower 16x16 tiles of the block, packed (blocklds.hpp: LayTri), the
 // reciprocal pivots, two scratch tiles: 79 392 bytes, so that TWO workgroups of a launch with this role fit one CU.
+#ifndef FI_BURST
+#define FI_BURST 8
+#endif
 #define POTF2_SMEM_DOUBLES (LayTri::DOUBLES + NB + 32 * XS_LD + 4)
 typedef LayTri PL;
 template <typename R>
@@ -64,17 +67,52 @@ __device__ __forceinline__ void potf2_body(double* __restrict__ smem, const int 
         if (c + 1 > r) v[1] = 0.0;
         return v;
     };
-    auto export_row = [&](int i, int t) {
-        for (int e = t; e < 16 * 64; e += SINK_THREADS) {
-            int r, c;
-            const d2 w = lower_chunk(i, e, r, c, true);
-            RV2 v;
-            v[0] = (R)w[0];
-            v[1] = (R)w[1];
-            *reinterpret_cast<RV2*>(Ablk + (int64_t)r * ld + c) = v;
+    // how the factor leaves (blocklds.hpp: lds_factor_inv)
+    struct Sink {
+        R* Ablk;
+        int64_t ld;
+        const double* D;
+        const double* invd;
+        // tile (t, p) from the solving wave's accumulator: four rows x 128 bytes per store instruction
+        __device__ __forceinline__ void tile(int t, int p, d4 acc, int lane) const {
+            R* dst = Ablk + (int64_t)(16 * t + (lane >> 4)) * ld + 16 * p + (lane & 15);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) dst[(int64_t)(4 * g) * ld] = (R)acc[g];
+        }
+        // tile (i, i-1), the diagonal tile (scaled, zeros above the diagonal) and the zero tiles right of it: one 16-byte
+        // chunk per lane and tile (row lane >> 3 and row 8 + (lane >> 3), column pair lane & 7)
+        __device__ __forceinline__ void row(int i, int lane) const {
+            const int c2 = (lane & 7) * 2;
+            d2 w[2][2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int rr = (lane >> 3) + 8 * h;
+                w[0][h] = (i > 0) ? *reinterpret_cast<const d2*>(D + PL::tile(i, i - 1) + PL::in(rr, c2)) : (d2){0.0, 0.0};
+                d2 v = *reinterpret_cast<const d2*>(D + PL::tile(i, i) + PL::in(rr, c2));
+                v[0] = (c2 > rr) ? 0.0 : v[0] * invd[16 * i + c2];
+                v[1] = (c2 + 1 > rr) ? 0.0 : v[1] * invd[16 * i + c2 + 1];
+                w[1][h] = v;
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                R* dst = Ablk + (int64_t)(16 * i + (lane >> 3) + 8 * h) * ld + c2;
+                RV2 v;
+                if (i > 0) {
+                    v[0] = (R)w[0][h][0];
+                    v[1] = (R)w[0][h][1];
+                    *reinterpret_cast<RV2*>(dst + 16 * (i - 1)) = v;
+                }
+                v[0] = (R)w[1][h][0];
+                v[1] = (R)w[1][h][1];
+                *reinterpret_cast<RV2*>(dst + 16 * i) = v;
+                v[0] = (R)0.0;
+                v[1] = (R)0.0;
+                for (int tj = i + 1; tj < 8; ++tj) *reinterpret_cast<RV2*>(dst + 16 * tj) = v;
+            }
         }
     };
-    lds_factor_inv<decltype(export_row), true, PL>(D, invd, Xs, 8, &s_bad, tid, export_row);
+    const Sink sink{Ablk, ld, D, invd};
+    lds_factor_inv<Sink, true, PL>(D, invd, Xs, 8, &s_bad, tid, sink);
     STAMP(2);
     // log-determinant partial (fixed order) from the reciprocal pivots
     if (wave < 2) {

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(NTH, 1) void fit_small_kernel(SmallFitArgs a) {
         SSTAMP(3);
         // Cholesky and triangular inverse in one sweep (the inverse is built block row by block row
         // behind the factorisation); D holds L^-1 afterwards
-        lds_factor_inv(D, invd, Xs, npan, &s_bad, tid, [](int, int) {});
+        lds_factor_inv(D, invd, Xs, npan, &s_bad, tid, FiNoSink{});
         // not positive-definite: the reference raises at this iteration (gpr.py:192) with u, the Adam
         // state and the history as the previous one left them -- stop here, record how far we got
         __syncthreads();

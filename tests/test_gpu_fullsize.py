@@ -146,6 +146,26 @@ def test_c3_batched_equals_single_on_samples(gpim):
         np.testing.assert_array_equal(sd[..., k], s1)
 
 
+@pytest.mark.parametrize("batch", [64, "auto"])
+def test_c3_own_size_against_oracle(gpim, batch):
+    """Config C3 at its own size (N = 1207 per slice: ragged last block, nb = 10, split lock-step batch) against the
+    oracle's per-slice reconstructor (reference: gpr.py:185-199 training step, gpr.py:247-250 posterior)."""
+    from gpim_amd import dist as gd
+    R, _ = hyperspectral_cube()
+    T = 5
+    kw = dict(kernel="RBF", lengthscale=[[1., 1.], [20., 20.]], learning_rate=0.1, iterations=T)
+    assert int(np.isfinite(R[..., 0]).sum()) == 1207
+    mean, sd, hyper = gd.reconstruct_slices(R, axis=-1, batch=batch, return_hyperparams=True, **kw)
+    for k in (0, 31, 63):
+        Rk = R[..., k]
+        mo, so, ho = O.reconstructor(gpim.utils.get_sparse_grid(Rk), Rk, gpim.utils.get_full_grid(Rk), verbose=0, **kw).run()
+        href = np.column_stack([np.reshape(ho["variance"], (T, -1)), np.reshape(ho["lengthscale"], (T, -1)),
+                                np.reshape(ho["noise"], (T, -1))])
+        assert_allclose(hyper[k], href, rtol=1e-9)
+        assert np.sqrt(np.mean((mean[..., k] - mo) ** 2)) < 1e-9
+        assert np.sqrt(np.mean((sd[..., k] - so) ** 2)) < 1e-9
+
+
 def test_split_batch_odd_sizes_and_ragged_block_equal_single(gpim):
     """Lock-step batches of more than four problems run as two halves taking turns (factorisation role of one half
     beside the pending tile operations of the other: csrc/cholstep.hip launch_potrf_steps); odd sizes give halves of

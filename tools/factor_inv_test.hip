@@ -16,12 +16,23 @@ __global__ __launch_bounds__(NTH, 1) void k(const double* A, double* Lout, doubl
     if (tid == 0) s_bad = 0;
     __syncthreads();
     const long long t0 = clock64();
-    lds_factor_inv(D, invd, Xs, npan, &s_bad, tid, [&](int i, int t) {
-        for (int e = t; e < 16 * ns; e += SINK_THREADS) {
-            const int r = i * 16 + e / ns, c = e % ns;
-            Lout[r * ns + c] = (c <= r) ? D[r * LDD + c] * ((c >> 4) == i ? invd[c] : 1.0) : 0.0;      // (diagonal tile: column c still times L_cc, chol16lp.hpp)
+    struct Sink {
+        double *Lout, *D, *invd;
+        int ns;
+        __device__ void tile(int t, int p, d4 acc, int lane) const {
+            for (int g = 0; g < 4; ++g) Lout[(16 * t + (lane >> 4) + 4 * g) * ns + 16 * p + (lane & 15)] = acc[g];
         }
-    });
+        __device__ void row(int i, int lane) const {
+            for (int e = lane; e < 16 * ns; e += 64) {
+                const int r = i * 16 + e / ns, c = e % ns;
+                // (diagonal tile: column c still times L_cc, chol16lp.hpp)
+                if ((c >> 4) == i) Lout[r * ns + c] = (c <= r) ? D[r * LDD + c] * invd[c] : 0.0;
+                else if ((c >> 4) == i - 1) Lout[r * ns + c] = D[r * LDD + c];
+                else if ((c >> 4) > i) Lout[r * ns + c] = 0.0;
+            }
+        }
+    };
+    lds_factor_inv(D, invd, Xs, npan, &s_bad, tid, Sink{Lout, D, invd, ns});
     const long long t1 = clock64();
     for (int e = tid; e < ns * ns; e += NTH) Xout[e] = ((e % ns) <= (e / ns)) ? D[(e / ns) * LDD + (e % ns)] : 0.0;
     if (tid == 0) cyc[0] = t1 - t0;

@@ -26,7 +26,7 @@ int main() {
     {
         long long fp[128];
         hipMemcpyFromSymbol(fp, HIP_SYMBOL(g_fprof), sizeof(fp));
-        printf("wave 0 inside lds_factor_inv, cycles per 16-column step: [panel solve | wait | own tile update | chol16 of the next tile | wait]\n");
+        printf("wave 0 inside lds_factor_inv, cycles per 16-column step: [panel solve | wait | own tile update | chol16_lp of the next tile | wait]\n");
         for (int p = 0; p < 8; ++p)
             printf("  step %d: %5lld | %5lld | %5lld | %5lld | %5lld   (step total %lld)\n", p, fp[8 * p + 1] - fp[8 * p], fp[8 * p + 2] - fp[8 * p + 1],
                    fp[8 * p + 3] - fp[8 * p + 2], fp[8 * p + 4] - fp[8 * p + 3], fp[8 * p + 5] - fp[8 * p + 4], fp[8 * p + 5] - fp[8 * p]);
