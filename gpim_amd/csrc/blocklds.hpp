@@ -25,11 +25,13 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 //           (rr = 4 s + (lane >> 4), cc = lane & 15) -- the 32 lanes of a group then hit 32 distinct bank pairs.  The
 //           swizzle is even: the pair (cc, cc + 1), cc even, stays one aligned 16-byte chunk.
 struct LayPad {
+    static constexpr bool XT = false;      // lds_factor_inv leaves the tiles of the inverse as they are
     static constexpr int DOUBLES = NB * LDD;
     __device__ __forceinline__ static int tile(int ti, int tj) { return ti * 16 * LDD + tj * 16; }
     __device__ __forceinline__ static int in(int rr, int cc) { return rr * LDD + cc; }
 };
 struct LayTri {
+    static constexpr bool XT = true;       // lds_factor_inv leaves every 16x16 tile of the inverse TRANSPOSED (see there)
     static constexpr int DOUBLES = 36 * 256;
     __device__ __forceinline__ static int tile(int ti, int tj) { return ((ti * (ti + 1)) / 2 + tj) * 256; }
     __device__ __forceinline__ static int in(int rr, int cc) { return rr * 16 + (cc ^ ((rr >> 1) << 1)); }
@@ -346,6 +348,9 @@ __device__ __forceinline__ void load_block_chol0(double* D, double* invd, int* s
 // the update phase costs is its MFMA count per SIMD: 896 MFMAs in all for eight panels.
 // Xs: TWO scratch tiles (2 x 16 x XS_LD doubles): the inverse of diagonal tile i lives in Xs + (i & 1) * 16 * XS_LD,
 // row-major, from the end of step i-1 to the panel-solve phase of step i+1.
+#ifndef FI_EXP
+#define FI_EXP 0
+#endif
 #ifdef POTF2_PROFILE
 __device__ long long g_fprof[128];       // tools/potf2_prof.hip: wave 0's clock at the marks below, 8 per 16-column step
 #define FSTAMP(i) do { if (threadIdx.x == 0) g_fprof[i] = clock64(); } while (0)
@@ -357,7 +362,7 @@ __device__ long long g_wprof[8 * 8 * 4];  // every wave's clock: [wave][step][af
 #endif
 // The factor leaves through `sink` (the inverse overwrites it in LDS):
 //   sink.tile(t, p, acc, lane)  tile (t, p), t > p + 1, from the registers of the wave that solved it, in the panel-solve
-//                               phase of step p: acc[g] = L[16 t + (lane >> 4) + 4 g][16 p + (lane & 15)];
+//                               phase of step p: acc = fi_frag of the tile, i.e. acc[2 h + e] = L[16 t + (lane & 15)][16 p + 8 h + 2 (lane >> 4) + e];
 //   sink.row(i, lane)           by wave 4 in the update phase of step i: the rest of block row i -- tile (i, i-1) (solved
 //                               by wave 0, which has no time for stores), the diagonal tile (column j still times L_jj:
 //                               chol16lp.hpp) and the zeros right of it.
@@ -369,12 +374,19 @@ struct FiNoSink {
 };
 
 // Who does what in the update phase of step p of an npan-panel block: w[npan][p][worker] packs
-//   bits 0-3 / 4-7   the tiles j of row p of the inverse this worker forms (15 = none),
-//   bits 8-11        its number of trailing tiles, then 6 bits each: (rt << 3) | ct.
+//   bits 0-3 / 4-7   the tiles j of row p of the inverse this worker forms (15 = none; the first is the smaller j),
+//   bits 8-11        its number of trailing ITEMS, then 12 bits each: (rtA << 9) | (ctA << 6) | (rtB << 3) | ctB --
+//                    two tiles updated together (rtB = 0: one tile alone).
 // Workers 0-5 are waves 1, 2, 3, 5, 6, 7; worker 6 is wave 0, which takes part in the last step only.  An fp64 MFMA
 // occupies its SIMD for 64 cycles whichever wave issued it, so the load is balanced per SIMD first (workers w and w + 3
 // share SIMD w + 1; worker 6 has SIMD 0 to itself) and between the two waves of a SIMD second: longest item first; an
 // inverse tile costs its k-range + 1 (the product with -X(p,p)), a trailing tile 1.
+// Why pairs (tools/r5_trail_probe.hip, cycles per tile and SIMD with two waves per SIMD; the MFMAs alone: 261): every
+// LDS instruction costs the SIMD ~20 cycles of MFMA issue whichever wave it comes from, and a tile alone is a chain of
+// load latency -> four dependent MFMAs -> store.  One tile per loop trip with the next one's operands prefetched
+// (round 5's first version: copies between register sets, each stalling on the MFMA that still reads its target) 669,
+// one tile per trip without prefetch 508, two tiles of one block row per trip (shared A fragments, two accumulator
+// chains) 348, two unrelated tiles 379.
 struct FiPlan {
     unsigned long long w[9][8][7];
 };
@@ -390,7 +402,6 @@ constexpr FiPlan make_fi_plan() {
                 int best = -1, best_simd = 0, best_wave = 0;
                 for (int w = 0; w < (lastp ? 7 : 6); ++w) {
                     if (inverse && ninv[w] >= 2) continue;
-                    if (!inverse && ntr[w] >= 8) continue;
                     const int simd = (w == 6) ? load[6] : load[w % 3] + load[w % 3 + 3];
                     if (best < 0 || simd < best_simd || (simd == best_simd && load[w] < best_wave)) {
                         best = w;
@@ -406,75 +417,175 @@ constexpr FiPlan make_fi_plan() {
                 ++ninv[w];
                 load[w] += (p - j) + 1;
             }
-            if (!lastp)
-                for (int rt = p + 1; rt < npan; ++rt)
-                    for (int ct = p + 1; ct <= rt; ++ct) {
-                        if (rt == p + 1 && ct == p + 1) continue;        // wave 0's own tile
-                        const int w = pick(false);
-                        word[w] |= (unsigned long long)((rt << 3) | ct) << (12 + 6 * ntr[w]);
-                        ++ntr[w];
-                        load[w] += 1;
+            if (!lastp) {
+                // the trailing tiles in row-major order, dealt in contiguous runs (neighbours in a run mostly share their block
+                // row, hence their A fragments) whose lengths even out the load: a trailing tile weighs 4, one 16-deep
+                // product of an inverse tile 3 (half the LDS instructions)
+                int tiles[32] = {}, nt = 0, cnt[7] = {0, 0, 0, 0, 0, 0, 0}, wl[7] = {0, 0, 0, 0, 0, 0, 0};
+                for (int rt = npan - 1; rt > p; --rt)
+                    for (int ct = p + 1; ct <= rt; ++ct)
+                        if (!(rt == p + 1 && ct == p + 1)) tiles[nt++] = (rt << 3) | ct;      // (not wave 0's own tile)
+                for (int w = 0; w < 6; ++w) wl[w] = 3 * load[w];
+                for (int i = 0; i < nt; ++i) {
+                    int best = 0;
+                    for (int w = 1; w < 6; ++w) {
+                        const int sb = wl[best % 3] + wl[best % 3 + 3], sw = wl[w % 3] + wl[w % 3 + 3];
+                        if (sw < sb || (sw == sb && wl[w] < wl[best])) best = w;
                     }
+                    ++cnt[best];
+                    wl[best] += 4;
+                }
+                int at = 0;
+                for (int w = 0; w < 6; ++w) {
+                    int i = 0;
+                    for (; i + 1 < cnt[w]; i += 2) {
+                        word[w] |= (unsigned long long)((tiles[at + i] << 6) | tiles[at + i + 1]) << (12 + 12 * ntr[w]);
+                        ++ntr[w];
+                    }
+                    if (i < cnt[w]) {
+                        word[w] |= (unsigned long long)(tiles[at + i] << 6) << (12 + 12 * ntr[w]);
+                        ++ntr[w];
+                    }
+                    at += cnt[w];
+                }
+            }
             for (int w = 0; w < 7; ++w) P.w[npan][p][w] = word[w] | ((unsigned long long)ntr[w] << 8);
         }
     return P;
 }
 static __constant__ FiPlan c_fi_plan = make_fi_plan();
 
-// A-operand fragments of a tile: f[s] = T[r][4 s + kq]
+// Operand fragments with 16-byte LDS accesses.  The four k-steps of a 16-deep product may visit the 16 columns of the
+// operand tiles in any order as long as both operands use the same one; with
+//     kappa(s, kq) = 8 (s >> 1) + 2 kq + (s & 1)        (k-step s, lane group kq = lane >> 4)
+// instead of 4 s + kq a lane's four values are two aligned pairs of ONE row -- columns 2 kq, 2 kq + 1 and 8 + 2 kq,
+// 9 + 2 kq -- i.e. two ds_read_b128 instead of four ds_read_b64 (both layouts keep an even-aligned column pair in one
+// 16-byte chunk; LayTri's swizzle stays conflict-free for the four 16-lane groups of a b128 access, also with the row
+// permutation rho below).  An LDS instruction costs its SIMD ~10-25 cycles of MFMA issue whichever wave it comes from
+// (tools/r5_trail_probe.hip: a 16-deep product with 8 ds_read_b64 423 cycles per SIMD, with 4 ds_read_b128 312, the four
+// MFMAs alone 262), so the instruction count is what the update phase pays for.
+//     fi_frag(T, row, kq)[s] = T[row][kappa(s, kq)]
 template <class Lay>
-__device__ __forceinline__ d4 fi_frag(const double* T, int r, int kq) {
-    d4 f;
-#pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) f[s4] = T[Lay::in(r, 4 * s4 + kq)];
-    return f;
+__device__ __forceinline__ d4 fi_frag(const double* T, int row, int kq) {
+    const d2 lo = *reinterpret_cast<const d2*>(T + Lay::in(row, 2 * kq)), hi = *reinterpret_cast<const d2*>(T + Lay::in(row, 8 + 2 * kq));
+    return (d4){lo[0], lo[1], hi[0], hi[1]};
 }
-// C(rt, ct) -= L(rt, p) L(ct, p)^T for one tile
+template <class Lay>
+__device__ __forceinline__ void fi_frag_store(double* T, int row, int kq, d4 v) {
+    *reinterpret_cast<d2*>(T + Lay::in(row, 2 * kq)) = (d2){v[0], v[1]};
+    *reinterpret_cast<d2*>(T + Lay::in(row, 8 + 2 * kq)) = (d2){v[2], v[3]};
+}
+// The accumulator of the MFMA is fixed: lane (r, kq), register g holds Out[4 g + kq][r].  With the A operand's rows
+// permuted by rho(i) = kappa(i >> 2, i & 3) the products below come out as Out[i][j] = C[j][rho(i)], so register g of
+// lane (r, kq) is C[r][kappa(g, kq)]: the accumulator IS fi_frag of the result tile and moves with two 16-byte accesses.
+__device__ __forceinline__ int fi_rho(int i) { return 8 * (i >> 3) + 2 * (i & 3) + ((i >> 2) & 1); }
+// B-operand fragments of a tile used untransposed: f[s] = T[kappa(s, kq)][r]
+template <class Lay>
+__device__ __forceinline__ d4 fi_fragT(const double* T, int r, int kq) {
+    return (d4){T[Lay::in(2 * kq, r)], T[Lay::in(2 * kq + 1, r)], T[Lay::in(8 + 2 * kq, r)], T[Lay::in(9 + 2 * kq, r)]};
+}
+// fragments of a 16x16 scratch tile (row-major, leading dimension XS_LD) in the same column order
+__device__ __forceinline__ d4 fi_frag_xs(const double* Xp, int row, int kq) {
+    const d2 lo = *reinterpret_cast<const d2*>(Xp + row * XS_LD + 2 * kq), hi = *reinterpret_cast<const d2*>(Xp + row * XS_LD + 8 + 2 * kq);
+    return (d4){lo[0], lo[1], hi[0], hi[1]};
+}
+// C(rt, ct) -= L(rt, p) L(ct, p)^T for one tile: Out[i][j] = sum_c L(ct, p)[rho(i)][c] L(rt, p)[j][c]
 template <class Lay>
 __device__ __forceinline__ void fi_trail1(double* D, int p, int rt, int ct, int lane) {
     const int r = lane & 15, kq = lane >> 4;
-    const d4 a = fi_frag<Lay>(D + Lay::tile(rt, p), r, kq), b = fi_frag<Lay>(D + Lay::tile(ct, p), r, kq);
+    const d4 a = fi_frag<Lay>(D + Lay::tile(ct, p), fi_rho(r), kq), b = fi_frag<Lay>(D + Lay::tile(rt, p), r, kq);
     double* C = D + Lay::tile(rt, ct);
-    d4 c = tile_read<Lay>(C, lane);
+    d4 c = fi_frag<Lay>(C, r, kq);
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) c = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[s4], b[s4], c, 0, 0, 0);
-    tile_write<Lay>(C, c, lane);
+    fi_frag_store<Lay>(C, r, kq, c);
 }
-// the operands of one trailing tile: fragments of L(rt, p) and L(ct, p), the tile itself
-template <class Lay>
-struct FiTrailOps {
-    d4 a, b, c;
-    __device__ __forceinline__ void load(const double* D, int p, int rt, int ct, int lane) {
-        const int r = lane & 15, kq = lane >> 4;
-        a = fi_frag<Lay>(D + Lay::tile(rt, p), r, kq);
-        b = fi_frag<Lay>(D + Lay::tile(ct, p), r, kq);
-        c = tile_read<Lay>(D + Lay::tile(rt, ct), lane);
+// ... for two tiles at once: two accumulator chains; SHARED: both in block row rtA (one set of fragments of L(rtA, p))
+template <class Lay, bool SHARED>
+__device__ __forceinline__ void fi_trail2(double* D, int p, int rtA, int ctA, int rtB, int ctB, int lane) {
+    const int r = lane & 15, kq = lane >> 4, rr = fi_rho(r);
+    const d4 b0 = fi_frag<Lay>(D + Lay::tile(rtA, p), r, kq);
+    const d4 b1 = SHARED ? b0 : fi_frag<Lay>(D + Lay::tile(rtB, p), r, kq);
+    const d4 a0 = fi_frag<Lay>(D + Lay::tile(ctA, p), rr, kq), a1 = fi_frag<Lay>(D + Lay::tile(ctB, p), rr, kq);
+    double* C0 = D + Lay::tile(rtA, ctA);
+    double* C1 = D + Lay::tile(rtB, ctB);
+    d4 c0 = fi_frag<Lay>(C0, r, kq), c1 = fi_frag<Lay>(C1, r, kq);
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+        c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a0[s4], b0[s4], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a1[s4], b1[s4], c1, 0, 0, 0);
     }
-};
-// X(p, j) = -X(p, p) * sum_{k = j}^{p-1} L(p, k) X(k, j), the operands of the next k in flight
+    fi_frag_store<Lay>(C0, r, kq, c0);
+    fi_frag_store<Lay>(C1, r, kq, c1);
+}
+// X(p, j) = -X(p, p) * sum_{k = j}^{p-1} L(p, k) X(k, j) for the tiles j1 < j2 of one worker (j2 = 15: j1 alone): where both
+// sums run they share the fragments of L(p, k) and their two accumulator chains alternate.
+// Lay::XT: the tiles of the inverse live in D TRANSPOSED -- the contraction runs over the ROWS of X(k, j), and only a
+// tile's columns come in 16-byte pairs: X(k, j)[kappa(s, kq)][r] = X(k, j)^T[r][kappa(s, kq)] is fi_frag of the stored
+// tile, and with the rows of -X(p, p) permuted by rho the result leaves the accumulator as fi_frag of X(p, j)^T.
+// Otherwise (the fused small-N trainer reads the inverse in place) the B operand is gathered with four 8-byte reads and the
+// result x[g] = X(p, j)[4 g + kq][r] is an accumulator tile (tile_write).
 template <class Lay>
-__device__ __forceinline__ d4 fi_inv_tile(const double* D, const double* Xp, int p, int j, int lane) {
+__device__ __forceinline__ d4 fi_xfrag(const double* T, int r, int kq) {
+    return Lay::XT ? fi_frag<Lay>(T, r, kq) : fi_fragT<Lay>(T, r, kq);
+}
+template <class Lay>
+__device__ __forceinline__ void fi_inv_pair(const double* D, const double* Xp, int p, int j1, int j2, int lane, d4& x1, d4& x2) {
     const int r = lane & 15, kq = lane >> 4;
-    d4 t = (d4){0.0, 0.0, 0.0, 0.0};
-    d4 a = fi_frag<Lay>(D + Lay::tile(p, j), r, kq), b;
+    d4 xa;
+    {
+        const int row = Lay::XT ? fi_rho(r) : r;
 #pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) b[s4] = D[Lay::tile(j, j) + Lay::in(4 * s4 + kq, r)];
-    for (int k = j; k < p; ++k) {
-        d4 an = a, bn = b;
-        if (k + 1 < p) {
-            an = fi_frag<Lay>(D + Lay::tile(p, k + 1), r, kq);
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) bn[s4] = D[Lay::tile(k + 1, j) + Lay::in(4 * s4 + kq, r)];
-        }
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) t = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s4], b[s4], t, 0, 0, 0);
-        a = an;
-        b = bn;
+        for (int s4 = 0; s4 < 4; ++s4) xa[s4] = -Xp[row * XS_LD + 4 * s4 + kq];
     }
-    d4 x = (d4){0.0, 0.0, 0.0, 0.0};
+    d4 t1 = (d4){0.0, 0.0, 0.0, 0.0}, t2 = t1;
+    const int ke = (j2 != 15) ? j2 : p;
+    int k = j1;
+    // (two register sets taking turns: the operands of step k + 1 are in flight during the MFMAs of step k, and no set is
+    // copied into another -- a copy waits for the MFMA that still reads its target)
+    if (k < ke) {
+        d4 a0 = fi_frag<Lay>(D + Lay::tile(p, k), r, kq), b0 = fi_xfrag<Lay>(D + Lay::tile(k, j1), r, kq), a1 = a0, b1 = b0;
+        for (; k < ke; k += 2) {
+            if (k + 1 < ke) {
+                a1 = fi_frag<Lay>(D + Lay::tile(p, k + 1), r, kq);
+                b1 = fi_xfrag<Lay>(D + Lay::tile(k + 1, j1), r, kq);
+            }
 #pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) x = __builtin_amdgcn_mfma_f64_16x16x4f64(-Xp[r * XS_LD + 4 * s4 + kq], t[s4], x, 0, 0, 0);
-    return x;
+            for (int s4 = 0; s4 < 4; ++s4) t1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[s4], b0[s4], t1, 0, 0, 0);
+            if (k + 1 >= ke) break;
+            if (k + 2 < ke) {
+                a0 = fi_frag<Lay>(D + Lay::tile(p, k + 2), r, kq);
+                b0 = fi_xfrag<Lay>(D + Lay::tile(k + 2, j1), r, kq);
+            }
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) t1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[s4], b1[s4], t1, 0, 0, 0);
+        }
+        k = ke;
+    }
+    for (; k < p; ++k) {
+        const d4 a = fi_frag<Lay>(D + Lay::tile(p, k), r, kq);
+        const d4 b1 = fi_xfrag<Lay>(D + Lay::tile(k, j1), r, kq), b2 = fi_xfrag<Lay>(D + Lay::tile(k, j2), r, kq);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            t1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s4], b1[s4], t1, 0, 0, 0);
+            t2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s4], b2[s4], t2, 0, 0, 0);
+        }
+    }
+    // (the B operand comes straight from the accumulators: t[g] = T[4 g + kq][r], so k-step g contracts rows 4 g + kq)
+    d4 y1 = (d4){0.0, 0.0, 0.0, 0.0}, y2 = y1;
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+        y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[s4], t1[s4], y1, 0, 0, 0);
+        y2 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[s4], t2[s4], y2, 0, 0, 0);
+    }
+    x1 = y1;
+    x2 = y2;
+}
+// a tile of the inverse from the accumulator of fi_inv_pair into D
+template <class Lay>
+__device__ __forceinline__ void fi_xstore(double* T, d4 x, int lane) {
+    if (Lay::XT) fi_frag_store<Lay>(T, lane & 15, lane >> 4, x);
+    else tile_write<Lay>(T, x, lane);
 }
 
 // FIRST_DONE: the caller has already factored the first diagonal tile (load_block_chol0).
@@ -504,28 +615,26 @@ __device__ __forceinline__ void lds_factor_inv(double* D, double* invd, double* 
             // panel solve of tile (p + 1 + slot, p):  S = A X_p^T
             const int t = p + 1 + slot;
             if (p < npan && t < npan) {
+                // Out[i][j] = sum_c X_p[rho(i)][c] A[j][c] = S[j][rho(i)]: the accumulator is fi_frag of the solved tile
                 double* C = D + Lay::tile(t, p);
                 const d4 a = fi_frag<Lay>(C, r, kq);
-                d4 x;
-#pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) x[s4] = Xp[r * XS_LD + 4 * s4 + kq];
+                const d4 x = fi_frag_xs(Xp, fi_rho(r), kq);
                 d4 acc = zero;
-                if (wave != 0) {
 #pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s4], x[s4], acc, 0, 0, 0);
-                    tile_write<Lay>(C, acc, lane);
+                for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x[s4], a[s4], acc, 0, 0, 0);
+                if (wave != 0) {
+                    fi_frag_store<Lay>(C, r, kq, acc);
+#if !(FI_EXP & 4)
                     sink.tile(t, p, acc, lane);
+#endif
                 } else {
-                    // operands swapped: acc = X_p A^T = S^T, i.e. acc[g] = S[r][4 g + kq] -- the A-operand fragment g of the
-                    // solved tile.  The tile the next 16x16 factorisation waits for is updated from these registers
-                    // (wave 0 waits for the other waves' solves only before chol16_lp)
+                    // acc[s] = S[r][kappa(s, kq)] is also the operand fragment s of the solved tile: the tile the next 16x16
+                    // factorisation waits for is updated from these registers (wave 0 waits for the other waves' solves only
+                    // before chol16_lp)
                     d4 c = tile_read<Lay>(D + Lay::tile(t, t), lane);
 #pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x[s4], a[s4], acc, 0, 0, 0);
-#pragma unroll
                     for (int s4 = 0; s4 < 4; ++s4) c = __builtin_amdgcn_mfma_f64_16x16x4f64(-acc[s4], acc[s4], c, 0, 0, 0);
-#pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4) C[Lay::in(r, 4 * s4 + kq)] = acc[s4];
+                    fi_frag_store<Lay>(C, r, kq, acc);
                     tile_write<Lay>(D + Lay::tile(t, t), c, lane);
                 }
             }
@@ -533,14 +642,14 @@ __device__ __forceinline__ void lds_factor_inv(double* D, double* invd, double* 
 #pragma unroll
             for (int cnt = 0; cnt < 2; ++cnt) {
                 const int j = (int)(held >> (4 * cnt)) & 15;
-                if (j != 15) tile_write<Lay>(D + Lay::tile(p - 1, j), keep[cnt], lane);
+                if (j != 15) fi_xstore<Lay>(D + Lay::tile(p - 1, j), keep[cnt], lane);
             }
         } else {
             if (p > 0) {
                 const double* Xq = Xs + ((p - 1) & 1) * 16 * XS_LD;
                 d4 xd;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) xd[g] = Xq[(kq + 4 * g) * XS_LD + r];
+                for (int g = 0; g < 4; ++g) xd[g] = Lay::XT ? Xq[r * XS_LD + kq + 4 * g] : Xq[(kq + 4 * g) * XS_LD + r];
                 tile_write<Lay>(D + Lay::tile(p - 1, p - 1), xd, lane);
             }
         }
@@ -553,38 +662,33 @@ __device__ __forceinline__ void lds_factor_inv(double* D, double* invd, double* 
         if (wave == 4) {
             // block row p of L (final since the end of step p-1; the inverse overwrites it in the solve phase of step p+1)
             // goes back to HBM
+#if !(FI_EXP & 4)
             sink.row(p, lane);
+#endif
             WSTAMP(p, 0);
         } else if (wave != 0 || lastp) {
             // row p of the inverse: this worker's tiles
             held = plan & 0xFF;
-#pragma unroll
-            for (int cnt = 0; cnt < 2; ++cnt) {
-                const int j = (int)(plan >> (4 * cnt)) & 15;
-                if (j != 15) keep[cnt] = fi_inv_tile<Lay>(D, Xp, p, j, lane);
-            }
+#if !(FI_EXP & 2)
+            if ((plan & 15) != 15) fi_inv_pair<Lay>(D, Xp, p, (int)plan & 15, (int)(plan >> 4) & 15, lane, keep[0], keep[1]);
+#endif
             WSTAMP(p, 1);
-            // its trailing tiles (rt >= ct > p), the operands of the next one in flight
+            // its trailing tiles (rt >= ct > p), two at a time
+#if FI_EXP & 8
+            const int ntr = 0;
+#else
             const int ntr = (int)(plan >> 8) & 15;
-            if (ntr > 0) {
-                FiTrailOps<Lay> cur, nxt;
-                int t0 = (int)(plan >> 12) & 63;
-                cur.load(D, p, t0 >> 3, t0 & 7, lane);
-                for (int n = 0; n < ntr; ++n) {
-                    const int t1 = (int)(plan >> (18 + 6 * n)) & 63;
-                    nxt = cur;
-                    if (n + 1 < ntr) nxt.load(D, p, t1 >> 3, t1 & 7, lane);
-                    d4 c = cur.c;
-#pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4) c = __builtin_amdgcn_mfma_f64_16x16x4f64(-cur.a[s4], cur.b[s4], c, 0, 0, 0);
-                    tile_write<Lay>(D + Lay::tile(t0 >> 3, t0 & 7), c, lane);
-                    cur = nxt;
-                    t0 = t1;
-                }
+#endif
+            for (int n = 0; n < ntr; ++n) {
+                const int it = (int)(plan >> (12 + 12 * n)) & 0xFFF;
+                const int rtA = it >> 9, ctA = (it >> 6) & 7, rtB = (it >> 3) & 7, ctB = it & 7;
+                if (rtB == 0) fi_trail1<Lay>(D, p, rtA, ctA, lane);
+                else if (rtA == rtB) fi_trail2<Lay, true>(D, p, rtA, ctA, rtB, ctB, lane);
+                else fi_trail2<Lay, false>(D, p, rtA, ctA, rtB, ctB, lane);
             }
             WSTAMP(p, 2);
         }
-        if (wave == 0 && !lastp) {
+        if (wave == 0 && !lastp && !(FI_EXP & 1)) {
             FSTAMP(8 * p + 3);
             const int c1 = c0 + 16;
             const int bad = chol16_lp<Lay, false>(D + Lay::tile(p + 1, p + 1), invd + c1, lane, Xs + ((p + 1) & 1) * 16 * XS_LD, XS_LD);

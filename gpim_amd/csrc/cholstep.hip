@@ -28,7 +28,9 @@
 #include "potf2_body.hpp"
 #include "gemm_body.hpp"
 
+#ifndef STEP_W
 #define STEP_W 4
+#endif
 
 struct StepArgs {
     double* A; int64_t ld; int kblk; int nb;
@@ -434,7 +436,10 @@ static void plan_inverse(int nb, std::vector<std::vector<TileDesc>>& fill, std::
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return nodes[a].height < nodes[b].height; });
     size_t open_nodes = 0;
     for (auto& n : nodes) open_nodes += (n.height > 0);
-    const double CHAIN = 1.1;                   // length of the factorisation role in cost units
+#ifndef PLAN_CHAIN
+#define PLAN_CHAIN 1.1
+#endif
+    const double CHAIN = PLAN_CHAIN;                   // length of the factorisation role in cost units
     for (int L = 0; open_nodes > 0; ++L) {
         const bool hosted = L < nb;
         if (!hosted) post.emplace_back();
@@ -451,7 +456,7 @@ static void plan_inverse(int nb, std::vector<std::vector<TileDesc>>& fill, std::
         // constants matter little: 1.5 ... 2.0 and 1.3 ... 1.6 measure the same)
         const bool two = hosted && q == 4 && pair_rule(out.size(), upd);
         if (hosted) pair[L] = two;
-        const double slow = two ? 1.7 : 1.0, chain = two ? 1.4 : CHAIN;
+        const double slow = two ? 1.7 : 1.0, chain = two ? CHAIN + 0.3 : CHAIN;
         HostSim sim(q == 1 || two ? HOST_SLOTS : HOST_SLOTS / 2);
         double target = 1e30;
         if (hosted) {

@@ -58,7 +58,11 @@ __device__ __forceinline__ void potf2_body(double* __restrict__ smem, const int 
         r = i * 16 + rr;
         c = tj * 16 + c2;
         d2 v = (d2){0.0, 0.0};
-        if (tj <= i) v = *reinterpret_cast<const d2*>(D + PL::tile(i, tj) + PL::in(rr, c2));
+        if (tj <= i) {
+            // (the tiles of the INVERSE are stored transposed: blocklds.hpp, Lay::XT)
+            if (factor_diag || !PL::XT) v = *reinterpret_cast<const d2*>(D + PL::tile(i, tj) + PL::in(rr, c2));
+            else v = (d2){D[PL::tile(i, tj) + PL::in(c2, rr)], D[PL::tile(i, tj) + PL::in(c2 + 1, rr)]};
+        }
         if (factor_diag && tj == i) {
             v[0] *= invd[c];
             v[1] *= invd[c + 1];
@@ -73,11 +77,17 @@ __device__ __forceinline__ void potf2_body(double* __restrict__ smem, const int 
         int64_t ld;
         const double* D;
         const double* invd;
-        // tile (t, p) from the solving wave's accumulator: four rows x 128 bytes per store instruction
+        // tile (t, p) from the solving wave's accumulator (blocklds.hpp: fi_frag order -- two column pairs of row lane & 15):
+        // a store instruction covers 16 rows x 64 bytes
         __device__ __forceinline__ void tile(int t, int p, d4 acc, int lane) const {
-            R* dst = Ablk + (int64_t)(16 * t + (lane >> 4)) * ld + 16 * p + (lane & 15);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) dst[(int64_t)(4 * g) * ld] = (R)acc[g];
+            R* dst = Ablk + (int64_t)(16 * t + (lane & 15)) * ld + 16 * p + 2 * (lane >> 4);
+            RV2 v;
+            v[0] = (R)acc[0];
+            v[1] = (R)acc[1];
+            *reinterpret_cast<RV2*>(dst) = v;
+            v[0] = (R)acc[2];
+            v[1] = (R)acc[3];
+            *reinterpret_cast<RV2*>(dst + 8) = v;
         }
         // tile (i, i-1), the diagonal tile (scaled, zeros above the diagonal) and the zero tiles right of it: one 16-byte
         // chunk per lane and tile (row lane >> 3 and row 8 + (lane >> 3), column pair lane & 7)
@@ -144,8 +154,8 @@ __device__ __forceinline__ void potf2_body(double* __restrict__ smem, const int 
             const int r = 16 * t + (l & 15), c = 8 * s2 + (l >> 4);     // c and c + 4 lie in the same 16-column tile
             const double* T = D + PL::tile(t, (s2 >> 1) <= t ? (s2 >> 1) : t);
             d2 v;
-            v[0] = (c <= r) ? T[PL::in(r & 15, c & 15)] : 0.0;
-            v[1] = (c + 4 <= r) ? T[PL::in(r & 15, (c + 4) & 15)] : 0.0;
+            v[0] = (c <= r) ? T[PL::XT ? PL::in(c & 15, r & 15) : PL::in(r & 15, c & 15)] : 0.0;
+            v[1] = (c + 4 <= r) ? T[PL::XT ? PL::in((c + 4) & 15, r & 15) : PL::in(r & 15, (c + 4) & 15)] : 0.0;
             *reinterpret_cast<d2*>(dB + 2 * e) = v;
         }
     }

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(NTH, 1) void fit_small_kernel(SmallFitArgs a) {
     __shared__ double xr[NB][4];          // raw coordinates (loaded once)
     __shared__ double xs[NB][5];          // scaled coordinates + squared norm
     __shared__ double yv[NB], zv[NB], al[NB], invd[NB];
-    __shared__ double Xs[32 * XS_LD];         // the two scratch tiles of lds_factor_inv
+    __shared__ __attribute__((aligned(16))) double Xs[32 * XS_LD];         // the two scratch tiles of lds_factor_inv
     __shared__ double red[NTH / 64][12];
     __shared__ ThetaDev sth;
     __shared__ double su[MAXP], sm_[MAXP], sv_[MAXP];

@@ -8,7 +8,7 @@
 __global__ __launch_bounds__(NTH, 1) void k(const double* A, double* Lout, double* Xout, int npan, long long* cyc) {
     __shared__ __attribute__((aligned(16))) double D[NB * LDD];
     __shared__ double invd[NB];
-    __shared__ double Xs[32 * XS_LD];
+    __shared__ __attribute__((aligned(16))) double Xs[32 * XS_LD];
     __shared__ int s_bad;
     const int tid = threadIdx.x;
     const int ns = npan * 16;
@@ -20,7 +20,7 @@ __global__ __launch_bounds__(NTH, 1) void k(const double* A, double* Lout, doubl
         double *Lout, *D, *invd;
         int ns;
         __device__ void tile(int t, int p, d4 acc, int lane) const {
-            for (int g = 0; g < 4; ++g) Lout[(16 * t + (lane >> 4) + 4 * g) * ns + 16 * p + (lane & 15)] = acc[g];
+            for (int g = 0; g < 4; ++g) Lout[(16 * t + (lane & 15)) * ns + 16 * p + 8 * (g >> 1) + 2 * (lane >> 4) + (g & 1)] = acc[g];
         }
         __device__ void row(int i, int lane) const {
             for (int e = lane; e < 16 * ns; e += 64) {
