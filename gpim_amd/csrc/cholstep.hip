@@ -273,7 +273,16 @@ static double wg_cost(int depth, int q) { return q == 4 ? 0.14 * depth + 0.24 : 
 //   * once fewer than 64 block columns remain a panel's updates are less than one round per launch and everything
 //     pending is flushed at once, evenly over the panel's launches.
 static void plan_updates(int nb, std::vector<std::vector<TileDesc>>& fill) {
-    const int W = STEP_W, S = HOST_SLOTS;
+    // chain-bound matrices of at least 16 block columns: panels of THREE (column updates <= 5 k-blocks deep: a hosted quadrant
+    // of depth 7 lasts 50 us, the factorisation role 28 since round 5 -- N = 4212 2.53 -> 2.47 ms per Adam iteration; the
+    // ten-block slices of config C3 in one lock-step batch of 64 are 1.4 % slower with it, hence the lower bound)
+#ifndef STEP_W_CHAIN
+#define STEP_W_CHAIN 3
+#endif
+#ifndef STEP_W_CHAIN_MIN
+#define STEP_W_CHAIN_MIN 16
+#endif
+    const int W = (nb >= STEP_W_CHAIN_MIN && nb < 64) ? STEP_W_CHAIN : STEP_W, S = HOST_SLOTS;
     const int npanel = (nb + W - 1) / W;
     auto by_depth = [](const TileDesc& a, const TileDesc& b) { return (a.kb1 - a.kb0) > (b.kb1 - b.kb0); };
     // left-looking column update of block column j inside a window of two outer panels: ONE tile operation per tile,
@@ -437,7 +446,7 @@ static void plan_inverse(int nb, std::vector<std::vector<TileDesc>>& fill, std::
     size_t open_nodes = 0;
     for (auto& n : nodes) open_nodes += (n.height > 0);
 #ifndef PLAN_CHAIN
-#define PLAN_CHAIN 1.1
+#define PLAN_CHAIN 0.9
 #endif
     const double CHAIN = PLAN_CHAIN;                   // length of the factorisation role in cost units
     for (int L = 0; open_nodes > 0; ++L) {
