@@ -1329,6 +1329,26 @@ int gpimhip_dist_finalize(gpimhip_handle h, const gpimhip_model_t* m, int64_t N,
     return launch_dist_finalize(h, m, N, S, quad, half_logdet, u, t > 0 ? 1 : 0, st, loss_out, grad_out, hist_row);
 }
 
+int gpimhip_dist_finalize_dev(gpimhip_handle h, const gpimhip_model_t* m, int64_t N, double* u, const double* red,
+                              const double* quad, double lr, int32_t t, double* loss_out, double* grad_out,
+                              double* hist_row) {
+    FP64_ONLY(h);
+    if (!h || !u || !red || !quad || N < 1 || t < 0 || !h->np) return GPIMHIP_E_BADARG;
+    GP_TRY(check_model(m));
+    HIP_TRY(hipSetDevice(h->device));
+    h->nbatch = 1;
+    GP_TRY(launch_theta(h, m, u));
+    AdamStep st;
+    st.beta1 = 0.9; st.beta2 = 0.999; st.eps = 1e-8;
+    st.lr_over_bc1 = t > 0 ? lr / (1.0 - pow(0.9, (double)t)) : 0.0;
+    st.bc2_sqrt = t > 0 ? sqrt(1.0 - pow(0.999, (double)t)) : 1.0;
+    if (t == 1) {
+        HIP_TRY(hipMemsetAsync(h->adam_m, 0, MAXP * sizeof(double), h->stream));
+        HIP_TRY(hipMemsetAsync(h->adam_v, 0, MAXP * sizeof(double), h->stream));
+    }
+    return launch_dist_finalize_dev(h, m, N, red, quad, u, t > 0 ? 1 : 0, st, loss_out, grad_out, hist_row);
+}
+
 int gpimhip_thin_batch(gpimhip_handle h, const double* vals, const int64_t* flat_idx, int32_t n, int32_t d,
                        const int64_t* shape, double dscale, int32_t max_out, int32_t* keep_out, int32_t* nkeep_out) {
     if (!h || !vals || !flat_idx || !shape || !keep_out || !nkeep_out || n < 1 || n > 1024 || d < 1 ||

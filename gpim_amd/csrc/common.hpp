@@ -218,6 +218,8 @@ int launch_dist_rows_acc(gpimhip_ctx* h, const double* A, int64_t ld, int64_t ro
 int launch_grad_reduce_tiles(gpimhip_ctx* h, const gpimhip_model_t* m, const double* Kinv, int64_t ld, const double* X,
                              int64_t N, int64_t np, const double* alpha, const TileDesc* tiles, int ntile, double* part);
 int launch_sum7(gpimhip_ctx* h, const double* part, int ntile, double* S);
+int launch_dist_finalize_dev(gpimhip_ctx* h, const gpimhip_model_t* m, int64_t N, const double* red, const double* quad,
+                             double* u, int do_adam, AdamStep st, double* loss_out, double* grad_out, double* hist_row);
 int launch_dist_finalize(gpimhip_ctx* h, const gpimhip_model_t* m, int64_t N, const double* S, double q2, double lg,
                          double* u, int do_adam, AdamStep st, double* loss_out, double* grad_out, double* hist_row);
 int launch_add_diag_theta(gpimhip_ctx* h, double* out, int64_t ld, int64_t row0, int64_t n, int64_t npad);

@@ -919,6 +919,30 @@ __global__ void dist_finalize_kernel(gpimhip_model_t m, int64_t N, const double*
     for (int k = 0; k < 8; ++k) Sl[k] = S[k];
     finalize_step(m, N, Sl, q2, lg, *th, u, adam_m, adam_v, do_adam, st, loss_out, grad_out, hist_row, prior_constant(m));
 }
+// ... with the scalars where the distributed driver leaves them -- device memory: red[0..7] = the all-reduced gradient
+// sums, red[8] = sum log L_ii, red[9] = how many ranks met a non-positive pivot (then nothing is touched but the loss,
+// which becomes NaN: the driver raises after its one read-back of the iteration); quad[0] = y^T alpha
+__global__ void dist_finalize_dev_kernel(gpimhip_model_t m, int64_t N, const double* __restrict__ red,
+                                         const double* __restrict__ quad, const ThetaDev* __restrict__ th,
+                                         double* __restrict__ u, double* __restrict__ adam_m, double* __restrict__ adam_v,
+                                         int do_adam, AdamStep st, double* __restrict__ loss_out,
+                                         double* __restrict__ grad_out, double* __restrict__ hist_row) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (red[9] != 0.0) {
+        if (loss_out) *loss_out = __builtin_nan("");
+        return;
+    }
+    double Sl[8];
+    for (int k = 0; k < 8; ++k) Sl[k] = red[k];
+    finalize_step(m, N, Sl, quad[0], red[8], *th, u, adam_m, adam_v, do_adam, st, loss_out, grad_out, hist_row, prior_constant(m));
+}
+int launch_dist_finalize_dev(gpimhip_ctx* h, const gpimhip_model_t* m, int64_t N, const double* red, const double* quad,
+                             double* u, int do_adam, AdamStep st, double* loss_out, double* grad_out, double* hist_row) {
+    hipLaunchKernelGGL(dist_finalize_dev_kernel, dim3(1), dim3(64), 0, h->stream, *m, N, red, quad, h->theta, u, h->adam_m,
+                       h->adam_v, do_adam, st, loss_out, grad_out, hist_row);
+    HIP_TRY(hipGetLastError());
+    return GPIMHIP_OK;
+}
 int launch_dist_finalize(gpimhip_ctx* h, const gpimhip_model_t* m, int64_t N, const double* S, double q2, double lg,
                          double* u, int do_adam, AdamStep st, double* loss_out, double* grad_out, double* hist_row) {
     hipLaunchKernelGGL(dist_finalize_kernel, dim3(1), dim3(64), 0, h->stream, *m, N, S, q2, lg, h->theta, u, h->adam_m,

@@ -108,6 +108,7 @@ class HipTileEngine:
         self.info = torch.zeros((4,), dtype=torch.int32, device=self.device)
         self.logdet = torch.zeros((layout.npanel, PANEL), dtype=torch.float64, device=self.device)
         self._ev = torch.cuda.Event()
+        self._own = None
 
     def empty(self, rows, cols):
         return torch.zeros((rows, cols), dtype=torch.float64, device=self.device)
@@ -184,9 +185,10 @@ class HipTileEngine:
     def half_logdet_owned(self):
         """sum of log L_ii over the owned panels (the factorisation role's per-block partial sums; padding rows are
         identity: log 1 = 0) as a 1-element device tensor"""
-        own = torch.tensor(self.layout.owned, dtype=torch.long, device=self.device)
-        return self.logdet[own].sum().reshape(1) if len(self.layout.owned) else torch.zeros((1,), dtype=torch.float64,
-                                                                                           device=self.device)
+        if self._own is None:
+            self._own = torch.tensor(self.layout.owned, dtype=torch.long, device=self.device)
+        return self.logdet[self._own].sum().reshape(1) if len(self.layout.owned) else torch.zeros((1,), dtype=torch.float64,
+                                                                                                 device=self.device)
 
     def failed_column(self):
         return int(self.info[0].item())
@@ -204,6 +206,7 @@ class DistributedCholesky:
         self.local = self.engine.empty(self.layout.np, self.layout.local_cols)
         # broadcast buffers: the panel's rows + 128 rows of diagonal-block inverses
         self._panel = [self.engine.empty(self.layout.np + NB, PW) for _ in range(2)]
+        self._X = self._Wt = None                      # workspaces of ``inverse``
 
     # ------------------------------------------------------------------ filling the local share
     def set_from_function(self, cols_fn):
@@ -229,9 +232,18 @@ class DistributedCholesky:
                 eng.panel_factor(self.local, p)
                 eng.pack(self.local, p, buf)
                 if L.world > 1:
-                    return dist.broadcast(buf, src=L.rank, group=self.group, async_op=True)
+                    return dist.broadcast(self._wire(buf, p), src=L.rank, group=self.group, async_op=True)
             return self._side_done()
-        return dist.broadcast(buf, src=L.owner(p), group=self.group, async_op=True)
+        return dist.broadcast(self._wire(buf, p), src=L.owner(p), group=self.group, async_op=True)
+
+    @staticmethod
+    def _wire(buf, p):
+        """What travels for panel p: rows p * 512 ... of the buffer (contiguous: the panel's rows from its diagonal block
+        down, then the 128 rows of diagonal-block inverses).  The rows above are structural zeros of L and of X = L^-1
+        alike and no consumer reads them (gpimhip_dist_update: tiles right of the panel; gpimhip_dist_solve_update: block
+        rows >= 4 p; gpimhip_dist_kinv_update: k-blocks >= the tile's row) -- on a receiver they hold whatever an earlier
+        panel left there.  Halves the volume: sum_p (np - 512 p + 128) * 512 doubles = N^2 / 2 + ... instead of N^2."""
+        return buf[p * PW:]
 
     def _side(self):
         eng = self.engine
@@ -241,7 +253,8 @@ class DistributedCholesky:
         eng = self.engine
         return eng.side_done() if hasattr(eng, "side_done") else _Ready()
 
-    def factor(self):
+    def factor(self, check=True):
+        """check=False: no host synchronisation -- the caller reads the failure flag itself (``failed_flag``)."""
         L, eng = self.layout, self.engine
         work = self._factor_and_send(0)
         for p in range(L.npanel):
@@ -258,6 +271,8 @@ class DistributedCholesky:
                 work = self._factor_and_send(nxt)
             if rest < L.npanel:
                 eng.update(buf, p, self.local, rest, L.npanel)
+        if not check:
+            return self
         bad = torch.tensor([eng.failed_column()], dtype=torch.int64)
         if L.world > 1:
             bad = bad.to(self.local.device if self.local.is_cuda else "cpu")
@@ -350,9 +365,9 @@ class DistributedCholesky:
             with self._side():
                 fill(buf)
                 if L.world > 1:
-                    return dist.broadcast(buf, src=L.rank, group=self.group, async_op=True)
+                    return dist.broadcast(self._wire(buf, p), src=L.rank, group=self.group, async_op=True)
             return self._side_done()
-        return dist.broadcast(buf, src=L.owner(p), group=self.group, async_op=True)
+        return dist.broadcast(self._wire(buf, p), src=L.owner(p), group=self.group, async_op=True)
 
     def _stream(self, fill_of):
         """Yields (p, buffer) for every panel in order; the broadcast of panel p + 1 is in flight while the caller
@@ -373,30 +388,40 @@ class DistributedCholesky:
         """X = L^-1, distributed like L: this rank's block columns (np x 512 * owned panels), lower triangular.
         The factor is streamed through the ranks once more and every rank forward-substitutes the identity
         columns it owns (gpimhip_dist_solve_update; block columns right of the current panel are still zero and
-        are skipped, so the work is that of a triangular inversion, N^3 / 3 flop over all ranks)."""
+        are skipped, so the work is that of a triangular inversion, N^3 / 3 flop over all ranks).
+        In place: block row p of the right-hand sides is dead once step p has turned it into block row p of X, which
+        takes its place (through the 512-row staging buffer the engine writes).  The matrix is a persistent workspace
+        of this object, re-seeded with the identity on every call -- the returned tensor is valid until the next call."""
         L, eng = self.layout, self.engine
-        Bw = eng.empty(L.np, L.local_cols)
+        if self._X is None:
+            self._X = eng.empty(L.np, L.local_cols)
+            self._Wt = eng.empty(PW, L.local_cols)
+        else:
+            self._X.zero_()
+        X, Wt = self._X, self._Wt
         for p in L.owned:
-            idx = torch.arange(L.width(p), device=Bw.device)
-            Bw[p * PW + idx, L.local_col0(p) + idx] = 1.0
-        Xl = eng.empty(L.np, L.local_cols)
+            idx = torch.arange(L.width(p), device=X.device)
+            X[p * PW + idx, L.local_col0(p) + idx] = 1.0
         for p, buf in self._stream_factor():
             nown = sum(1 for c in L.owned if c <= p)
             if nown:
-                eng.solve_update(buf, p, Bw, Xl[p * PW:], None, nown * PANEL)
-        return Xl
+                eng.solve_update(buf, p, X, Wt, None, nown * PANEL)
+                w = L.width(p)
+                X[p * PW:p * PW + w, :nown * PW].copy_(Wt[:w, :nown * PW])
+        return X
 
-    def kinv(self, Xl):
+    def kinv(self, Xl, out=None):
         """K^-1 = X^T X (lower tiles) for the owned block columns, np x 512 * owned panels: every owner broadcasts
         its block columns of X in turn (the next one in flight while the current one is consumed) and each rank forms
-        the rows of that panel against its own columns on the MFMA tile engine (gpimhip_dist_kinv_update)."""
+        the rows of that panel against its own columns on the MFMA tile engine (gpimhip_dist_kinv_update).
+        out: where to (default: a new matrix); the training loop passes ``self.local`` -- the factor is dead by then."""
         L, eng = self.layout, self.engine
-        Kl = eng.empty(L.np, L.local_cols)
+        Kl = out if out is not None else eng.empty(L.np, L.local_cols)
 
         def fill_of(c):
             def fill(buf):
-                l0 = L.local_col0(c)
-                buf[:L.np, :L.width(c)].copy_(Xl[:, l0:l0 + L.width(c)])
+                l0, r0 = L.local_col0(c), c * PW
+                buf[r0:L.np, :L.width(c)].copy_(Xl[r0:, l0:l0 + L.width(c)])
             return fill
         for c, buf in self._stream(fill_of):
             eng.kinv_update(buf, c, Xl, Kl)
@@ -537,32 +562,48 @@ def exact_gp_fit(X, y, kernel="RBF", lengthscale=None, learning_rate=5e-2, itera
     T = int(iterations)
     hist = torch.zeros((max(T, 1), P), dtype=torch.float64, device=dev)
     loss = torch.zeros((max(T, 1),), dtype=torch.float64, device=dev)
-    S = torch.zeros((8,), dtype=torch.float64, device=dev)
+    # red[0..7]: the gradient sums, red[8]: this rank's sum log L_ii, red[9]: 1 if this rank met a non-positive pivot --
+    # ONE all-reduce per iteration; quad = y^T alpha is replicated arithmetic.  Nothing is read back inside an iteration:
+    # the loss and the failure count of iteration t reach the host through one pinned copy, awaited after iteration
+    # t has been enqueued (three .item() synchronisations per iteration until round 4).
+    red = torch.zeros((10,), dtype=torch.float64, device=dev)
+    quad = torch.zeros((1,), dtype=torch.float64, device=dev)
     alpha_pad = torch.zeros((L.np,), dtype=torch.float64, device=dev)
+    back = torch.zeros((2,), dtype=torch.float64).pin_memory() if dev.type == "cuda" else torch.zeros((2,), dtype=torch.float64)
     ld = chol.local.stride(0)
+    eng = chol.engine
     for t in range(1, T + 1):
         for p in L.owned:
             l0 = L.local_col0(p)
             _lib.check(lib.gpimhip_dist_kmat_cols(H.h, ctypes.byref(m), _lib.ptr(Xd), N, _lib.ptr(u), p * PW, L.width(p),
                                                   ctypes.c_void_p(chol.local.data_ptr() + 8 * l0), ld))
-        chol.factor()
-        half_logdet = 0.5 * chol.logdet()
+        chol.factor(check=False)
         alpha = chol.solve(yd)
-        quad = float((yd * alpha).sum().item())
+        torch.sum(yd * alpha, dim=0, keepdim=True, out=quad)
         alpha_pad[:N] = alpha
         Xl = chol.inverse()
-        Kl = chol.kinv(Xl)
-        del Xl
+        Kl = chol.kinv(Xl, out=chol.local)                    # (the factor is dead: K^-1 takes its place)
         _lib.check(lib.gpimhip_dist_grad_sums(H.h, ctypes.byref(m), _lib.ptr(Xd), N, _lib.ptr(u), _lib.ptr(Kl),
-                                              Kl.stride(0), _lib.ptr(alpha_pad), _lib.ptr(S)))
-        del Kl
+                                              Kl.stride(0), _lib.ptr(alpha_pad), _lib.ptr(red)))
+        red[8:9].copy_(eng.half_logdet_owned())
+        red[9:10].copy_((eng.info[0:1] != 0).to(torch.float64))
         if world > 1:
-            dist.all_reduce(S, group=group)
-        _lib.check(lib.gpimhip_dist_finalize(H.h, ctypes.byref(m), N, _lib.ptr(u), _lib.ptr(S), quad, half_logdet,
-                                             float(learning_rate), t, ctypes.c_void_p(loss[t - 1:].data_ptr()), None,
-                                             ctypes.c_void_p(hist[t - 1].data_ptr())))
+            dist.all_reduce(red, group=group)
+        _lib.check(lib.gpimhip_dist_finalize_dev(H.h, ctypes.byref(m), N, _lib.ptr(u), _lib.ptr(red), _lib.ptr(quad),
+                                                 float(learning_rate), t, ctypes.c_void_p(loss[t - 1:].data_ptr()), None,
+                                                 ctypes.c_void_p(hist[t - 1].data_ptr())))
+        back[0:1].copy_(red[9:10], non_blocking=True)
+        back[1:2].copy_(loss[t - 1:t], non_blocking=True)
+        if dev.type == "cuda":
+            torch.cuda.current_stream(dev).synchronize()
+        if back[0].item() != 0:
+            bad = torch.tensor([eng.failed_column()], dtype=torch.int64, device=dev)
+            if world > 1:
+                dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=group)
+            raise torch.linalg.LinAlgError("linalg.cholesky: the input is not positive-definite "
+                                           "(leading minor of order %d)" % int(bad.item()))
         if verbose and rank == 0 and (t == 1 or t % 10 == 0 or t == T):
-            print("iter: {} ... loss: {:.4f}".format(t - 1, float(loss[t - 1].item())))
+            print("iter: {} ... loss: {:.4f}".format(t - 1, float(back[1].item())))
     hcpu = hist[:T].cpu().numpy()
     hyper = {"variance": hcpu[:, 0], "lengthscale": hcpu[:, 1:1 + spec.n_ls], "noise": hcpu[:, 1 + spec.n_ls],
              "loss": loss[:T].cpu().numpy()}

@@ -303,7 +303,12 @@ int gpimhip_dist_solve_update(gpimhip_handle h, const double* buf, int64_t ldbuf
  *   gpimhip_dist_finalize     loss (given quad = y^T alpha and half_logdet = sum log L_ii), d loss / du, and -- for
  *                             t >= 1, the 1-based Adam iteration -- torch.optim.Adam's step on u (state in the handle,
  *                             reset at t = 1) and the constrained values of the stepped u in hist_row; t = 0:
- *                             loss and gradient only.  Identical inputs on every rank -> identical u. */
+ *                             loss and gradient only.  Identical inputs on every rank -> identical u.
+ *   gpimhip_dist_finalize_dev the same with the scalars read from DEVICE memory, so that the training loop of
+ *                             gpim_amd.dist_chol.exact_gp_fit enqueues an iteration without reading anything back:
+ *                             red[0..7] = the all-reduced sums, red[8] = sum log L_ii over all ranks, red[9] = number of
+ *                             ranks whose factorisation met a non-positive pivot (if not 0: *loss_out = NaN, nothing else
+ *                             is written), quad[0] = y^T alpha. */
 int gpimhip_dist_kmat_cols(gpimhip_handle h, const gpimhip_model_t* m, const double* X, int64_t N, const double* u,
                            int64_t col0, int64_t ncols_pad, double* out, int64_t ld);
 /* The O(N^2) vector solves of alpha = K^-1 y of the distributed model (torch.linalg.solve_triangular over the whole
@@ -326,6 +331,9 @@ int gpimhip_dist_grad_sums(gpimhip_handle h, const gpimhip_model_t* m, const dou
 int gpimhip_dist_finalize(gpimhip_handle h, const gpimhip_model_t* m, int64_t N, double* u, const double* S,
                           double quad, double half_logdet, double lr, int32_t t, double* loss_out, double* grad_out,
                           double* hist_row);
+int gpimhip_dist_finalize_dev(gpimhip_handle h, const gpimhip_model_t* m, int64_t N, double* u, const double* red,
+                              const double* quad, double lr, int32_t t, double* loss_out, double* grad_out,
+                              double* hist_row);
 
 /* Batch thinning of boptimizer.update_points (gpim/gpbayes/boptim.py:326-376): among n <= 1024 ranked
  * candidates (vals, flat grid indices into a d-dimensional grid of the given shape) repeatedly keep the

@@ -155,7 +155,8 @@ class NumpyTileEngine:
         from gpim_amd.dist_chol import PW
         L = self.layout
         w, r0 = L.width(c), c * PW
-        full = xbuf[:L.np, :w].T @ Xloc                         # rows of panel c of X^T X against the owned columns
+        # rows of panel c of X^T X against the owned columns (X is zero above its diagonal blocks: only rows >= r0 travel)
+        full = xbuf[r0:L.np, :w].T @ Xloc[r0:]
         for p in L.owned:
             if p <= c:                                          # block columns left of / at the panel: tiles i >= j
                 l0 = L.local_col0(p)
@@ -206,6 +207,8 @@ def _chol_worker(rank, world, port, ret):
         A = torch.from_numpy(B @ B.T + n * np.eye(n))
         y = torch.from_numpy(rng.standard_normal(n))
         ch = DistributedCholesky(n, engine_factory=NumpyTileEngine)
+        for b in ch._panel:
+            b.fill_(float("nan"))        # a consumer that read rows which no broadcast delivers would spread NaNs
         lay = ch.layout
         assert lay.owned == [p for p in range(lay.npanel) if p % world == rank]
         assert ch.local.shape == (lay.np, max(1, len(lay.owned)) * 512)
