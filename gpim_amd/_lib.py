@@ -87,6 +87,9 @@ _PROTOS = {
     "gpimhip_dist_solve_update": (ctypes.c_int, [ctypes.c_void_p, c_dp, ctypes.c_int64, ctypes.c_int32, c_dp,
                                                  ctypes.c_int64, ctypes.c_int64, c_dp, ctypes.c_int64, c_dp,
                                                  ctypes.c_int32]),
+    "gpimhip_dist_solve_update2": (ctypes.c_int, [ctypes.c_void_p, c_dp, ctypes.c_int64, ctypes.c_int32, c_dp,
+                                                  ctypes.c_int64, ctypes.c_int64, c_dp, ctypes.c_int64, c_dp,
+                                                  ctypes.c_int32, ctypes.c_int32]),
     "gpimhip_dist_kmat_cols": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ModelStruct), c_dp, ctypes.c_int64, c_dp,
                                               ctypes.c_int64, ctypes.c_int64, c_dp, ctypes.c_int64]),
     "gpimhip_dist_kinv_update": (ctypes.c_int, [ctypes.c_void_p, c_dp, ctypes.c_int64, ctypes.c_int32, c_dp,
@@ -217,8 +220,9 @@ class Handle:
 
 
 def ptr(t):
-    """Device address of a contiguous CUDA tensor (or None)."""
+    """Device address of a CUDA tensor (or None): contiguous, or a row-major matrix with padded rows (unit column stride;
+    the callee gets the row stride as its leading dimension)."""
     if t is None:
         return None
-    assert t.is_cuda and t.is_contiguous()
+    assert t.is_cuda and (t.is_contiguous() or (t.dim() == 2 and t.stride(1) == 1))
     return ctypes.c_void_p(t.data_ptr())

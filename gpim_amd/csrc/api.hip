@@ -1064,9 +1064,14 @@ int gpimhip_dist_setup(gpimhip_handle h, int64_t n, int32_t world, int32_t rank)
     D.kinv_panel.assign(npanel, {0, 0});
     for (int c = 0; c < npanel; ++c) {
         size_t s0 = tl.size();
-        for (int ci = c * OUTER_W; ci < std::min(c * OUTER_W + OUTER_W, nb); ++ci)
-            for (size_t q = 0; q < gblk.size(); ++q)
-                if (gblk[q] <= ci) tl.push_back({ci, local_of((int)q), ci, nb});
+        // 64 consecutive tiles = the panel's four block rows x 16 owned columns: dealt to the XCDs in chunks of 64
+        // (gpimhip_dist_kinv_update) a patch streams 4 + 16 operand panels for 64 tiles (row by row it was 1 + 64, and the
+        // pass ran at 56 TFLOP/s at N = 65536)
+        const int ci1 = std::min(c * OUTER_W + OUTER_W, nb);
+        for (size_t q0 = 0; q0 < gblk.size(); q0 += 16)
+            for (int ci = c * OUTER_W; ci < ci1; ++ci)
+                for (size_t q = q0; q < std::min(gblk.size(), q0 + 16); ++q)
+                    if (gblk[q] <= ci) tl.push_back({ci, local_of((int)q), ci, nb});
         D.kinv_panel[c] = mark(s0);
     }
     {
@@ -1213,19 +1218,15 @@ static int dist_rect_ensure(gpimhip_ctx* h, int cols) {
 //                  B[4p+b+1 .. 4p+3] -= L[., 4p+b] W_b                       (rows inside the panel)
 //   B[4p+4 ..] -= L[., panel p] Wt                                           (k-depth 512)
 //   q[j] += sum over the panel's rows of W[r][j]^2
-int gpimhip_dist_solve_update(gpimhip_handle h, const double* buf, int64_t ldbuf, int32_t panel_glob_blk0, double* Bm,
-                              int64_t ldb, int64_t mpad, double* Wt, int64_t ldw, double* q, int32_t col_tiles) {
-    FP64_ONLY(h);
-    if (!h || !buf || !Bm || !Wt || !dist_plan_ok(h) || panel_glob_blk0 < 0 || panel_glob_blk0 % OUTER_W ||
-        mpad < NB || mpad % NB || ldb < mpad || ldw < mpad)
-        return GPIMHIP_E_BADARG;
-    HIP_TRY(hipSetDevice(h->device));
+// The last line rewrites the rank's whole share of B below the panel once per panel: at N = 65536 the streamed inverse
+// moved 4.4 TB that way and ran at 39 TFLOP/s.  Panels therefore go in PAIRS where the caller can hold two of them
+// (gpimhip_dist_solve_update2): the first panel of a pair updates only the block rows of the second, and after the second
+// panel's own solves ONE update of k-depth 1024 -- both panels side by side in a buffer of 1024 columns, both W's
+// one below the other -- brings the rest of B up to date: half the passes over B.
+static int dist_solve_panel(gpimhip_ctx* h, const double* buf, int64_t ldbuf, int g0, double* Bm, int64_t ldb, int cols,
+                            double* Wt, int64_t ldw, int32_t col_tiles) {
     const DistPlan& D = h->dplan;
-    const int nb = D.nb, g0 = panel_glob_blk0;
-    if (g0 >= nb) return GPIMHIP_E_BADARG;
-    h->nbatch = 1;
-    const int cols = (int)(mpad / NB), nblk = std::min(OUTER_W, nb - g0);
-    GP_TRY(dist_rect_ensure(h, cols));
+    const int nb = D.nb, nblk = std::min(OUTER_W, nb - g0);
     const double* dinv = buf + h->np * ldbuf;               // 128 x (128 nblk): the panel's diagonal-block inverses
     const double* Ps = buf - (int64_t)g0 * NB;              // global k-block index -> buffer column
     for (int b = 0; b < nblk; ++b) {
@@ -1246,16 +1247,76 @@ int gpimhip_dist_solve_update(gpimhip_handle h, const double* buf, int64_t ldbuf
             GP_TRY(launch_gemm(h, false, true, EPI_STORE, u));
         }
     }
-    const int rows_below = nb - g0 - nblk;
-    if (rows_below > 0) {
-        GemmArgs u = gemm_args(Ps, ldbuf, Wt, ldw, Bm, ldb, -1.0, 1.0, D.d_rect, rows_below * cols, h->np);
-        u.a_roff = g0 + nblk; u.a_coff = g0; u.c_roff = g0 + nblk;
-        u.kfix0 = 0; u.kfix1 = nblk;
-        u.chunk = deal_chunk(u.ntiles);
-        u.cj_max = col_tiles;
-        GP_TRY(launch_gemm(h, false, true, EPI_STORE, u));
-    }
+    return GPIMHIP_OK;
+}
+// B[row0 .. row0 + nrows) -= L[., kb0 .. kb0 + kblk) * Wt  (block indices; abase: the buffer whose column 0 is block column kb0)
+static int dist_solve_below(gpimhip_ctx* h, const double* abase, int64_t ldbuf, int kb0, int kblk, int row0, int nrows,
+                            double* Bm, int64_t ldb, int cols, const double* Wt, int64_t ldw, int32_t col_tiles) {
+    if (nrows <= 0) return GPIMHIP_OK;
+    const DistPlan& D = h->dplan;
+    const double* Ps = abase - (int64_t)kb0 * NB;
+    // only the column tiles that are not structurally zero, in 8 x 8 patches, one patch per XCD at a time (until round 5:
+    // the row-major list over ALL column tiles with the zero ones leaving at once -- three workgroups in four at the
+    // middle of an inverse -- and a row of 100-500 tiles between two uses of a W panel: 37 TFLOP/s per launch)
+    const int ncol = col_tiles > 0 ? std::min<int>(col_tiles, cols) : cols;
+    GemmArgs u = gemm_args(Ps, ldbuf, Wt, ldw, Bm, ldb, -1.0, 1.0, D.d_rect, nrows * ncol, h->np);
+    u.a_roff = row0; u.a_coff = kb0; u.c_roff = row0;
+    u.kfix0 = 0; u.kfix1 = kblk;
+    u.rect_rows = nrows; u.rect_cols = ncol;
+    u.chunk = 64;
+    return launch_gemm(h, false, true, EPI_STORE, u);
+}
+static int dist_solve_check(gpimhip_ctx* h, const double* buf, int32_t g0, const double* Bm, int64_t ldb, int64_t mpad,
+                            const double* Wt, int64_t ldw) {
+    if (!h || !buf || !Bm || !Wt || !dist_plan_ok(h) || g0 < 0 || g0 % OUTER_W || mpad < NB || mpad % NB || ldb < mpad ||
+        ldw < mpad || g0 >= h->dplan.nb)
+        return GPIMHIP_E_BADARG;
+    return GPIMHIP_OK;
+}
+int gpimhip_dist_solve_update(gpimhip_handle h, const double* buf, int64_t ldbuf, int32_t panel_glob_blk0, double* Bm,
+                              int64_t ldb, int64_t mpad, double* Wt, int64_t ldw, double* q, int32_t col_tiles) {
+    FP64_ONLY(h);
+    GP_TRY(dist_solve_check(h, buf, panel_glob_blk0, Bm, ldb, mpad, Wt, ldw));
+    HIP_TRY(hipSetDevice(h->device));
+    const DistPlan& D = h->dplan;
+    const int nb = D.nb, g0 = panel_glob_blk0;
+    h->nbatch = 1;
+    const int cols = (int)(mpad / NB), nblk = std::min(OUTER_W, nb - g0);
+    GP_TRY(dist_rect_ensure(h, cols));
+    GP_TRY(dist_solve_panel(h, buf, ldbuf, g0, Bm, ldb, cols, Wt, ldw, col_tiles));
+    GP_TRY(dist_solve_below(h, buf, ldbuf, g0, nblk, g0 + nblk, nb - g0 - nblk, Bm, ldb, cols, Wt, ldw, col_tiles));
     if (q) GP_TRY(launch_colsumsq_acc(h, Wt, ldw, nblk * NB, mpad, q));
+    return GPIMHIP_OK;
+}
+// The same step for the panels of a PAIR held side by side: `wide` is a buffer of 1024 columns (leading dimension ldbuf
+// >= 1024) with the pair's first panel in columns [0, 512) and the second in [512, 1024), both packed like the
+// single-panel buffer (np rows + 128 rows of diagonal-block inverses); Wt2 holds 1024 rows.
+//   second = 0: the pair's first panel (global block panel_glob_blk0): its own solves, W -> rows [0, 512) of Wt2, and the
+//               update of the NEXT panel's block rows only;
+//   second = 1: the pair's second panel (panel_glob_blk0 = the first panel's + 4): its own solves, W -> rows [512, 1024),
+//               then every block row below it receives both panels at once (k-depth 1024).
+int gpimhip_dist_solve_update2(gpimhip_handle h, const double* wide, int64_t ldbuf, int32_t panel_glob_blk0, double* Bm,
+                               int64_t ldb, int64_t mpad, double* Wt2, int64_t ldw, double* q, int32_t col_tiles,
+                               int32_t second) {
+    FP64_ONLY(h);
+    GP_TRY(dist_solve_check(h, wide, panel_glob_blk0, Bm, ldb, mpad, Wt2, ldw));
+    if (ldbuf < 2 * OUTER_W * NB || (second && panel_glob_blk0 < OUTER_W)) return GPIMHIP_E_BADARG;
+    HIP_TRY(hipSetDevice(h->device));
+    const DistPlan& D = h->dplan;
+    const int nb = D.nb, g0 = panel_glob_blk0;
+    h->nbatch = 1;
+    const int cols = (int)(mpad / NB), nblk = std::min(OUTER_W, nb - g0);
+    GP_TRY(dist_rect_ensure(h, cols));
+    const double* half = wide + (second ? OUTER_W * NB : 0);
+    double* Wh = Wt2 + (second ? (int64_t)OUTER_W * NB * ldw : 0);
+    GP_TRY(dist_solve_panel(h, half, ldbuf, g0, Bm, ldb, cols, Wh, ldw, col_tiles));
+    if (!second)
+        GP_TRY(dist_solve_below(h, half, ldbuf, g0, nblk, g0 + nblk, std::min(OUTER_W, nb - g0 - nblk), Bm, ldb, cols, Wh, ldw,
+                                col_tiles));
+    else
+        GP_TRY(dist_solve_below(h, wide, ldbuf, g0 - OUTER_W, OUTER_W + nblk, g0 + nblk, nb - g0 - nblk, Bm, ldb, cols, Wt2,
+                                ldw, col_tiles));
+    if (q) GP_TRY(launch_colsumsq_acc(h, Wh, ldw, nblk * NB, mpad, q));
     return GPIMHIP_OK;
 }
 
@@ -1291,7 +1352,7 @@ int gpimhip_dist_kinv_update(gpimhip_handle h, const double* xbuf, int64_t ldx, 
     GemmArgs g = gemm_args(xbuf, ldx, Xloc, ldloc, Kinv, ldk, 1.0, 0.0, D.d_tiles + r.off, r.n, h->np);
     g.a_coff = -panel_glob_blk0;
     g.krev = 1;
-    g.chunk = deal_chunk(g.ntiles);
+    g.chunk = 64;
     return launch_gemm(h, true, true, EPI_STORE, g);
 }
 

@@ -252,6 +252,10 @@ struct GemmArgs {
                                            // zero and skipped (exact GP with (N - 1) % 128 < 64: rag_of())
     int krev;                              // walk each tile's k-range from its end (ranges sharing their upper end)
     int kfix0, kfix1;                      // when kfix1 > kfix0: every tile uses this k-block range (its own is ignored)
+    int rect_rows, rect_cols;              // rect_cols > 0: no list -- the launch covers the rect_rows x rect_cols tiles of a
+                                           // rectangle (ntiles = their product) in strips of eight rows, column by column
+                                           // inside a strip: 64 consecutive tiles are an 8 x 8 patch (with chunk = 64 one
+                                           // patch per XCD at a time: 8 + 8 operand panels for 64 tiles); needs kfix0 / kfix1
     double* colpart; int64_t ld_colpart;   // EPI_COLSUMSQ: colpart[ci*ld + cj*128 + col]
     int64_t sA, sB, sC, sColpart;          // per-problem (blockIdx.y) strides in elements
 };

@@ -160,8 +160,18 @@ template <bool A_KM, bool B_KM, int EPI, int NW, int TSM, int TSN, int NSTG = 2>
 __device__ __forceinline__ void gemm_tile_body(GemmArgs g, const int bx, const int by, double* __restrict__ smem) {
     int quad;
     const int p = gemm_tile_pos<TSM, TSN>(g.ntiles, g.chunk, bx, quad);
-    if (g.rag) gemm_tile_core<A_KM, B_KM, EPI, NW, TSM, TSN, NSTG, true>(g, g.tiles[p], quad, by, smem);
-    else gemm_tile_core<A_KM, B_KM, EPI, NW, TSM, TSN, NSTG, false>(g, g.tiles[p], quad, by, smem);
+    TileDesc t;
+    if (g.rect_cols > 0) {
+        const int per = 8 * g.rect_cols, s = p / per, q = p - s * per, rows_here = min(8, g.rect_rows - 8 * s);
+        t.ci = 8 * s + q % rows_here;
+        t.cj = q / rows_here;
+        t.kb0 = g.kfix0;
+        t.kb1 = g.kfix1;
+    } else {
+        t = g.tiles[p];
+    }
+    if (g.rag) gemm_tile_core<A_KM, B_KM, EPI, NW, TSM, TSN, NSTG, true>(g, t, quad, by, smem);
+    else gemm_tile_core<A_KM, B_KM, EPI, NW, TSM, TSN, NSTG, false>(g, t, quad, by, smem);
 }
 
 // one tile (or its quadrant / half `quad`) of a tile-engine launch

@@ -158,6 +158,12 @@ class HipTileEngine:
                                                       self._lib.ptr(B), B.stride(0), B.shape[1], self._lib.ptr(Wt),
                                                       Wt.stride(0), self._lib.ptr(q), col_tiles))
 
+    def solve_update2(self, wide, p, B, Wt2, q, col_tiles, second):
+        lib = self.H.lib
+        self._lib.check(lib.gpimhip_dist_solve_update2(self.H.h, self._lib.ptr(wide), wide.stride(0), p * PANEL,
+                                                       self._lib.ptr(B), B.stride(0), B.shape[1], self._lib.ptr(Wt2),
+                                                       Wt2.stride(0), self._lib.ptr(q), col_tiles, int(second)))
+
     def kinv_update(self, xbuf, c, Xloc, Kinv):
         lib = self.H.lib
         self._lib.check(lib.gpimhip_dist_kinv_update(self.H.h, self._lib.ptr(xbuf), xbuf.stride(0), c * PANEL,
@@ -203,10 +209,18 @@ class DistributedCholesky:
         self.layout = Layout(n, rank, world)
         self.engine = engine_factory(self.layout)
         self.group = group
-        self.local = self.engine.empty(self.layout.np, self.layout.local_cols)
+        self.local = self._matrix(self.layout.np, self.layout.local_cols)
         # broadcast buffers: the panel's rows + 128 rows of diagonal-block inverses
         self._panel = [self.engine.empty(self.layout.np + NB, PW) for _ in range(2)]
         self._X = self._Wt = None                      # workspaces of ``inverse``
+        self._wide = None                              # two panels side by side (``_stream_pairs``), two such buffers
+
+    def _matrix(self, rows, cols):
+        """A rows x cols workspace matrix whose leading dimension is NOT a large power of two: with 512 * owned-panels
+        columns (65536 at N = 65536 on one GPU) the k-rows of an operand tile are 512 KB apart and land in few HBM
+        channels; 256 extra columns spread them."""
+        pad = 256 if cols % 2048 == 0 else 0
+        return self.engine.empty(rows, cols + pad)[:, :cols]
 
     # ------------------------------------------------------------------ filling the local share
     def set_from_function(self, cols_fn):
@@ -348,11 +362,11 @@ class DistributedCholesky:
             Bp = eng.empty(L.np, mpad)
             Bp[:, :m] = B
             B = Bp
-        Wt = eng.empty(PW, mpad)
+        Wt2 = eng.empty(2 * PW, mpad)
         q = torch.zeros((mpad,), dtype=torch.float64, device=B.device)
-        for p, buf in self._stream_factor():
+        for p, wide, second in self._stream_factor_pairs():
             if m:
-                eng.solve_update(buf, p, B, Wt, q)
+                eng.solve_update2(wide, p, B, Wt2, q, 0, second)
         return q[:m]
 
     def _start_panel(self, p, fill):
@@ -384,6 +398,22 @@ class DistributedCholesky:
         """The factored panels once more (packed with the inverses of their diagonal blocks)."""
         return self._stream(lambda p: (lambda buf: self.engine.pack(self.local, p, buf)))
 
+    def _stream_pairs(self, fill_of):
+        """Yields (p, wide, second): the panels in order, each copied from its (contiguous) broadcast buffer into one half
+        of a buffer of 1024 columns -- panel 2q in columns [0, 512) and panel 2q + 1 in [512, 1024) of buffer q & 1 -- so
+        that a consumer can apply both panels of a pair in one pass of k-depth 1024 (engine.solve_update2).  The copy is
+        268 MB at N = 65536, a tenth of a millisecond per panel."""
+        L = self.layout
+        if self._wide is None:
+            self._wide = [self.engine.empty(L.np + NB, 2 * PW) for _ in range(2)]
+        for p, buf in self._stream(fill_of):
+            wide, second = self._wide[(p // 2) & 1], p & 1
+            wide[p * PW:, second * PW:(second + 1) * PW].copy_(buf[p * PW:])
+            yield p, wide, second
+
+    def _stream_factor_pairs(self):
+        return self._stream_pairs(lambda p: (lambda buf: self.engine.pack(self.local, p, buf)))
+
     def inverse(self):
         """X = L^-1, distributed like L: this rank's block columns (np x 512 * owned panels), lower triangular.
         The factor is streamed through the ranks once more and every rank forward-substitutes the identity
@@ -394,20 +424,26 @@ class DistributedCholesky:
         of this object, re-seeded with the identity on every call -- the returned tensor is valid until the next call."""
         L, eng = self.layout, self.engine
         if self._X is None:
-            self._X = eng.empty(L.np, L.local_cols)
-            self._Wt = eng.empty(PW, L.local_cols)
+            self._X = self._matrix(L.np, L.local_cols)
+            self._Wt = self._matrix(2 * PW, L.local_cols)
         else:
             self._X.zero_()
-        X, Wt = self._X, self._Wt
+        X, Wt2 = self._X, self._Wt
         for p in L.owned:
             idx = torch.arange(L.width(p), device=X.device)
             X[p * PW + idx, L.local_col0(p) + idx] = 1.0
-        for p, buf in self._stream_factor():
+        nprev = 0
+        for p, wide, second in self._stream_factor_pairs():
             nown = sum(1 for c in L.owned if c <= p)
             if nown:
-                eng.solve_update(buf, p, X, Wt, None, nown * PANEL)
+                if second and nown > nprev:
+                    # the pair's second panel is this rank's: its identity columns join the right-hand sides now, and the
+                    # first panel's W is structurally zero there (the k-depth-1024 update reads those columns of it)
+                    Wt2[:PW, nprev * PW:nown * PW].zero_()
+                eng.solve_update2(wide, p, X, Wt2, None, nown * PANEL, second)
                 w = L.width(p)
-                X[p * PW:p * PW + w, :nown * PW].copy_(Wt[:w, :nown * PW])
+                X[p * PW:p * PW + w, :nown * PW].copy_(Wt2[second * PW:second * PW + w, :nown * PW])
+            nprev = nown
         return X
 
     def kinv(self, Xl, out=None):
@@ -416,7 +452,7 @@ class DistributedCholesky:
         the rows of that panel against its own columns on the MFMA tile engine (gpimhip_dist_kinv_update).
         out: where to (default: a new matrix); the training loop passes ``self.local`` -- the factor is dead by then."""
         L, eng = self.layout, self.engine
-        Kl = out if out is not None else eng.empty(L.np, L.local_cols)
+        Kl = out if out is not None else self._matrix(L.np, L.local_cols)
 
         def fill_of(c):
             def fill(buf):

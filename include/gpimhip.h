@@ -287,6 +287,15 @@ int gpimhip_dist_update(gpimhip_handle h, const double* buf, int64_t ldbuf, int3
 int gpimhip_dist_solve_update(gpimhip_handle h, const double* buf, int64_t ldbuf, int32_t panel_glob_blk0,
                               double* B, int64_t ldb, int64_t mpad, double* Wt, int64_t ldw, double* q,
                               int32_t col_tiles);
+/* ... for two panels held side by side in a buffer of 1024 columns (gpim_amd.dist_chol._stream_pairs): the first panel of
+ * a pair (second = 0) updates the second panel's block rows only; after the second panel's own solves (second = 1) the
+ * rows below receive both panels in ONE pass of k-depth 1024 -- half the read-modify-write traffic over the rank's
+ * right-hand sides.  wide: first panel in columns [0, 512), second in [512, 1024), each packed by gpimhip_dist_panel_pack
+ * with ldbuf >= 1024; Wt2: 1024 rows.  The arithmetic per element is that of two consecutive gpimhip_dist_solve_update
+ * calls with the two subtractions of a row below the pair summed in one accumulation. */
+int gpimhip_dist_solve_update2(gpimhip_handle h, const double* wide, int64_t ldbuf, int32_t panel_glob_blk0, double* Bm,
+                               int64_t ldb, int64_t mpad, double* Wt2, int64_t ldw, double* q, int32_t col_tiles,
+                               int32_t second);
 
 /* Distributed TRAINING of that one exact GP (gpim/gpreg/gpr.py:170-217 for a covariance that does not fit one
  * device; driver: gpim_amd/dist_chol.py exact_gp_fit).  Per Adam iteration, at the unconstrained parameters u:

@@ -151,6 +151,25 @@ class NumpyTileEngine:
         if r0 + w < L.np:
             B[r0 + w:, :nc].addmm_(buf[r0 + w:L.np, :w], Wp, alpha=-1.0)
 
+    def solve_update2(self, wide, p, B, Wt2, q, col_tiles, second):
+        """Panels in pairs (gpimhip_dist_solve_update2): the first updates the second panel's rows only, the rows below the
+        pair receive both panels at once."""
+        from gpim_amd.dist_chol import PW
+        L = self.layout
+        w, r0 = L.width(p), p * PW
+        nc = col_tiles * 128 if col_tiles else B.shape[1]
+        half = wide[:, second * PW:(second + 1) * PW]
+        Wp = torch.linalg.solve_triangular(torch.tril(half[r0:r0 + w, :w]), B[r0:r0 + w, :nc], upper=False)
+        Wt2[second * PW:second * PW + w, :nc] = Wp
+        if q is not None:
+            q[:nc] += (Wp * Wp).sum(0)
+        if not second:
+            r1 = min(L.np, r0 + w + PW)
+            if r0 + w < L.np:
+                B[r0 + w:r1, :nc].addmm_(half[r0 + w:r1, :w], Wp, alpha=-1.0)
+        elif r0 + w < L.np:
+            B[r0 + w:, :nc].addmm_(wide[r0 + w:L.np, :PW + w], Wt2[:PW + w, :nc], alpha=-1.0)
+
     def kinv_update(self, xbuf, c, Xloc, Kinv):
         from gpim_amd.dist_chol import PW
         L = self.layout
@@ -207,7 +226,8 @@ def _chol_worker(rank, world, port, ret):
         A = torch.from_numpy(B @ B.T + n * np.eye(n))
         y = torch.from_numpy(rng.standard_normal(n))
         ch = DistributedCholesky(n, engine_factory=NumpyTileEngine)
-        for b in ch._panel:
+        ch._wide = [ch.engine.empty(ch.layout.np + 128, 1024) for _ in range(2)]
+        for b in ch._panel + ch._wide:
             b.fill_(float("nan"))        # a consumer that read rows which no broadcast delivers would spread NaNs
         lay = ch.layout
         assert lay.owned == [p for p in range(lay.npanel) if p % world == rank]
