@@ -1,4 +1,7 @@
-"""Per-iteration time of the distributed training loop (exact_gp_fit) on one GPU.  usage: dist_fit_time.py N [T]"""
+"""Per-iteration time of the distributed training loop (exact_gp_fit) on one GPU.  usage: dist_fit_time.py N [T] [streams4]
+streams4: four extra torch streams are created and touched first -- the process state in which round 3 / 4 saw dependent
+launches start 30-45 us late when a side stream's pending wait sat in the fifth or a later hardware queue (DESIGN.md
+section 6); the distributed driver still has a side stream."""
 import sys, os, time
 import numpy as np, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -11,6 +14,13 @@ R, _ = lattice_image(size=side, frac=1.0, seed=1)
 ii, jj = np.meshgrid(np.arange(side, dtype=np.float64), np.arange(side, dtype=np.float64), indexing="ij")
 X = np.stack([ii.ravel(), jj.ravel()], 1); y = R.ravel()
 kw = dict(kernel="Matern52", lengthscale=[[1., 1.], [20., 20.]], learning_rate=0.1)
+if "streams4" in sys.argv[3:]:
+    keep = []
+    for _ in range(4):
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            torch.zeros(1024, device="cuda").add_(1.0)
+        st.synchronize(); keep.append(st)
 exact_gp_fit(X[:2048], y[:2048], iterations=1, **kw)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 hyper, u = exact_gp_fit(X, y, iterations=T, **kw)

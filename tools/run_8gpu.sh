@@ -6,6 +6,10 @@
 N=${1:-8}; PORT=${2:-29555}
 cd "$(dirname "$0")/.."
 export HSA_ENABLE_IPC_MODE_LEGACY=0
+# ONE exact GP on the complete image across the GPUs: phase times of an Adam iteration per rank (what each rank waited
+# for included; the compute-only share of a rank, measured on one GPU: tools/r5_dist_rank_share.py)
+python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port $PORT \
+    tools/r5_dist_phases_mp.py 65536
 for w in c2 c3 c2full; do
   python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port $PORT \
       bench.py --gpus $N --workload $w --steps 2 --warmup 1
