@@ -473,6 +473,9 @@ static void plan_inverse(int nb, std::vector<std::vector<TileDesc>>& fill, std::
             for (auto& t : out)
                 for (int w = 0; w < q; ++w) sim.add(slow * wg_cost(t.kb1 - t.kb0, q));
             target = std::max(sim.makespan, chain);
+            // (round 5: a larger budget for the inverse's chunks in the second half of a large factorisation -- + 0.5 / 1 / 2
+            // units from launch nb / 2 or 3 nb / 4 on -- measured 72.5 - 72.8 ms per iteration at N = 16384 against 72.25:
+            // what a launch hosts beyond its own length runs at the hosted tiles' 60 TFLOP/s, after the last step at 69)
         }
         bool full = false;
         for (int idx : order) {
