@@ -260,7 +260,7 @@ def extra_configs(gpim):
                              "reconstructor.run()" % (n1, R.size),
                  "seconds": dt, "grid_points_per_s": R.size / dt, "ms_per_adam_iteration": dt / 300 * 1e3,
                  "mfma_frac": (300 * n1 ** 3 + 2 * n1 ** 3 / 3 + n1 ** 2 * R.size) / dt / 1e12 / FP64_MFMA_PEAK_TFLOPS}
-    # C3: 64 slices of 64x64, RBF, T = 250, lock-step batch of 64 on one GPU
+    # C3: 64 slices of 64x64, RBF, T = 250: four lock-step batches of 16 at a time on one GPU
     cube, _ = hyperspectral_cube()
     gdist.reconstruct_slices(cube, axis=-1, batch=16, batch_concurrency=4, **dict(C3, iterations=3))
     sync(); t0 = time.perf_counter()

@@ -321,9 +321,9 @@ def _fit_once(_lib, H, N, T, seed):
 
 
 def test_handle_reuse_across_sizes_and_regimes(eng):
-    """One handle walks through the three regimes (fused small-N trainer, graph-replayed blocked path,
-    plain launches, look-ahead factorisation on side streams) in growing and shrinking order -- workspace, tile plans and lazily created streams
-    are re-used or rebuilt -- and every result is bit-identical to the one of a fresh handle."""
+    """One handle walks through the three regimes (fused small-N trainer, graph-replayed blocked path, plain in-order
+    launches at large N) in growing and shrinking order -- workspace, tile plans and the captured graph are re-used or
+    rebuilt -- and every result is bit-identical to the one of a fresh handle."""
     _lib, H = eng
     # (1207 / 449 / 448: a ragged last block -- at most 64 valid rows, whose padding the tile engine skips -- between
     # sizes of the same padded order that fill it: what a skipped region holds from the previous fit must never be read)
@@ -355,8 +355,8 @@ def test_two_handles_interleaved(eng):
 
 @pytest.mark.parametrize("N,T", [(90, 10), (800, 10), (6200, 2)])
 def test_user_stream_matches_default_stream(eng, N, T):
-    """A handle created under a non-default torch stream runs on that stream (fork/join of the
-    look-ahead side streams included) and returns the same bits as one on the default stream."""
+    """A handle created under a non-default torch stream runs on that stream (a fit is ONE in-order stream; mid-size N
+    replays a graph captured on the library's capture stream) and returns the same bits as one on the default stream."""
     _lib, H = eng
     want = _fit_once(_lib, H, N, T, seed=7)
     s = torch.cuda.Stream()
@@ -371,11 +371,9 @@ def test_user_stream_matches_default_stream(eng, N, T):
 
 
 def test_concurrent_handles_share_side_streams(eng):
-    """The capture / panel / bulk side streams are per device, shared by all handles (api.hip:
-    ensure_lookahead_streams).  Two threads, each with its own handle on its own torch stream, train at the same
-    time in the look-ahead regime (N = 6200) and in the graph-replayed regime (N = 800): every cross-stream
-    dependency is an event of the handle that recorded it, so the interleaving on the shared streams cannot mix
-    the two models up -- results are bit-identical to the sequential ones."""
+    """The capture stream is per device, shared by all handles (api.hip: SideStreams).  Two threads, each with its own
+    handle on its own torch stream, train at the same time at large N (N = 6200, plain launches) and in the
+    graph-replayed regime (N = 800): the two models cannot mix up -- results are bit-identical to the sequential ones."""
     import threading
     _lib, H = eng
     jobs = [(6200, 2, 11), (800, 10, 12), (6200, 2, 13), (800, 10, 14)]

@@ -2,8 +2,8 @@
 Oracle parity in every execution regime of the engine, at the sizes the benchmark and the
 BASELINE.json configs actually use ("next" item 1):
 
-  * look-ahead regime (N >= 6144: multi-stream Cholesky schedule, K^-1 product with the two mat-vecs
-    on the side stream) -- the path bench.py times: loss / gradient / posterior and three Adam
+  * large-N regime (N >= 6144: plain in-order launches -- the step schedule of csrc/cholstep.hip with the inverse riding
+    in the factorisation's launches, one stream) -- the path bench.py times: loss / gradient / posterior and three Adam
     iterations against O.ExactGP for Matern52 (N = 8192) and RBF (N = 6400);
   * graph-replayed blocked path (128 < N < 6144): a 200-iteration Adam trajectory at N = 300;
   * general path at BO sizes (GPIMHIP_NO_SMALLN=1): the reference's three golden BO runs;
