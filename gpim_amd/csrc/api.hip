@@ -160,7 +160,7 @@ static int ws_ensure_b(gpimhip_ctx* h, int64_t N, int B, int padded, bool matric
     // launch plans of the single-GPU path (built here: building one synchronises the stream, which a graph
     // capture does not allow); the distributed factorisation has its own (gpimhip_dist_setup)
     if (matrices) {
-        int rc = plan_ensure(h, (int)nb);
+        rc = plan_ensure(h, (int)nb);
         // fit / predict invert the factor in the factorisation's launches (double precision); float matrices and
         // gpimhip_potrf use the plain plan, which is built on first use (never inside a capture)
         if (rc == GPIMHIP_OK) rc = h->fp32 ? step_plan_ensure(h, (int)nb) : step_plan_ensure_inv(h, (int)nb);
@@ -758,8 +758,8 @@ static int fit_impl(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X, i
     // Every iteration enqueues the same launches (the iteration index lives on the device), so one
     // iteration is captured into a hipGraph and replayed: ~10 us of host work per iteration instead
     // of one launch call per kernel.  Not used while stage timing is on or for very short fits.
-    // Large N: the launch cost no longer matters and the iteration is enqueued launch by launch, its launch-chain
-    // stages on the engine's high-priority stream and the mat-vecs on a side stream (factor_at_u, loss_grad_at_u).
+    // Large N: the launch cost no longer matters and the iteration is enqueued launch by launch on the caller's stream
+    // (ONE in-order stream: factor_at_u, loss_grad_at_u).
     const int npanel = (int)((h->np / NB + OUTER_W - 1) / OUTER_W);
     const bool large = npanel >= EAGER_MIN_PANELS;
     const bool use_graph = T >= 8 && !h->timing && !getenv("GPIMHIP_NO_GRAPH") && !large && ensure_capture_stream(h);

@@ -436,7 +436,9 @@ static int host_shape(int64_t update_kblocks, int quad_max = 2000) { return upda
 // (>= 300 update quadrants of average depth >= 3; 420 / 3.5 before the planner knew: N = 8192 11.42 -> 11.31 ms per
 // iteration; 240 / 2.5, depth 2 and never pairing -- 12.15 ms -- are slower)
 static bool pair_rule(size_t ntiles, int64_t kblocks) { return 4 * ntiles >= 300 && 10 * kblocks >= 30 * (int64_t)ntiles; }
-static void plan_inverse(int nb, std::vector<std::vector<TileDesc>>& fill, std::vector<std::vector<TileDesc>>& post,
+// returns false if the plan did not close (every launch completes at least one phase of one node, so this cannot happen
+// with the dependency rule as it stands; a caller must not run a partial plan: A would be left a half-inverted factor)
+static bool plan_inverse(int nb, std::vector<std::vector<TileDesc>>& fill, std::vector<std::vector<TileDesc>>& post,
                          std::vector<uint8_t>& pair) {
     std::vector<TriNodeS> nodes;
     tri_nodes(0, nb, nodes);
@@ -512,8 +514,9 @@ static void plan_inverse(int nb, std::vector<std::vector<TileDesc>>& fill, std::
             return ((a.kb1 & 0xffff) - a.kb0) > ((b.kb1 & 0xffff) - b.kb0);
         });
         if (!hosted && out.empty()) post.pop_back();      // (dependencies only resolve across launches)
-        if (L > nb + 4 * 64) break;                        // cannot happen: every launch completes at least one phase
+        if (L > nb + 4 * 64) return false;
     }
+    return true;
 }
 
 static int step_plan_build(gpimhip_ctx* h, int nb, StepPlan& P, bool with_inverse) {
@@ -562,7 +565,10 @@ static int step_plan_build(gpimhip_ctx* h, int nb, StepPlan& P, bool with_invers
     for (int j = 0; j < nb; ++j)
         for (auto& t : fill[j]) P.n_update[j] += t.kb1 - t.kb0;
     P.pair.assign(nb, 0);
-    if (with_inverse) plan_inverse(nb, fill, post, P.pair);
+    if (with_inverse && !plan_inverse(nb, fill, post, P.pair)) {
+        gpim_set_error("step plan: the inverse's tile operations did not all find a launch (nb = " + std::to_string(nb) + ")");
+        return GPIMHIP_E_BADARG;
+    }
     else
         for (int j = 0; j < nb; ++j) P.pair[j] = host_shape(P.n_update[j]) == 4 && pair_rule(fill[j].size(), P.n_update[j]);
     P.n_all.assign(nb, 0);
@@ -605,7 +611,7 @@ extern "C" int gpimhip_step_plan_host(int32_t nb, int32_t with_inverse, int32_t*
     std::vector<std::vector<TileDesc>> fill(nb), post;
     plan_updates(nb, fill);
     std::vector<uint8_t> pair(nb, 0);
-    if (with_inverse) plan_inverse(nb, fill, post, pair);
+    if (with_inverse && !plan_inverse(nb, fill, post, pair)) return GPIMHIP_E_BADARG;
     int64_t n = 0;
     auto emit = [&](int launch, const std::vector<TileDesc>& v) {
         for (const TileDesc& t : v) {

@@ -246,6 +246,11 @@ struct GemmArgs {
                                            // stored at local columns (distributed layouts); needs kfix0 / kfix1
     int chunk;                             // XCD dealing: 0 = contiguous slices, >0 = round-robin chunks
     int inplace;                           // C aliases an operand tile (panel solve): one workgroup must own the whole tile
+    // INVARIANT of ragged launches: the padding rows of the last block row of Tm and B (workspace matrices) are zeroed at
+    // allocation only and never written by a rag launch; every reader of Tm / B under rag skips them too (X phase with
+    // kb1 == nb, lauum with krev, the COLSUMSQ predict path).  Non-rag fits and the sparse model on the same handle write
+    // those rows fully, so after them they hold stale data: a NEW consumer of Tm or B (a full-np reduction over K^-1, say)
+    // must either skip the padding rows or zero them first.
     int rag;                               // > 0: block rag - 1 (the LAST block of the matrix order) holds at most 64 valid
                                            // rows / columns, the rest is identity padding: output rows >= 64 of block row
                                            // rag - 1 and the k-steps >= 64 of a range ending with that block are structurally

@@ -63,6 +63,9 @@ __global__ __launch_bounds__(512) void dist_trsv_kernel(const double* __restrict
     __shared__ double part[4][NB];
     const int tid = threadIdx.x, r = tid & 127, q = tid >> 7;
     for (int e = tid; e < nblk * NB; e += 512) x[e] = 0.0;
+    // a ragged last panel (nblk < 4): the entries of `out` (512 doubles, broadcast and copied as a whole by the driver)
+    // it does not own are zero, not what the previous panel left there
+    for (int e = nblk * NB + tid; e < 4 * NB; e += 512) out[e] = 0.0;
     __syncthreads();
     for (int s = 0; s < nblk; ++s) {
         const int b = backward ? nblk - 1 - s : s;
