@@ -491,7 +491,10 @@ static int factor_at_u(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X
                        const double* u) {
     const int64_t np = h->np, ld = h->ld;
     GP_TRY(launch_theta(h, m, u));
-    GP_TRY(launch_kmat(h, m, X, N, nullptr, N, h->theta, 0.0, 1, h->A, ld, np, np, 1, 1, x_bs, x_bs, np * ld));
+    if (h->refl.mask)      // symmetry-reduced model: problem b of the batch is the block of sign pattern b (engine.hip)
+        GP_TRY(launch_kmat_refl(h, m, X, N, nullptr, N, h->theta, h->A, ld, np, np, 1, x_bs, x_bs, np * ld, 1.0));
+    else
+        GP_TRY(launch_kmat(h, m, X, N, nullptr, N, h->theta, 0.0, 1, h->A, ld, np, np, 1, 1, x_bs, x_bs, np * ld));
     GP_TRY(launch_potrf_inv(h, h->A, h->Tm, np, ld, h->info, rag_of(N, np)));
     return solve_vectors(h, m, X, x_bs, N);
 }
@@ -504,6 +507,14 @@ static int loss_grad_at_u(gpimhip_ctx* h, const gpimhip_model_t* m, const double
     const int64_t np = h->np;
     GP_TRY(factor_at_u(h, m, X, x_bs, N, u));
     { StageTimer t(h, 2); GP_TRY(launch_lauum(h, h->A, h->B, np, h->ld, rag_of(N, np))); }
+    if (h->refl.mask) {
+        GP_TRY(launch_grad_reduce_refl(h, m, h->B, h->ld, X, N, (int)(np / NB), h->alpha, x_bs));
+        if (tab)
+            return launch_finalize_coupled(h, m, N, np, u, do_adam, st, nullptr, nullptr, nullptr, tab->iter, tab->bc, tab->T,
+                                           tab->hist_base, tab->loss_base);
+        return launch_finalize_coupled(h, m, N, np, u, do_adam, st, loss_out, grad_out, hist_row, nullptr, nullptr, 0, nullptr,
+                                       nullptr);
+    }
     GP_TRY(launch_grad_reduce(h, m, h->B, h->ld, X, N, (int)(np / NB), h->alpha, x_bs));
     if (tab)
         GP_TRY(launch_finalize(h, m, N, np, u, do_adam, st, nullptr, nullptr, nullptr, tab->iter, tab->bc, tab->T,
@@ -742,7 +753,7 @@ static int fit_impl(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X, i
     h->fit_completed = T;
     if (T == 0) return GPIMHIP_OK;
     GP_TRY(upload_bc_table(h, lr, T));
-    if (use_small_path(N)) {
+    if (use_small_path(N) && !h->refl.mask) {
         // fused single-launch trainer, one workgroup per problem
         GP_TRY(launch_fit_small(h, m, X, x_bs, y, (int)N, u, h->bc, h->bc + T, T, hist_out, loss_out, nullptr));
         return finish_and_check(h);
@@ -807,7 +818,7 @@ static int predict_cols(gpimhip_ctx* h, const gpimhip_model_t* m, const double* 
     const int64_t np = h->np;
     const int nb = (int)(np / NB);
     // few observations: one fused launch, K* stays in LDS (predict.hip)
-    if (!h->fp32 && fused_predict_fits(np))
+    if (!h->fp32 && fused_predict_fits(np) && !h->refl.mask)
         return launch_predict_fused(h, m, X, x_bs, N, Xs, M, mean_out, var_out, nullptr, nullptr, -1, 0.0, nullptr, 0.0,
                                     nullptr);
     // chunk the test points so that the K* slabs of all problems together stay <= ~1 GiB
@@ -820,10 +831,14 @@ static int predict_cols(gpimhip_ctx* h, const gpimhip_model_t* m, const double* 
         const int64_t cnt = std::min(mc, M - m0);
         const int64_t cpad = pad_to(cnt, NB);
         // the test grid Xs is shared by all problems of the batch (z stride 0)
-        GP_TRY(launch_kmat(h, m, X, N, Xs + m0 * m->dim, cnt, h->theta, 0.0, 0, h->Ks, kld, np, cpad, 0, 0, x_bs, 0,
-                           np * kld));
+        if (h->refl.mask)      // V_s^T k(X, x*): the block's rows against the test point and its mirror images, |G|^-1/2 each
+            GP_TRY(launch_kmat_refl(h, m, X, N, Xs + m0 * m->dim, cnt, h->theta, h->Ks, kld, np, cpad, 0, x_bs, 0, np * kld,
+                                    1.0 / sqrt((double)B)));
+        else
+            GP_TRY(launch_kmat(h, m, X, N, Xs + m0 * m->dim, cnt, h->theta, 0.0, 0, h->Ks, kld, np, cpad, 0, 0, x_bs, 0,
+                               np * kld));
         GP_TRY(launch_gemv_t(h, h->Ks, kld, np, cpad, h->alpha, h->mean_tmp, 0, np * kld, np, mcap));
-        GP_TRY(launch_copy_slice(h, h->mean_tmp, mean_out + m0, cnt, mcap, M));
+        if (!h->refl.mask) GP_TRY(launch_copy_slice(h, h->mean_tmp, mean_out + m0, cnt, mcap, M));
         GemmArgs g = gemm_args(h->A, h->ld, h->Ks, kld, nullptr, 0, 1.0, 0.0, h->pred_tiles, 0, h->np);
         g.sB = np * kld;
         g.colpart = h->colpart;
@@ -834,7 +849,8 @@ static int predict_cols(gpimhip_ctx* h, const gpimhip_model_t* m, const double* 
         g.chunk = deal_chunk(g.ntiles);
         g.rag = h->fp32 ? 0 : rag_of(N, np);
         { StageTimer t(h, 3); GP_TRY(launch_gemm(h, false, true, EPI_COLSUMSQ, g)); }
-        GP_TRY(launch_predict_var(h, mcap, nb, m0, cnt, var_out, M));
+        if (h->refl.mask) GP_TRY(launch_predict_coupled(h, mcap, nb, m0, cnt, mcap, mean_out, var_out));
+        else GP_TRY(launch_predict_var(h, mcap, nb, m0, cnt, var_out, M));
     }
     return GPIMHIP_OK;
 }
@@ -1408,6 +1424,17 @@ int gpimhip_dist_finalize_dev(gpimhip_handle h, const gpimhip_model_t* m, int64_
         HIP_TRY(hipMemsetAsync(h->adam_v, 0, MAXP * sizeof(double), h->stream));
     }
     return launch_dist_finalize_dev(h, m, N, red, quad, u, t > 0 ? 1 : 0, st, loss_out, grad_out, hist_row);
+}
+
+int gpimhip_set_reflection(gpimhip_handle h, int32_t mask, const double* twoc) {
+    if (!h || mask < 0 || mask >= (1 << GPIMHIP_MAX_DIM) || (mask && !twoc)) return GPIMHIP_E_BADARG;
+    if (mask && h->fp32) {
+        gpim_set_error("the symmetry-reduced model computes in double precision");
+        return GPIMHIP_E_BADARG;
+    }
+    h->refl.mask = mask;
+    for (int k = 0; k < GPIMHIP_MAX_DIM; ++k) h->refl.twoc[k] = mask ? twoc[k] : 0.0;
+    return GPIMHIP_OK;
 }
 
 int gpimhip_thin_batch(gpimhip_handle h, const double* vals, const int64_t* flat_idx, int32_t n, int32_t d,

@@ -99,7 +99,15 @@ struct DistPlan {
     int64_t n_rect = 0;
 };
 
+// Reflection symmetry of a complete, uniform grid under a stationary kernel that is even in every coordinate difference
+// (gpimhip_set_reflection; engine.hip: kmat_refl_kernel): mask = the reflected dimensions (bit k), twoc[k] = first + last
+// coordinate of dimension k, so that the mirror image of z_k is twoc[k] - z_k.
+struct ReflArgs {
+    int mask;
+    double twoc[GPIMHIP_MAX_DIM];
+};
 struct gpimhip_ctx {
+    ReflArgs refl = {0, {0, 0, 0, 0}};
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t capture_stream = nullptr; // internal stream used only to capture one iteration into a hipGraph
@@ -218,6 +226,16 @@ int launch_dist_rows_acc(gpimhip_ctx* h, const double* A, int64_t ld, int64_t ro
 int launch_grad_reduce_tiles(gpimhip_ctx* h, const gpimhip_model_t* m, const double* Kinv, int64_t ld, const double* X,
                              int64_t N, int64_t np, const double* alpha, const TileDesc* tiles, int ntile, double* part);
 int launch_sum7(gpimhip_ctx* h, const double* part, int ntile, double* S);
+int launch_kmat_refl(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X, int64_t N, const double* Z, int64_t M,
+                     const ThetaDev* theta, double* out, int64_t ld, int64_t rows_pad, int64_t cols_pad, int sym, int64_t x_bs,
+                     int64_t z_bs, int64_t out_bs, double scale);
+int launch_grad_reduce_refl(gpimhip_ctx* h, const gpimhip_model_t* m, const double* Kinv, int64_t ld, const double* X,
+                            int64_t N, int nb, const double* alpha, int64_t x_bs);
+int launch_finalize_coupled(gpimhip_ctx* h, const gpimhip_model_t* m, int64_t N, int64_t np, double* u, int do_adam,
+                            AdamStep st, double* loss_out, double* grad_out, double* hist_row, int32_t* iter,
+                            const double* bc, int T, double* hist_base, double* loss_base);
+int launch_predict_coupled(gpimhip_ctx* h, int64_t ldp, int nb, int64_t m0, int64_t mcount, int64_t mean_bs, double* mean_out,
+                           double* var_out);
 int launch_dist_finalize_dev(gpimhip_ctx* h, const gpimhip_model_t* m, int64_t N, const double* red, const double* quad,
                              double* u, int do_adam, AdamStep st, double* loss_out, double* grad_out, double* hist_row);
 int launch_dist_finalize(gpimhip_ctx* h, const gpimhip_model_t* m, int64_t N, const double* S, double q2, double lg,

@@ -951,6 +951,284 @@ int launch_dist_finalize(gpimhip_ctx* h, const gpimhip_model_t* m, int64_t N, co
     return GPIMHIP_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// Symmetry-reduced exact GP on a complete uniform grid (reconstructor(structured=True) with a kernel that does not
+// factorise over the axes: role of the reference's structured class gpim/gpreg/skgpr.py:399-448, exact instead of SKI).
+// A stationary kernel that is even in every coordinate difference commutes with the reflections g of the grid about
+// its centre planes; in the basis  v_{s,p} = |G|^-1/2 sum_g chi_s(g) e_{g p}  (p in the fundamental domain: the first
+// half of every reflected axis, s a sign pattern, chi_s(g) = prod_{k in g} s_k) the covariance is block diagonal with
+//     K_s[p, q] = sum_g chi_s(g) k(p, g q)              (N / |G| points each, |G| = 2^(reflected axes))
+// and (noise + jitter) I stays what it is.  The |G| blocks are the problems of ONE lock-step batch (problem b <-> sign
+// pattern: bit j of b = the sign of the j-th reflected axis is -1) with ONE set of hyper-parameters: their gradient sums,
+// quadratic forms and log-determinants add up (finalize_coupled_kernel).  Cost of the O(N^3) stages: |G|^-2 of the dense
+// model -- 1/16 in two dimensions.  Exact up to rounding: an orthogonal change of basis.
+// ------------------------------------------------------------------------------------------
+struct ReflPair {
+    double dm2[GPIMHIP_MAX_DIM], dp2[GPIMHIP_MAX_DIM];       // squared scaled differences to z and to its mirror image
+};
+// sum over the reflections: acc(g, chi, r2) for every subset g of mask
+template <typename F>
+__device__ __forceinline__ void refl_for_each(const ReflPair& p, int mask, int pb, int d, F f) {
+    double base = 0.0;
+    int dims[GPIMHIP_MAX_DIM], nref = 0;
+    for (int k = 0; k < GPIMHIP_MAX_DIM; ++k) {
+        if (k >= d) continue;
+        if ((mask >> k) & 1) dims[nref++] = k;
+        else base += p.dm2[k];
+    }
+    for (int g = 0; g < (1 << nref); ++g) {
+        double r2 = base;
+        int gm = 0;
+        for (int j = 0; j < nref; ++j) {
+            const bool refl = (g >> j) & 1;
+            r2 += refl ? p.dp2[dims[j]] : p.dm2[dims[j]];
+            gm |= refl ? (1 << dims[j]) : 0;
+        }
+        const double chi = (__popc(g & pb) & 1) ? -1.0 : 1.0;
+        f(gm, chi, r2);
+    }
+}
+template <int KIND>
+__global__ __launch_bounds__(256) void kmat_refl_kernel(const double* __restrict__ X, int64_t N, const double* __restrict__ Z,
+                                                        int64_t M, int d, const ThetaDev* __restrict__ th, double* __restrict__ out,
+                                                        int64_t ld, int ntc, int sym, int64_t x_bs, int64_t z_bs, int64_t out_bs,
+                                                        ReflArgs refl, double scale) {
+    __shared__ double xa[128][4];
+    __shared__ double xz[128][4];
+    const int tid = threadIdx.x, pb = blockIdx.y;
+    X += blockIdx.y * x_bs;
+    Z += blockIdx.y * z_bs;
+    th += blockIdx.y;
+    out += blockIdx.y * out_bs;
+    const int ci = blockIdx.x / ntc, cj = blockIdx.x % ntc;
+    const ThetaDev t = *th;
+    {
+        const bool isrow = tid < 128;
+        const int loc = tid & 127;
+        const int64_t g = (int64_t)(isrow ? ci : cj) * 128 + loc;
+        const double* src = isrow ? X : Z;
+        const int64_t lim = isrow ? N : M;
+        double (*dst)[4] = isrow ? xa : xz;
+        for (int k = 0; k < GPIMHIP_MAX_DIM; ++k) dst[loc][k] = (k < d && g < lim) ? src[g * d + k] / t.ls[k] : 0.0;
+    }
+    __syncthreads();
+    double cz[GPIMHIP_MAX_DIM];
+    for (int k = 0; k < GPIMHIP_MAX_DIM; ++k) cz[k] = refl.twoc[k] / t.ls[k];
+    const int ty = tid >> 4, tx = tid & 15;
+    for (int rr = 0; rr < 8; ++rr) {
+        const int r = ty + 16 * rr;
+        const int64_t gi = (int64_t)ci * 128 + r;
+        for (int cc = 0; cc < 8; ++cc) {
+            const int c = tx + 16 * cc;
+            const int64_t gj = (int64_t)cj * 128 + c;
+            ReflPair p;
+            for (int k = 0; k < GPIMHIP_MAX_DIM; ++k) {
+                const double dm = xa[r][k] - xz[c][k], dp = (xa[r][k] + xz[c][k]) - cz[k];
+                p.dm2[k] = dm * dm;
+                p.dp2[k] = dp * dp;
+            }
+            double acc = 0.0;
+            refl_for_each(p, refl.mask, pb, d, [&](int, double chi, double r2) { acc += chi * kfun_value<KIND>(r2, t.alpha); });
+            double k = scale * t.var * acc;
+            if (gi >= N || gj >= M) k = (sym && gi == gj) ? 1.0 : 0.0;
+            else if (sym && gi == gj) k += t.diag_add;
+            out[gi * ld + gj] = k;
+        }
+    }
+}
+int launch_kmat_refl(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X, int64_t N, const double* Z, int64_t M,
+                     const ThetaDev* theta, double* out, int64_t ld, int64_t rows_pad, int64_t cols_pad, int sym, int64_t x_bs,
+                     int64_t z_bs, int64_t out_bs, double scale) {
+    const int ntr = (int)(rows_pad / 128), ntc = (int)(cols_pad / 128);
+    if (ntr <= 0 || ntc <= 0) return GPIMHIP_OK;
+    const double* Zp = Z ? Z : X;
+    if (!Z) z_bs = x_bs;
+    dim3 grid((unsigned)(ntr * ntc), h->nbatch), block(256);
+#define KR_LAUNCH(KIND)                                                                                                 \
+    hipLaunchKernelGGL((kmat_refl_kernel<KIND>), grid, block, 0, h->stream, X, N, Zp, M, m->dim, theta, out, ld, ntc, sym, x_bs, \
+                       z_bs, out_bs, h->refl, scale)
+    switch (m->kernel) {
+        case GPIMHIP_KERNEL_RBF: KR_LAUNCH(GPIMHIP_KERNEL_RBF); break;
+        case GPIMHIP_KERNEL_MATERN52: KR_LAUNCH(GPIMHIP_KERNEL_MATERN52); break;
+        case GPIMHIP_KERNEL_RQ: KR_LAUNCH(GPIMHIP_KERNEL_RQ); break;
+        default: gpim_set_error("unknown kernel kind"); return GPIMHIP_E_BADARG;
+    }
+#undef KR_LAUNCH
+    HIP_TRY(hipGetLastError());
+    return GPIMHIP_OK;
+}
+// the gradient sums of grad_reduce_kernel for one block K_s: the same contraction with every entry's kernel value and
+// derivative factors summed over the reflections (a mirror image's scaled difference (a_k + b_k - c_k / l_k) scales with
+// 1 / l_k like the plain one)
+template <int KIND>
+__global__ __launch_bounds__(256) void grad_reduce_refl_kernel(const double* __restrict__ Kinv, int64_t ld,
+                                                               const double* __restrict__ X, int64_t N, int d,
+                                                               const double* __restrict__ alpha,
+                                                               const ThetaDev* __restrict__ th, double* __restrict__ part,
+                                                               int64_t x_bs, int64_t np, ReflArgs refl) {
+    __shared__ double xa[128][4];
+    __shared__ double xz[128][4];
+    __shared__ double al_r[128], al_c[128];
+    __shared__ double red[4][8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, pb = blockIdx.y;
+    Kinv += blockIdx.y * np * ld;
+    X += blockIdx.y * x_bs;
+    alpha += blockIdx.y * np;
+    th += blockIdx.y;
+    part += (int64_t)blockIdx.y * gridDim.x * 8;
+    int ci, cj;
+    lower_tile_from_linear(blockIdx.x, ci, cj);
+    const ThetaDev t = *th;
+    {
+        const bool isrow = tid < 128;
+        const int loc = tid & 127;
+        const int64_t g = (int64_t)(isrow ? ci : cj) * 128 + loc;
+        double (*dst)[4] = isrow ? xa : xz;
+        for (int k = 0; k < GPIMHIP_MAX_DIM; ++k) dst[loc][k] = (k < d && g < N) ? X[g * d + k] / t.ls[k] : 0.0;
+        (isrow ? al_r : al_c)[loc] = (g < N) ? alpha[g] : 0.0;
+    }
+    __syncthreads();
+    double cz[GPIMHIP_MAX_DIM];
+    for (int k = 0; k < GPIMHIP_MAX_DIM; ++k) cz[k] = refl.twoc[k] / t.ls[k];
+    double S[7] = {0, 0, 0, 0, 0, 0, 0};
+    const int ty = tid >> 4, tx = tid & 15;
+    for (int rr = 0; rr < 8; ++rr) {
+        const int r = ty + 16 * rr;
+        const int64_t gi = (int64_t)ci * 128 + r;
+        const double ali = al_r[r];
+        for (int cc = 0; cc < 8; ++cc) {
+            const int c = tx + 16 * cc;
+            const int64_t gj = (int64_t)cj * 128 + c;
+            if (gi >= N || gj > gi) continue;
+            const double g = Kinv[gi * ld + gj] - ali * al_c[c];
+            const double w = (gi == gj) ? g : 2.0 * g;
+            ReflPair p;
+            for (int k = 0; k < GPIMHIP_MAX_DIM; ++k) {
+                const double dm = xa[r][k] - xz[c][k], dp = (xa[r][k] + xz[c][k]) - cz[k];
+                p.dm2[k] = dm * dm;
+                p.dp2[k] = dp * dp;
+            }
+            refl_for_each(p, refl.mask, pb, d, [&](int gm, double chi, double r2) {
+                const KVal kv = kfun_grad<KIND>(r2, t.alpha);
+                const double wc = w * chi;
+                S[0] = fma(wc, kv.e, S[0]);
+                const double wh = wc * kv.h;
+                for (int k = 0; k < GPIMHIP_MAX_DIM; ++k) S[1 + k] = fma(wh, ((gm >> k) & 1) ? p.dp2[k] : p.dm2[k], S[1 + k]);
+                if (KIND == GPIMHIP_KERNEL_RQ) S[6] = fma(wc, kv.ga, S[6]);
+            });
+            if (gi == gj) S[5] += g;
+        }
+    }
+    for (int k = 0; k < 7; ++k) {
+        const double v = wave_sum(S[k]);
+        if (lane == 0) red[wave][k] = v;
+    }
+    __syncthreads();
+    if (tid < 8) {
+        double v = 0.0;
+        if (tid < 7) v = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+        part[(int64_t)blockIdx.x * 8 + tid] = v;
+    }
+}
+int launch_grad_reduce_refl(gpimhip_ctx* h, const gpimhip_model_t* m, const double* Kinv, int64_t ld, const double* X,
+                            int64_t N, int nb, const double* alpha, int64_t x_bs) {
+    const int ntile = nb * (nb + 1) / 2;
+    dim3 grid(ntile, h->nbatch), block(256);
+#define GR_LAUNCH(KIND)                                                                                              \
+    hipLaunchKernelGGL((grad_reduce_refl_kernel<KIND>), grid, block, 0, h->stream, Kinv, ld, X, N, m->dim, alpha, h->theta, \
+                       h->grad_part, x_bs, h->np, h->refl)
+    switch (m->kernel) {
+        case GPIMHIP_KERNEL_RBF: GR_LAUNCH(GPIMHIP_KERNEL_RBF); break;
+        case GPIMHIP_KERNEL_MATERN52: GR_LAUNCH(GPIMHIP_KERNEL_MATERN52); break;
+        case GPIMHIP_KERNEL_RQ: GR_LAUNCH(GPIMHIP_KERNEL_RQ); break;
+        default: gpim_set_error("unknown kernel kind"); return GPIMHIP_E_BADARG;
+    }
+#undef GR_LAUNCH
+    HIP_TRY(hipGetLastError());
+    return GPIMHIP_OK;
+}
+// finalize for the coupled blocks: the sums of all B problems (fixed order: problem by problem), ONE loss / gradient /
+// Adam step on the parameters of problem 0, which are then copied to the other problems' slots
+__global__ __launch_bounds__(256) void finalize_coupled_kernel(gpimhip_model_t m, int64_t N, int64_t np, int nb, int ntile, int B,
+                                                               const double* __restrict__ grad_part, const double* __restrict__ z,
+                                                               const double* __restrict__ zb,
+                                                               const double* __restrict__ logdet_part,
+                                                               const ThetaDev* __restrict__ th, double* __restrict__ u,
+                                                               double* __restrict__ adam_m, double* __restrict__ adam_v,
+                                                               int do_adam, AdamStep st, double* __restrict__ loss_out,
+                                                               double* __restrict__ grad_out, double* __restrict__ hist_row,
+                                                               FinalizeIter fi, int32_t* __restrict__ info) {
+    __shared__ double red[256];
+    __shared__ double S[8];
+    const int tid = threadIdx.x;
+    const int P = 2 + m.n_ls + (m.kernel == GPIMHIP_KERNEL_RQ ? 1 : 0);
+    double q2 = 0.0, lg = 0.0;
+    if (tid < 8) S[tid] = 0.0;
+    __syncthreads();
+    for (int b = 0; b < B; ++b) {
+        for (int k = 0; k < 7; ++k) {
+            double v = 0.0;
+            for (int q = tid; q < ntile; q += 256) v += grad_part[((int64_t)b * ntile + q) * 8 + k];
+            v = block_sum_256(v, red);
+            if (tid == 0) S[k] += v;
+        }
+        double qb = 0.0;
+        for (int64_t i = tid; i < np; i += 256) qb = fma(z[b * np + i], zb[b * np + i], qb);
+        q2 += block_sum_256(qb, red);
+        double lb = 0.0;
+        for (int k = tid; k < nb; k += 256) lb += logdet_part[(int64_t)b * nb + k];
+        lg += block_sum_256(lb, red);
+    }
+    if (tid != 0) return;
+    if (fi.iter) {
+        const int it = *fi.iter;
+        if (*info != 0) {
+            atomicMin(info + 1, it);
+            return;
+        }
+        st.lr_over_bc1 = fi.bc[it];
+        st.bc2_sqrt = fi.bc[fi.T + it];
+        loss_out = fi.loss_base ? fi.loss_base + it : nullptr;
+        hist_row = fi.hist_base ? fi.hist_base + (int64_t)it * P : nullptr;
+        *fi.iter = it + 1;
+    }
+    finalize_step(m, N * B, S, q2, lg, *th, u, adam_m, adam_v, do_adam, st, loss_out, grad_out, hist_row, prior_constant(m));
+    for (int b = 1; b < B; ++b)
+        for (int k = 0; k < P; ++k) u[(int64_t)b * P + k] = u[k];
+}
+int launch_finalize_coupled(gpimhip_ctx* h, const gpimhip_model_t* m, int64_t N, int64_t np, double* u, int do_adam,
+                            AdamStep st, double* loss_out, double* grad_out, double* hist_row, int32_t* iter,
+                            const double* bc, int T, double* hist_base, double* loss_base) {
+    const int nb = (int)(np / NB);
+    FinalizeIter fi{iter, bc, T, hist_base, loss_base};
+    hipLaunchKernelGGL(finalize_coupled_kernel, dim3(1), dim3(256), 0, h->stream, *m, N, np, nb, nb * (nb + 1) / 2, h->nbatch,
+                       h->grad_part, h->z, h->fp32 ? h->alpha : h->z, h->logdet_part, h->theta, u, h->adam_m, h->adam_v, do_adam,
+                       st, loss_out, grad_out, hist_row, fi, h->info);
+    HIP_TRY(hipGetLastError());
+    return GPIMHIP_OK;
+}
+// posterior of the coupled blocks: mean_j = sum_b mean_b[j], var_j = clamp(s2 - sum_b sum_ci colpart_b[ci][j], 0) + noise
+__global__ void predict_coupled_kernel(const double* __restrict__ colpart, int64_t ldp, int nb, int B, int64_t m0, int64_t mcount,
+                                       const double* __restrict__ mean_tmp, int64_t mean_bs, const ThetaDev* __restrict__ th,
+                                       double* __restrict__ mean_out, double* __restrict__ var_out) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= mcount) return;
+    double q = 0.0, mu = 0.0;
+    for (int b = 0; b < B; ++b) {
+        for (int ci = 0; ci < nb; ++ci) q += colpart[((int64_t)b * nb + ci) * ldp + j];
+        mu += mean_tmp[b * mean_bs + j];
+    }
+    mean_out[m0 + j] = mu;
+    var_out[m0 + j] = clamp0_nan(th->var - q) + th->noise;
+}
+int launch_predict_coupled(gpimhip_ctx* h, int64_t ldp, int nb, int64_t m0, int64_t mcount, int64_t mean_bs, double* mean_out,
+                           double* var_out) {
+    hipLaunchKernelGGL(predict_coupled_kernel, dim3((unsigned)((mcount + 255) / 256)), dim3(256), 0, h->stream, h->colpart, ldp,
+                       nb, h->nbatch, m0, mcount, h->mean_tmp, mean_bs, h->theta, mean_out, var_out);
+    HIP_TRY(hipGetLastError());
+    return GPIMHIP_OK;
+}
+
 // The diagonal of a column slab of the covariance (columns row0 .. row0 + npad - 1 of the padded matrix):
 // out[(row0 + j) * ld + j] += jitter + noise(theta) for the n valid columns, = 1 for the padding columns
 __global__ void add_diag_theta_kernel(double* __restrict__ out, int64_t ld, int64_t row0, int64_t n, int64_t npad,

@@ -344,6 +344,20 @@ int gpimhip_dist_finalize_dev(gpimhip_handle h, const gpimhip_model_t* m, int64_
                               const double* quad, double lr, int32_t t, double* loss_out, double* grad_out,
                               double* hist_row);
 
+/* Symmetry-reduced exact GP on a COMPLETE uniform grid, for kernels that do not factorise over the axes (Matern52,
+ * RationalQuadratic; RBF works too): the role of the reference's structured class (gpim/gpreg/skgpr.py:399-448 with
+ * gpim/kernels/gpytorch_kernels.py:65), exact instead of interpolated.  mask: bit k = dimension k of the grid is
+ * reflection-symmetric (its coordinates are first, first + step, ..., last with an EVEN count); twoc[k] = first + last.
+ * With a mask set, gpimhip_fit_exact_batched / gpimhip_predict_exact_batched / gpimhip_nll_grad-style calls treat the
+ * B = 2^popcount(mask) problems of a batch as the diagonal blocks of ONE model in the reflection-adapted basis:
+ *   X         the fundamental domain (the first half of every reflected axis): N / B points, shared (x_stride 0)
+ *   y         B stacked vectors  y_s[p] = B^-1/2 sum_g chi_s(g) y[g p]   (sign pattern s = problem index, bit j = the
+ *             j-th reflected dimension in ascending order carries sign -1)
+ *   u         B copies of ONE parameter vector (all updated alike); hist_out / loss_out: the slots of problem 0
+ *   predict   mean_out, var_out: M doubles (NOT B x M) -- the posterior of the full model at Xs
+ * mask = 0 switches back.  Double precision only. */
+int gpimhip_set_reflection(gpimhip_handle h, int32_t mask, const double* twoc);
+
 /* Batch thinning of boptimizer.update_points (gpim/gpbayes/boptim.py:326-376): among n <= 1024 ranked
  * candidates (vals, flat grid indices into a d-dimensional grid of the given shape) repeatedly keep the
  * largest remaining value and drop every candidate within Euclidean index distance <= dscale of it

@@ -1,0 +1,91 @@
+"""
+Symmetry-reduced exact GP on complete grids (reconstructor(structured=True) with Matern52 / RationalQuadratic; role of the
+reference's structured class gpim/gpreg/skgpr.py:399-448, exact instead of interpolated) against the DENSE oracle: the
+reflection-adapted basis is an orthogonal change of basis, so losses, hyper-parameter histories and posteriors must
+agree with the dense model to rounding.
+"""
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose
+
+pytestmark = pytest.mark.gpu
+
+from oracle import gpim_oracle as O
+
+
+@pytest.fixture(scope="module")
+def gpim(ensure_built):
+    import gpim_amd
+    return gpim_amd
+
+
+def _image(shape, seed):
+    rng = np.random.default_rng(seed)
+    grids = np.meshgrid(*[np.arange(n, dtype=np.float64) for n in shape], indexing="ij")
+    R = np.ones(shape)
+    for k, g in enumerate(grids):
+        R = R * np.cos(g / (2.0 + k) + 0.3 * k)
+    return R + 0.05 * rng.standard_normal(shape)
+
+
+@pytest.mark.parametrize("shape,kernel,kw", [
+    ((12, 10), "Matern52", dict(lengthscale=[[1., 1.], [6., 6.]])),          # both axes reflected: 4 blocks of 30
+    ((12, 9), "Matern52", dict(lengthscale=[[1., 1.], [6., 6.]])),           # one even axis: 2 blocks of 54
+    ((18, 16), "RationalQuadratic", dict(lengthscale=[[1., 1.], [8., 8.]])),  # 4 blocks of 72
+    ((6, 4, 8), "Matern52", dict(lengthscale=[[1., 1., 1.], [4., 4., 4.]])),  # 3-D: 8 blocks of 24
+    ((16, 14), "Matern52", dict(lengthscale=[1., 6.], isotropic=True)),
+])
+def test_symmetry_reduced_vs_dense_oracle(gpim, shape, kernel, kw):
+    R = _image(shape, seed=len(shape) + shape[0])
+    X = gpim.utils.get_full_grid(R)
+    T = 12
+    args = dict(kernel=kernel, learning_rate=0.1, iterations=T, verbose=0, **kw)
+    rec = gpim.reconstructor(X, R, X, structured=True, **args)
+    assert rec.do_symm and not rec.do_structured
+    mean, sd, hyper = rec.run()
+    mo, so, ho = O.reconstructor(X, R, X, **args).run()
+    assert_allclose(rec.loss_all, O_losses(X, R, args), rtol=1e-10)
+    for k in ("lengthscale", "noise", "variance"):
+        assert_allclose(np.asarray(hyper[k], dtype=float), np.asarray(ho[k], dtype=float), rtol=1e-8)
+    assert np.abs(mean - mo).max() < 1e-8 and np.abs(sd - so).max() < 1e-8
+    # the dense HIP path gives the same answers
+    md, sdd, hd = gpim.reconstructor(X, R, X, **args).run()
+    assert np.abs(mean - md).max() < 1e-8 and np.abs(sd - sdd).max() < 1e-8
+    # prediction at points off the grid (no product structure needed)
+    Xoff = np.stack([g.ravel()[:50] + 0.37 for g in X]).reshape((len(shape), 50))
+    m2, s2 = rec.predict(Xoff)
+    orc = O.reconstructor(X, R, X, **args)
+    orc.train()
+    m2o, s2o = orc.predict(Xoff)
+    assert np.abs(m2 - m2o).max() < 1e-8 and np.abs(s2 - s2o).max() < 1e-8
+
+
+def test_symmetry_reduced_64x64_vs_dense_oracle(gpim):
+    """A 64 x 64 image (N = 4096: four blocks of 1024, the blocked general path with eight block columns)."""
+    R = _image((64, 64), seed=5)
+    X = gpim.utils.get_full_grid(R)
+    args = dict(kernel="Matern52", lengthscale=[[1., 1.], [20., 20.]], learning_rate=0.1, iterations=3, verbose=0)
+    rec = gpim.reconstructor(X, R, X, structured=True, **args)
+    mean, sd, hyper = rec.run()
+    import torch
+    torch.set_num_threads(min(32, torch.get_num_threads() * 32))
+    orc = O.reconstructor(X, R, X, **args)
+    mo, so, ho = orc.run()
+    torch.set_num_threads(1)
+    assert_allclose(rec.loss_all, orc.loss_all, rtol=1e-10)
+    for k in ("lengthscale", "noise", "variance"):
+        assert_allclose(np.asarray(hyper[k], dtype=float), np.asarray(ho[k], dtype=float), rtol=1e-8)
+    assert np.sqrt(np.mean((mean - mo) ** 2)) < 1e-8 and np.sqrt(np.mean((sd - so) ** 2)) < 1e-8
+
+
+def O_losses(X, R, args):
+    orc = O.reconstructor(X, R, X, **args)
+    orc.train()
+    return np.asarray(orc.loss_all, dtype=float)
+
+
+def test_symmetry_reduced_needs_an_even_axis(gpim):
+    R = _image((9, 7), 1)
+    X = gpim.utils.get_full_grid(R)
+    with pytest.raises(NotImplementedError):
+        gpim.reconstructor(X, R, X, structured=True, kernel="Matern52", verbose=0)
