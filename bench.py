@@ -317,6 +317,38 @@ def extra_configs(gpim):
                                               "(reconstructor(structured=True)), RBF, T=200",
                                   "seconds": dt, "grid_points_per_s": cube4.size / dt,
                                   "ms_per_adam_iteration": dt / (5 * 200) * 1e3}
+    # the COMPLETE 256x256 image (N = M = 65536, Matern52) as one exact GP: the symmetry-reduced structured solver
+    # (reconstructor(structured=True): four reflection blocks of 16384 points in one lock-step batch) next to the dense
+    # distributed driver on the same GPU (dist_chol.exact_gp_fit, P = 1)
+    from problems import lattice_image as _li
+    from gpim_amd.dist_chol import exact_gp_fit
+    Rc, _ = _li(size=WORKLOAD["size"], frac=1.0, seed=1)
+    Xc = gpim.utils.get_full_grid(Rc)
+    kwc = dict(kernel=WORKLOAD["kernel"], lengthscale=WORKLOAD["lengthscale"], learning_rate=WORKLOAD["learning_rate"], verbose=0)
+    rc_ = gpim.reconstructor(Xc, Rc, Xc, structured=True, iterations=2, **kwc)
+    rc_.train()
+    sync(); t0 = time.perf_counter()
+    rc_.train(iterations=5)
+    sync(); t_it = (time.perf_counter() - t0) / 5
+    t0 = time.perf_counter()
+    rc_.predict()
+    sync(); t_pr = time.perf_counter() - t0
+    loss_s = list(rc_.loss_all[2:4])
+    del rc_
+    gc_ = __import__("gc"); gc_.collect(); torch.cuda.empty_cache()
+    ii, jj = np.meshgrid(np.arange(Rc.shape[0], dtype=np.float64), np.arange(Rc.shape[1], dtype=np.float64), indexing="ij")
+    Xf_, yf_ = np.stack([ii.ravel(), jj.ravel()], 1), Rc.ravel()
+    sync(); t0 = time.perf_counter()
+    hyp_d, _ = exact_gp_fit(Xf_, yf_, iterations=2, kernel=WORKLOAD["kernel"], lengthscale=WORKLOAD["lengthscale"],
+                            learning_rate=WORKLOAD["learning_rate"])
+    sync(); t_dense = (time.perf_counter() - t0) / 2
+    gc_.collect(); torch.cuda.empty_cache()
+    out["C2_complete_structured"] = {
+        "workload": "the complete 256x256 image (N = M = 65536), Matern52: reconstructor(structured=True) -- four reflection "
+                    "blocks of 16384 points, one lock-step batch with shared hyper-parameters; exact",
+        "seconds_per_adam_iteration": t_it, "predict_seconds": t_pr,
+        "dense_seconds_per_adam_iteration": t_dense, "speedup_over_dense": t_dense / t_it,
+        "loss_first_two_iterations": loss_s, "dense_loss_first_two_iterations": [float(v) for v in hyp_d["loss"][:2]]}
     # C2 in single precision: the headline workload with reconstructor(precision='single') (float matrices, fp32
     # matrix cores; gpimhip_set_precision) -- NOT the headline number, whose dtype is the reference's default f64
     from problems import lattice_image

@@ -966,26 +966,28 @@ int launch_dist_finalize(gpimhip_ctx* h, const gpimhip_model_t* m, int64_t N, co
 struct ReflPair {
     double dm2[GPIMHIP_MAX_DIM], dp2[GPIMHIP_MAX_DIM];       // squared scaled differences to z and to its mirror image
 };
-// sum over the reflections: acc(g, chi, r2) for every subset g of mask
-template <typename F>
-__device__ __forceinline__ void refl_for_each(const ReflPair& p, int mask, int pb, int d, F f) {
-    double base = 0.0;
-    int dims[GPIMHIP_MAX_DIM], nref = 0;
-    for (int k = 0; k < GPIMHIP_MAX_DIM; ++k) {
-        if (k >= d) continue;
-        if ((mask >> k) & 1) dims[nref++] = k;
-        else base += p.dm2[k];
-    }
-    for (int g = 0; g < (1 << nref); ++g) {
-        double r2 = base;
-        int gm = 0;
-        for (int j = 0; j < nref; ++j) {
-            const bool refl = (g >> j) & 1;
-            r2 += refl ? p.dp2[dims[j]] : p.dm2[dims[j]];
-            gm |= refl ? (1 << dims[j]) : 0;
+// the dimensions whose sign is -1 in the block of problem pb: bit j of pb belongs to the j-th reflected dimension
+__device__ __forceinline__ int refl_sign_dims(int mask, int pb) {
+    int sg = 0, j = 0;
+#pragma unroll
+    for (int k = 0; k < GPIMHIP_MAX_DIM; ++k)
+        if ((mask >> k) & 1) {
+            if ((pb >> j) & 1) sg |= 1 << k;
+            ++j;
         }
-        const double chi = (__popc(g & pb) & 1) ? -1.0 : 1.0;
-        f(gm, chi, r2);
+    return sg;
+}
+// f(g, chi, r2) for every reflection g (a subset of mask, as a bit mask over the dimensions); constant trip counts and a
+// wave-uniform skip, so that everything stays in registers (unused dimensions hold zeros in p)
+template <typename F>
+__device__ __forceinline__ void refl_for_each(const ReflPair& p, int mask, int sg, F f) {
+#pragma unroll
+    for (int g = 0; g < (1 << GPIMHIP_MAX_DIM); ++g) {
+        if (g & ~mask) continue;
+        double r2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < GPIMHIP_MAX_DIM; ++k) r2 += ((g >> k) & 1) ? p.dp2[k] : p.dm2[k];
+        f(g, (__popc(g & sg) & 1) ? -1.0 : 1.0, r2);
     }
 }
 template <int KIND>
@@ -995,12 +997,15 @@ __global__ __launch_bounds__(256) void kmat_refl_kernel(const double* __restrict
                                                         ReflArgs refl, double scale) {
     __shared__ double xa[128][4];
     __shared__ double xz[128][4];
-    const int tid = threadIdx.x, pb = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int sg = refl_sign_dims(refl.mask, blockIdx.y);
     X += blockIdx.y * x_bs;
     Z += blockIdx.y * z_bs;
     th += blockIdx.y;
     out += blockIdx.y * out_bs;
-    const int ci = blockIdx.x / ntc, cj = blockIdx.x % ntc;
+    int ci, cj;
+    if (sym) lower_tile_from_linear(blockIdx.x, ci, cj);       // (the factorisation reads the lower tiles only)
+    else { ci = blockIdx.x / ntc; cj = blockIdx.x % ntc; }
     const ThetaDev t = *th;
     {
         const bool isrow = tid < 128;
@@ -1009,30 +1014,41 @@ __global__ __launch_bounds__(256) void kmat_refl_kernel(const double* __restrict
         const double* src = isrow ? X : Z;
         const int64_t lim = isrow ? N : M;
         double (*dst)[4] = isrow ? xa : xz;
+#pragma unroll
         for (int k = 0; k < GPIMHIP_MAX_DIM; ++k) dst[loc][k] = (k < d && g < lim) ? src[g * d + k] / t.ls[k] : 0.0;
     }
     __syncthreads();
     double cz[GPIMHIP_MAX_DIM];
-    for (int k = 0; k < GPIMHIP_MAX_DIM; ++k) cz[k] = refl.twoc[k] / t.ls[k];
+#pragma unroll
+    for (int k = 0; k < GPIMHIP_MAX_DIM; ++k) cz[k] = (k < d) ? refl.twoc[k] / t.ls[k] : 0.0;
     const int ty = tid >> 4, tx = tid & 15;
     for (int rr = 0; rr < 8; ++rr) {
         const int r = ty + 16 * rr;
         const int64_t gi = (int64_t)ci * 128 + r;
-        for (int cc = 0; cc < 8; ++cc) {
-            const int c = tx + 16 * cc;
-            const int64_t gj = (int64_t)cj * 128 + c;
-            ReflPair p;
-            for (int k = 0; k < GPIMHIP_MAX_DIM; ++k) {
-                const double dm = xa[r][k] - xz[c][k], dp = (xa[r][k] + xz[c][k]) - cz[k];
-                p.dm2[k] = dm * dm;
-                p.dp2[k] = dp * dp;
+        const double a0 = xa[r][0], a1 = xa[r][1], a2 = xa[r][2], a3 = xa[r][3];
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+            d2 v;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int c = tx * 2 + 32 * cc + e;
+                const int64_t gj = (int64_t)cj * 128 + c;
+                const double av[4] = {a0, a1, a2, a3};
+                ReflPair p;
+#pragma unroll
+                for (int k = 0; k < GPIMHIP_MAX_DIM; ++k) {
+                    const double dm = av[k] - xz[c][k], dp = (av[k] + xz[c][k]) - cz[k];
+                    p.dm2[k] = dm * dm;
+                    p.dp2[k] = dp * dp;
+                }
+                double acc = 0.0;
+                refl_for_each(p, refl.mask, sg, [&](int, double chi, double r2) { acc = fma(chi, kfun_value<KIND>(r2, t.alpha), acc); });
+                double k = scale * t.var * acc;
+                if (gi >= N || gj >= M) k = (sym && gi == gj) ? 1.0 : 0.0;
+                else if (sym && gi == gj) k += t.diag_add;
+                v[e] = k;
             }
-            double acc = 0.0;
-            refl_for_each(p, refl.mask, pb, d, [&](int, double chi, double r2) { acc += chi * kfun_value<KIND>(r2, t.alpha); });
-            double k = scale * t.var * acc;
-            if (gi >= N || gj >= M) k = (sym && gi == gj) ? 1.0 : 0.0;
-            else if (sym && gi == gj) k += t.diag_add;
-            out[gi * ld + gj] = k;
+            *reinterpret_cast<d2*>(out + gi * ld + (int64_t)cj * 128 + tx * 2 + 32 * cc) = v;
         }
     }
 }
@@ -1043,7 +1059,7 @@ int launch_kmat_refl(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X, 
     if (ntr <= 0 || ntc <= 0) return GPIMHIP_OK;
     const double* Zp = Z ? Z : X;
     if (!Z) z_bs = x_bs;
-    dim3 grid((unsigned)(ntr * ntc), h->nbatch), block(256);
+    dim3 grid((unsigned)(sym ? ntr * (ntr + 1) / 2 : ntr * ntc), h->nbatch), block(256);
 #define KR_LAUNCH(KIND)                                                                                                 \
     hipLaunchKernelGGL((kmat_refl_kernel<KIND>), grid, block, 0, h->stream, X, N, Zp, M, m->dim, theta, out, ld, ntc, sym, x_bs, \
                        z_bs, out_bs, h->refl, scale)
@@ -1070,7 +1086,8 @@ __global__ __launch_bounds__(256) void grad_reduce_refl_kernel(const double* __r
     __shared__ double xz[128][4];
     __shared__ double al_r[128], al_c[128];
     __shared__ double red[4][8];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, pb = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sg = refl_sign_dims(refl.mask, blockIdx.y);
     Kinv += blockIdx.y * np * ld;
     X += blockIdx.y * x_bs;
     alpha += blockIdx.y * np;
@@ -1108,11 +1125,12 @@ __global__ __launch_bounds__(256) void grad_reduce_refl_kernel(const double* __r
                 p.dm2[k] = dm * dm;
                 p.dp2[k] = dp * dp;
             }
-            refl_for_each(p, refl.mask, pb, d, [&](int gm, double chi, double r2) {
+            refl_for_each(p, refl.mask, sg, [&](int gm, double chi, double r2) {
                 const KVal kv = kfun_grad<KIND>(r2, t.alpha);
                 const double wc = w * chi;
                 S[0] = fma(wc, kv.e, S[0]);
                 const double wh = wc * kv.h;
+#pragma unroll
                 for (int k = 0; k < GPIMHIP_MAX_DIM; ++k) S[1 + k] = fma(wh, ((gm >> k) & 1) ? p.dp2[k] : p.dm2[k], S[1 + k]);
                 if (KIND == GPIMHIP_KERNEL_RQ) S[6] = fma(wc, kv.ga, S[6]);
             });
