@@ -333,7 +333,7 @@ def extra_configs(gpim):
     t0 = time.perf_counter()
     rc_.predict()
     sync(); t_pr = time.perf_counter() - t0
-    loss_s = list(rc_.loss_all[2:4])
+    loss_s = list(rc_.loss_all[0:2])
     del rc_
     gc_ = __import__("gc"); gc_.collect(); torch.cuda.empty_cache()
     ii, jj = np.meshgrid(np.arange(Rc.shape[0], dtype=np.float64), np.arange(Rc.shape[1], dtype=np.float64), indexing="ij")
