@@ -429,6 +429,9 @@ static int tri_nodes(int lo, int hi, std::vector<TriNodeS>& nodes) {
 // (Round 3 drew the lines at 128 / 512 tiles of average depth 5; tools/r3_exp*.sh.)
 // (Round 4 re-measured the first line with deepest-first lists: 2000 instead of 700 -- N = 6000 5.50 -> 5.43 ms per Adam
 // iteration, 8192 11.57 -> 11.43, 12288 33.27 -> 32.97, 16384 72.56 -> 72.28; 1100 / 1500 / 2400 / 2800 lie between.)
+#ifndef BATCH_QUAD_MAX
+#define BATCH_QUAD_MAX 700
+#endif
 static int host_shape(int64_t update_kblocks, int quad_max = 2000) { return update_kblocks <= quad_max ? 4 : (update_kblocks <= 2800 ? 2 : 1); }
 
 // pair[L] (out): the step launch L runs its hosted quadrants two per CU (launch_step) -- decided here from the update
@@ -728,7 +731,7 @@ int launch_potrf_steps(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_
             a.g.rag = rag;
             // a large batch is bound by throughput: every hosted k-block counts (P.n_all), not only the trailing update's
             // (batches: 700 / 2800 re-measured on C3 against 300, 2000, 4000 / 1500, 6000 -- the defaults stay)
-            q = B > host_max_batch ? host_shape((int64_t)P.n_all[j] * problems, 700) : host_shape((int64_t)P.n_update[j] * problems);
+            q = B > host_max_batch ? host_shape((int64_t)P.n_all[j] * problems, BATCH_QUAD_MAX) : host_shape((int64_t)P.n_update[j] * problems);
             return nf;
         };
         if (B > host_max_batch) {
