@@ -91,6 +91,28 @@ __device__ __forceinline__ double frag_mk_swz(const double* lds, int m0, int kk,
     return lds[(m >> 3) * MK_GROUP + ((m & 7) * 8 + ((k >> 1) ^ (m & 7))) * 2 + (k & 1)];
 }
 
+// Fragments of TWO k-steps per LDS instruction.  The four k-steps of a 16-deep stage may visit its 16 k-values in any order
+// as long as both operands use the same one; with  kappa(s, kq) = 8 (s >> 1) + 2 kq + (s & 1)  (k-step s, kq = lane >> 4)
+// a lane's values for the steps 2h and 2h + 1 are the aligned pair k = 8 h + 2 kq, + 1 -- one 16-byte chunk of a
+// k-contiguous ("MK") operand row, i.e. one ds_read_b128 instead of two ds_read_b64 (the swizzle keeps a chunk whole).
+// An LDS instruction costs its SIMD 10-25 cycles of MFMA issue whichever wave it comes from (tools/r5_trail_probe.hip);
+// the 8-wave shapes hosted by the Cholesky step kernel issue 0.75-1.5 fragment reads per MFMA.  m-contiguous ("KM")
+// operands follow the same k order with single reads.
+__device__ __forceinline__ d2 frag2_mk_swz(const double* lds, int m0, int h, int lane) {
+    const int m = m0 + (lane & 15), kq = lane >> 4;
+    return *reinterpret_cast<const d2*>(lds + (m >> 3) * MK_GROUP + ((m & 7) * 8 + ((4 * h + kq) ^ (m & 7))) * 2);
+}
+template <int TS>
+__device__ __forceinline__ d2 frag2_km(const double* lds, int m0, int h, int lane) {
+    const int k = 8 * h + 2 * (lane >> 4), m = m0 + (lane & 15);
+    return (d2){lds[k * (TS + 16) + m], lds[(k + 1) * (TS + 16) + m]};
+}
+template <bool KM, int TS>
+__device__ __forceinline__ d2 frag2(const double* lds, int m0, int h, int lane) {
+    if (KM) return frag2_km<TS>(lds, m0, h, lane);
+    return frag2_mk_swz(lds, m0, h, lane);
+}
+
 template <bool KM, int NW, int TS>
 __device__ __forceinline__ void stage_direct(const double* __restrict__ base, int64_t ld, int64_t mrow0, int64_t kcol0,
                                              double* lds, int wave, int lane) {
@@ -248,19 +270,19 @@ __device__ __forceinline__ void gemm_tile_core(GemmArgs g, TileDesc t, const int
             __builtin_amdgcn_s_setprio(3);
             if (!RAG || !dead) {
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                double a[MT], bb[NTL];
+            for (int h = 0; h < 2; ++h) {
+                d2 a[MT], bb[NTL];
 #pragma unroll
-                for (int i = 0; i < MT; ++i)
-                    a[i] = (!A_KM) ? frag_mk_swz(As, wm * WROWS + i * 16, kk, lane) : frag<A_KM, TSM>(As, wm * WROWS + i * 16, kk, lane);
+                for (int i = 0; i < MT; ++i) a[i] = frag2<A_KM, TSM>(As, wm * WROWS + i * 16, h, lane);
 #pragma unroll
-                for (int j = 0; j < NTL; ++j)
-                    bb[j] = (!B_KM) ? frag_mk_swz(Bs, wn * WCOLS + j * 16, kk, lane) : frag<B_KM, TSN>(Bs, wn * WCOLS + j * 16, kk, lane);
+                for (int j = 0; j < NTL; ++j) bb[j] = frag2<B_KM, TSN>(Bs, wn * WCOLS + j * 16, h, lane);
 #pragma unroll
-                for (int i = 0; i < MT; ++i)
+                for (int e = 0; e < 2; ++e)
 #pragma unroll
-                    for (int j = 0; j < NTL; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bb[j], acc[i][j], 0, 0, 0);
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < NTL; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][e], bb[j][e], acc[i][j], 0, 0, 0);
             }
             }
             __builtin_amdgcn_s_setprio(0);
@@ -313,6 +335,9 @@ __device__ __forceinline__ void gemm_tile_core(GemmArgs g, TileDesc t, const int
             // issue slots from the matrix pipe (tools/gemm_ablate.hip: 66.1 -> 71.2 TFLOP/s for this loop).
             __builtin_amdgcn_s_setprio(3);
             if (!RAG || !dead) {
+            // (pairs for the 8-wave shapes only: the 4-wave shapes issue 0.5 fragment reads per MFMA and measured 0.2 % slower
+            // with them at N = 16384 -- K^-1 product, variance product, the launches after the last step)
+            if constexpr (NW != 8) {
     #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 double a[MT], bb[NTL];
@@ -335,6 +360,30 @@ __device__ __forceinline__ void gemm_tile_core(GemmArgs g, TileDesc t, const int
     #pragma unroll
                     for (int j = 0; j < NTL; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bb[j], acc[i][j], 0, 0, 0);
+            }
+            } else {
+    #pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                d2 a[MT], bb[NTL];
+                if (false) {
+    #pragma unroll
+                    for (int i = 0; i < MT; ++i) a[i] = a0[i];
+    #pragma unroll
+                    for (int j = 0; j < NTL; ++j) bb[j] = b0[j];
+                } else {
+    #pragma unroll
+                    for (int i = 0; i < MT; ++i) a[i] = frag2<A_KM, TSM>(As, wm * WROWS + i * 16, h, lane);
+    #pragma unroll
+                    for (int j = 0; j < NTL; ++j) bb[j] = frag2<B_KM, TSN>(Bs, wn * WCOLS + j * 16, h, lane);
+                }
+    #pragma unroll
+                for (int e = 0; e < 2; ++e)
+    #pragma unroll
+                    for (int i = 0; i < MT; ++i)
+    #pragma unroll
+                        for (int j = 0; j < NTL; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][e], bb[j][e], acc[i][j], 0, 0, 0);
+            }
             }
             }
             __builtin_amdgcn_s_setprio(0);
