@@ -604,6 +604,8 @@ __device__ __forceinline__ void lds_factor_inv(double* D, double* invd, double* 
         }
         __syncthreads();
     }
+    d4 s0 = zero;                    // wave 0: its solved tile across the solve phase's barrier (the diagonal tile it updates
+                                     // is NOT prefetched across it: eight more live registers slow chol16_lp by 0.3K cycles per tile)
     d4 keep[2] = {zero, zero};       // tiles of block row p-1 of X, carried into step p
     unsigned long long held = 0xFF;  // which ones (the two low fields of the plan word of the step that formed them)
     for (int p = 0; p <= npan; ++p) {
@@ -628,14 +630,12 @@ __device__ __forceinline__ void lds_factor_inv(double* D, double* invd, double* 
                     sink.tile(t, p, acc, lane);
 #endif
                 } else {
-                    // acc[s] = S[r][kappa(s, kq)] is also the operand fragment s of the solved tile: the tile the next 16x16
-                    // factorisation waits for is updated from these registers (wave 0 waits for the other waves' solves only
-                    // before chol16_lp)
-                    d4 c = tile_read<Lay>(D + Lay::tile(t, t), lane);
-#pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4) c = __builtin_amdgcn_mfma_f64_16x16x4f64(-acc[s4], acc[s4], c, 0, 0, 0);
+                    // acc[s] = S[r][kappa(s, kq)] is also the operand fragment s of the solved tile: wave 0 updates the tile its
+                    // next 16x16 factorisation waits for from these registers -- AFTER the barrier that ends the solve phase
+                    // (nobody else touches that tile), so that the other waves' update phase starts ~0.5K cycles earlier: the
+                    // steps are bound by the workers, not by wave 0's chain
                     fi_frag_store<Lay>(C, r, kq, acc);
-                    tile_write<Lay>(D + Lay::tile(t, t), c, lane);
+                    s0 = acc;
                 }
             }
             // the tiles of block row p-1 of X held in registers since the previous step
@@ -687,6 +687,13 @@ __device__ __forceinline__ void lds_factor_inv(double* D, double* invd, double* 
                 else fi_trail2<Lay, false>(D, p, rtA, ctA, rtB, ctB, lane);
             }
             WSTAMP(p, 2);
+        }
+        if (wave == 0 && !lastp) {
+            double* Cd = D + Lay::tile(p + 1, p + 1);
+            d4 c = tile_read<Lay>(Cd, lane);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) c = __builtin_amdgcn_mfma_f64_16x16x4f64(-s0[s4], s0[s4], c, 0, 0, 0);
+            tile_write<Lay>(Cd, c, lane);
         }
         if (wave == 0 && !lastp && !(FI_EXP & 1)) {
             FSTAMP(8 * p + 3);

@@ -13,6 +13,6 @@ gd.reconstruct_slices(R[..., :$B], axis=-1, batch=$B, batch_concurrency=1, **kw)
 PY
 GPIMHIP_NO_GRAPH=1 timeout 200 rocprofv3 --kernel-trace --output-format csv -d $O/kt -- python /tmp/c3t.py > $O/log.txt 2>&1
 f=$(find $O/kt -name '*kernel_trace.csv' | head -1)
-python $GRAFT_REPO_ROOT/tools/r4_kt_iter.py $f 200 > $O/iter.txt 2>&1
+python $GRAFT_REPO_ROOT/tools/r4_kt_iter.py $f 200 1 > $O/iter.txt 2>&1
 rm -rf $O/kt
 head -80 $O/iter.txt
