@@ -451,7 +451,7 @@ static bool plan_inverse(int nb, std::vector<std::vector<TileDesc>>& fill, std::
     size_t open_nodes = 0;
     for (auto& n : nodes) open_nodes += (n.height > 0);
 #ifndef PLAN_CHAIN
-#define PLAN_CHAIN 0.9
+#define PLAN_CHAIN 0.8
 #endif
     const double CHAIN = PLAN_CHAIN;                   // length of the factorisation role in cost units
     for (int L = 0; open_nodes > 0; ++L) {
