@@ -1426,14 +1426,16 @@ int gpimhip_dist_finalize_dev(gpimhip_handle h, const gpimhip_model_t* m, int64_
     return launch_dist_finalize_dev(h, m, N, red, quad, u, t > 0 ? 1 : 0, st, loss_out, grad_out, hist_row);
 }
 
-int gpimhip_set_reflection(gpimhip_handle h, int32_t mask, const double* twoc) {
-    if (!h || mask < 0 || mask >= (1 << GPIMHIP_MAX_DIM) || (mask && !twoc)) return GPIMHIP_E_BADARG;
+int gpimhip_set_reflection(gpimhip_handle h, int32_t mask, const double* twoc, const double* wts, int64_t n_total) {
+    if (!h || mask < 0 || mask >= (1 << GPIMHIP_MAX_DIM) || (mask && !twoc) || n_total < 0) return GPIMHIP_E_BADARG;
     if (mask && h->fp32) {
         gpim_set_error("the symmetry-reduced model computes in double precision");
         return GPIMHIP_E_BADARG;
     }
     h->refl.mask = mask;
     for (int k = 0; k < GPIMHIP_MAX_DIM; ++k) h->refl.twoc[k] = mask ? twoc[k] : 0.0;
+    h->refl.wts = mask ? wts : nullptr;
+    h->refl.n_total = mask ? n_total : 0;
     return GPIMHIP_OK;
 }
 

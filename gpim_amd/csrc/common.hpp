@@ -102,12 +102,17 @@ struct DistPlan {
 // Reflection symmetry of a complete, uniform grid under a stationary kernel that is even in every coordinate difference
 // (gpimhip_set_reflection; engine.hip: kmat_refl_kernel): mask = the reflected dimensions (bit k), twoc[k] = first + last
 // coordinate of dimension k, so that the mirror image of z_k is twoc[k] - z_k.
+// wts (optional, device, B x N): per block and point 1 / sqrt(|stabiliser|) -- 1 off the mirror planes, 2^-1/2 on one
+// plane (axes of odd length), ... -- and 0 where the point does not exist in that block (a point on the mirror plane of
+// an axis whose sign is -1): such rows are identity rows of K_s.  n_total: the number of observations of the full model.
 struct ReflArgs {
     int mask;
     double twoc[GPIMHIP_MAX_DIM];
+    const double* wts;
+    int64_t n_total;
 };
 struct gpimhip_ctx {
-    ReflArgs refl = {0, {0, 0, 0, 0}};
+    ReflArgs refl = {0, {0, 0, 0, 0}, nullptr, 0};
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t capture_stream = nullptr; // internal stream used only to capture one iteration into a hipGraph

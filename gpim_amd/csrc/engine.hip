@@ -997,12 +997,14 @@ __global__ __launch_bounds__(256) void kmat_refl_kernel(const double* __restrict
                                                         ReflArgs refl, double scale) {
     __shared__ double xa[128][4];
     __shared__ double xz[128][4];
+    __shared__ double wr_s[128], wc_s[128];
     const int tid = threadIdx.x;
     const int sg = refl_sign_dims(refl.mask, blockIdx.y);
     X += blockIdx.y * x_bs;
     Z += blockIdx.y * z_bs;
     th += blockIdx.y;
     out += blockIdx.y * out_bs;
+    const double* wts = refl.wts ? refl.wts + (int64_t)blockIdx.y * N : nullptr;
     int ci, cj;
     if (sym) lower_tile_from_linear(blockIdx.x, ci, cj);       // (the factorisation reads the lower tiles only)
     else { ci = blockIdx.x / ntc; cj = blockIdx.x % ntc; }
@@ -1016,6 +1018,8 @@ __global__ __launch_bounds__(256) void kmat_refl_kernel(const double* __restrict
         double (*dst)[4] = isrow ? xa : xz;
 #pragma unroll
         for (int k = 0; k < GPIMHIP_MAX_DIM; ++k) dst[loc][k] = (k < d && g < lim) ? src[g * d + k] / t.ls[k] : 0.0;
+        // weights of the block's points (rows; the columns too when they are the same points)
+        (isrow ? wr_s : wc_s)[loc] = (wts && (isrow || sym) && g < lim) ? wts[g] : 1.0;
     }
     __syncthreads();
     double cz[GPIMHIP_MAX_DIM];
@@ -1043,8 +1047,9 @@ __global__ __launch_bounds__(256) void kmat_refl_kernel(const double* __restrict
                 }
                 double acc = 0.0;
                 refl_for_each(p, refl.mask, sg, [&](int, double chi, double r2) { acc = fma(chi, kfun_value<KIND>(r2, t.alpha), acc); });
-                double k = scale * t.var * acc;
-                if (gi >= N || gj >= M) k = (sym && gi == gj) ? 1.0 : 0.0;
+                const double ww = wr_s[r] * wc_s[c];
+                double k = scale * t.var * acc * ww;
+                if (gi >= N || gj >= M || (sym && ww == 0.0)) k = (sym && gi == gj) ? 1.0 : 0.0;      // padding / absent points
                 else if (sym && gi == gj) k += t.diag_add;
                 v[e] = k;
             }
@@ -1085,9 +1090,11 @@ __global__ __launch_bounds__(256) void grad_reduce_refl_kernel(const double* __r
     __shared__ double xa[128][4];
     __shared__ double xz[128][4];
     __shared__ double al_r[128], al_c[128];
+    __shared__ double wr_s[128], wc_s[128];
     __shared__ double red[4][8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int sg = refl_sign_dims(refl.mask, blockIdx.y);
+    const double* wts = refl.wts ? refl.wts + (int64_t)blockIdx.y * N : nullptr;
     Kinv += blockIdx.y * np * ld;
     X += blockIdx.y * x_bs;
     alpha += blockIdx.y * np;
@@ -1103,6 +1110,7 @@ __global__ __launch_bounds__(256) void grad_reduce_refl_kernel(const double* __r
         double (*dst)[4] = isrow ? xa : xz;
         for (int k = 0; k < GPIMHIP_MAX_DIM; ++k) dst[loc][k] = (k < d && g < N) ? X[g * d + k] / t.ls[k] : 0.0;
         (isrow ? al_r : al_c)[loc] = (g < N) ? alpha[g] : 0.0;
+        (isrow ? wr_s : wc_s)[loc] = (wts && g < N) ? wts[g] : 1.0;
     }
     __syncthreads();
     double cz[GPIMHIP_MAX_DIM];
@@ -1118,7 +1126,9 @@ __global__ __launch_bounds__(256) void grad_reduce_refl_kernel(const double* __r
             const int64_t gj = (int64_t)cj * 128 + c;
             if (gi >= N || gj > gi) continue;
             const double g = Kinv[gi * ld + gj] - ali * al_c[c];
-            const double w = (gi == gj) ? g : 2.0 * g;
+            const double ww = wr_s[r] * wc_s[c];
+            if (ww == 0.0) continue;                   // (a point that does not exist in this block: an identity row)
+            const double w = ((gi == gj) ? g : 2.0 * g) * ww;
             ReflPair p;
             for (int k = 0; k < GPIMHIP_MAX_DIM; ++k) {
                 const double dm = xa[r][k] - xz[c][k], dp = (xa[r][k] + xz[c][k]) - cz[k];
@@ -1167,7 +1177,7 @@ int launch_grad_reduce_refl(gpimhip_ctx* h, const gpimhip_model_t* m, const doub
 }
 // finalize for the coupled blocks: the sums of all B problems (fixed order: problem by problem), ONE loss / gradient /
 // Adam step on the parameters of problem 0, which are then copied to the other problems' slots
-__global__ __launch_bounds__(256) void finalize_coupled_kernel(gpimhip_model_t m, int64_t N, int64_t np, int nb, int ntile, int B,
+__global__ __launch_bounds__(256) void finalize_coupled_kernel(gpimhip_model_t m, int64_t n_total, int64_t np, int nb, int ntile, int B,
                                                                const double* __restrict__ grad_part, const double* __restrict__ z,
                                                                const double* __restrict__ zb,
                                                                const double* __restrict__ logdet_part,
@@ -1210,7 +1220,7 @@ __global__ __launch_bounds__(256) void finalize_coupled_kernel(gpimhip_model_t m
         hist_row = fi.hist_base ? fi.hist_base + (int64_t)it * P : nullptr;
         *fi.iter = it + 1;
     }
-    finalize_step(m, N * B, S, q2, lg, *th, u, adam_m, adam_v, do_adam, st, loss_out, grad_out, hist_row, prior_constant(m));
+    finalize_step(m, n_total, S, q2, lg, *th, u, adam_m, adam_v, do_adam, st, loss_out, grad_out, hist_row, prior_constant(m));
     for (int b = 1; b < B; ++b)
         for (int k = 0; k < P; ++k) u[(int64_t)b * P + k] = u[k];
 }
@@ -1219,7 +1229,8 @@ int launch_finalize_coupled(gpimhip_ctx* h, const gpimhip_model_t* m, int64_t N,
                             const double* bc, int T, double* hist_base, double* loss_base) {
     const int nb = (int)(np / NB);
     FinalizeIter fi{iter, bc, T, hist_base, loss_base};
-    hipLaunchKernelGGL(finalize_coupled_kernel, dim3(1), dim3(256), 0, h->stream, *m, N, np, nb, nb * (nb + 1) / 2, h->nbatch,
+    hipLaunchKernelGGL(finalize_coupled_kernel, dim3(1), dim3(256), 0, h->stream, *m, h->refl.n_total > 0 ? h->refl.n_total : N * h->nbatch, np, nb,
+                       nb * (nb + 1) / 2, h->nbatch,
                        h->grad_part, h->z, h->fp32 ? h->alpha : h->z, h->logdet_part, h->theta, u, h->adam_m, h->adam_v, do_adam,
                        st, loss_out, grad_out, hist_row, fi, h->info);
     HIP_TRY(hipGetLastError());

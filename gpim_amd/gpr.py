@@ -129,9 +129,10 @@ class reconstructor:
             reference's structured-kernel ``skreconstructor`` (gpim/gpreg/skgpr.py), exact rather than
             interpolated.  With a kernel that does not factorise over the axes ('Matern52', 'RationalQuadratic') the
             reflection symmetry of the complete grid is used instead: in the basis adapted to the reflections of every
-            axis of EVEN length the covariance is block diagonal -- 2^r dense blocks of N / 2^r points, one lock-step
+            axis the covariance is block diagonal -- 2^r dense blocks of N / 2^r points, one lock-step
             batch with shared hyper-parameters (csrc/engine.hip: kmat_refl_kernel) -- 4^-r of the dense model's O(N^3)
-            work (1/16 for a 2-D image), the same model and results to rounding; predictions at arbitrary points.
+            work (1/16 for a 2-D image), the same model and results to rounding; predictions at arbitrary points.  Axes of
+            odd length are reflected too (their mirror plane belongs to the fundamental domain, with weights).
     """
 
     def __init__(self, X, y, Xtest=None, kernel='RBF', lengthscale=None, sparse=False,
@@ -238,42 +239,58 @@ class reconstructor:
 
     def _symm_setup(self, X, y):
         """The symmetry-reduced form of the model (csrc/engine.hip: kmat_refl_kernel): the fundamental domain of the
-        grid's reflections and the observations in the reflection-adapted basis."""
+        grid's reflections, the observations in the reflection-adapted basis and -- for axes of odd length, whose mirror
+        plane belongs to the domain -- the per-block weights of its points."""
         d = X.shape[0]
         mask, twoc, dims = 0, [0.0] * 4, []
         for k, c in enumerate(self._axes):
             n = len(c)
-            if n % 2 == 0 and n >= 2 and np.allclose(c + c[::-1], c[0] + c[-1], rtol=0, atol=1e-12 * max(1.0, abs(c[-1]))):
+            if n >= 2 and np.allclose(c + c[::-1], c[0] + c[-1], rtol=0, atol=1e-12 * max(1.0, abs(c[-1]), abs(c[0]))):
                 mask |= 1 << k
                 twoc[k] = float(c[0] + c[-1])
                 dims.append(k)
         if not dims:
-            raise NotImplementedError("structured=True with kernel %r needs at least one grid axis of even length with "
-                                      "symmetric coordinates" % (self._kernel_name,))
+            raise NotImplementedError("structured=True with kernel %r needs at least one grid axis with coordinates that are "
+                                      "symmetric about their centre" % (self._kernel_name,))
         B = 1 << len(dims)
-        fund = tuple(slice(0, y.shape[k] // 2) if k in dims else slice(None) for k in range(d))
+        fund = tuple(slice(0, (y.shape[k] + 1) // 2) if k in dims else slice(None) for k in range(d))
         Xq = X[(slice(None),) + fund].reshape(d, -1).T.copy()
-        ys = np.empty((B, Xq.shape[0]))
+        fshape = y[fund].shape
+        # on_plane[j]: the points of the domain that lie on the mirror plane of the j-th reflected axis (odd length only)
+        idx = np.indices(fshape)
+        on_plane = [(idx[k] == y.shape[k] // 2) & (y.shape[k] % 2 == 1) for k in dims]
+        nplanes = np.sum(on_plane, axis=0) if dims else np.zeros(fshape, dtype=int)
+        w_pt = 2.0 ** (-0.5 * nplanes)                      # 1 / sqrt(|stabiliser|)
+        ys, wts = np.empty((B, Xq.shape[0])), np.empty((B, Xq.shape[0]))
         for b in range(B):
-            acc = np.zeros(y[fund].shape)
+            acc = np.zeros(fshape)
             for g in range(B):
                 axes = tuple(dims[j] for j in range(len(dims)) if (g >> j) & 1)
                 chi = -1.0 if bin(g & b).count("1") & 1 else 1.0
                 acc += chi * (np.flip(y, axis=axes) if axes else y)[fund]
-            ys[b] = acc.reshape(-1) / np.sqrt(B)
-        self._symm = {"mask": mask, "twoc": (ctypes.c_double * 4)(*twoc), "B": B, "Xq": Xq, "ys": ys}
+            present = np.ones(fshape, dtype=bool)
+            for j in range(len(dims)):
+                if (b >> j) & 1:
+                    present &= ~on_plane[j]                 # antisymmetric along an axis: nothing on its mirror plane
+            wb = np.where(present, w_pt, 0.0)
+            ys[b] = (acc * wb).reshape(-1) / np.sqrt(B)
+            wts[b] = wb.reshape(-1)
+        odd = bool(nplanes.any())
+        self._symm = {"mask": mask, "twoc": (ctypes.c_double * 4)(*twoc), "B": B, "Xq": Xq, "ys": ys,
+                      "wts": wts if odd else None, "n_total": int(y.size)}
 
     def _symm_call(self, fn):
         """fn(Xq, ys, Nq, B, u_b) with the handle in reflection mode; the B parameter slots hold one vector."""
         S, lib, h = self._symm, self._handle.lib, self._handle.h
         if "Xq_d" not in S:
             S["Xq_d"], S["ys_d"] = self._to_device(S["Xq"]), self._to_device(S["ys"])
+            S["wts_d"] = self._to_device(S["wts"]) if S["wts"] is not None else None
         u_b = self._u.repeat(S["B"]).contiguous()
-        _lib.check(lib.gpimhip_set_reflection(h, S["mask"], S["twoc"]))
+        _lib.check(lib.gpimhip_set_reflection(h, S["mask"], S["twoc"], _lib.ptr(S["wts_d"]), S["n_total"]))
         try:
             rc = fn(S["Xq_d"], S["ys_d"], S["Xq_d"].shape[0], S["B"], u_b)
         finally:
-            _lib.check(lib.gpimhip_set_reflection(h, 0, None))
+            _lib.check(lib.gpimhip_set_reflection(h, 0, None, None, 0))
         self._u.copy_(u_b[:self._u.numel()])
         return rc
 

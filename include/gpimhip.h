@@ -347,7 +347,7 @@ int gpimhip_dist_finalize_dev(gpimhip_handle h, const gpimhip_model_t* m, int64_
 /* Symmetry-reduced exact GP on a COMPLETE uniform grid, for kernels that do not factorise over the axes (Matern52,
  * RationalQuadratic; RBF works too): the role of the reference's structured class (gpim/gpreg/skgpr.py:399-448 with
  * gpim/kernels/gpytorch_kernels.py:65), exact instead of interpolated.  mask: bit k = dimension k of the grid is
- * reflection-symmetric (its coordinates are first, first + step, ..., last with an EVEN count); twoc[k] = first + last.
+ * reflection-symmetric (its coordinates are symmetric about their centre); twoc[k] = first + last.
  * With a mask set, gpimhip_fit_exact_batched / gpimhip_predict_exact_batched / gpimhip_nll_grad-style calls treat the
  * B = 2^popcount(mask) problems of a batch as the diagonal blocks of ONE model in the reflection-adapted basis:
  *   X         the fundamental domain (the first half of every reflected axis): N / B points, shared (x_stride 0)
@@ -355,8 +355,13 @@ int gpimhip_dist_finalize_dev(gpimhip_handle h, const gpimhip_model_t* m, int64_
  *             j-th reflected dimension in ascending order carries sign -1)
  *   u         B copies of ONE parameter vector (all updated alike); hist_out / loss_out: the slots of problem 0
  *   predict   mean_out, var_out: M doubles (NOT B x M) -- the posterior of the full model at Xs
+ * Axes of ODD length: the fundamental domain includes the mirror plane; wts (device, B x (N / B rounded up to the domain's
+ * size), or NULL when every reflected axis is even) holds per block and point 2^(-m/2), m = the number of mirror planes the
+ * point lies on, and 0 for a point that does not exist in the block (it lies on the mirror plane of an axis whose sign is
+ * -1: its combination vanishes) -- such rows are identity rows of the block, and y of the block is 0 there.  n_total = the
+ * number of observations of the full model (0: B x N).
  * mask = 0 switches back.  Double precision only. */
-int gpimhip_set_reflection(gpimhip_handle h, int32_t mask, const double* twoc);
+int gpimhip_set_reflection(gpimhip_handle h, int32_t mask, const double* twoc, const double* wts, int64_t n_total);
 
 /* Batch thinning of boptimizer.update_points (gpim/gpbayes/boptim.py:326-376): among n <= 1024 ranked
  * candidates (vals, flat grid indices into a d-dimensional grid of the given shape) repeatedly keep the

@@ -138,12 +138,7 @@ def test_full_image_256_structured(gpim):
 def test_structured_rejects_what_it_cannot_do(gpim):
     R = smooth_grid((8, 8), seed=3)
     Xf = gpim.utils.get_full_grid(R)
-    # (Matern52 / RationalQuadratic on a complete grid go through the reflection blocks since round 5 -- test_gpu_symm.py --
-    # unless no axis has an even length)
-    R9 = smooth_grid((9, 7), seed=3)
-    with pytest.raises(NotImplementedError):
-        gpim.reconstructor(gpim.utils.get_full_grid(R9), R9, gpim.utils.get_full_grid(R9), kernel="Matern52", structured=True,
-                           verbose=0)
+    # (Matern52 / RationalQuadratic on a complete grid go through the reflection blocks since round 5: test_gpu_symm.py)
     Rn = R.copy()
     Rn[2, 3] = np.nan
     with pytest.raises(NotImplementedError):

@@ -30,7 +30,9 @@ def _image(shape, seed):
 
 @pytest.mark.parametrize("shape,kernel,kw", [
     ((12, 10), "Matern52", dict(lengthscale=[[1., 1.], [6., 6.]])),          # both axes reflected: 4 blocks of 30
-    ((12, 9), "Matern52", dict(lengthscale=[[1., 1.], [6., 6.]])),           # one even axis: 2 blocks of 54
+    ((12, 9), "Matern52", dict(lengthscale=[[1., 1.], [6., 6.]])),           # an odd axis: its mirror plane is in the domain
+    ((9, 7), "Matern52", dict(lengthscale=[[1., 1.], [5., 5.]])),            # both odd: points on one and on two planes
+    ((7, 6, 5), "RationalQuadratic", dict(lengthscale=[[1., 1., 1.], [4., 4., 4.]])),
     ((18, 16), "RationalQuadratic", dict(lengthscale=[[1., 1.], [8., 8.]])),  # 4 blocks of 72
     ((6, 4, 8), "Matern52", dict(lengthscale=[[1., 1., 1.], [4., 4., 4.]])),  # 3-D: 8 blocks of 24
     ((16, 14), "Matern52", dict(lengthscale=[1., 6.], isotropic=True)),
@@ -84,8 +86,10 @@ def O_losses(X, R, args):
     return np.asarray(orc.loss_all, dtype=float)
 
 
-def test_symmetry_reduced_needs_an_even_axis(gpim):
+def test_symmetry_reduced_needs_a_symmetric_axis(gpim):
     R = _image((9, 7), 1)
-    X = gpim.utils.get_full_grid(R)
+    X = gpim.utils.get_full_grid(R).astype(np.float64)
+    X[0] = X[0] ** 1.5                                      # neither axis is symmetric about its centre any more
+    X[1] = X[1] ** 1.5
     with pytest.raises(NotImplementedError):
         gpim.reconstructor(X, R, X, structured=True, kernel="Matern52", verbose=0)
