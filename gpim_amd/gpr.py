@@ -238,46 +238,13 @@ class reconstructor:
         return axes, (ctypes.c_int32 * d)(*[len(c) for c in axes])
 
     def _symm_setup(self, X, y):
-        """The symmetry-reduced form of the model (csrc/engine.hip: kmat_refl_kernel): the fundamental domain of the
-        grid's reflections, the observations in the reflection-adapted basis and -- for axes of odd length, whose mirror
-        plane belongs to the domain -- the per-block weights of its points."""
-        d = X.shape[0]
-        mask, twoc, dims = 0, [0.0] * 4, []
-        for k, c in enumerate(self._axes):
-            n = len(c)
-            if n >= 2 and np.allclose(c + c[::-1], c[0] + c[-1], rtol=0, atol=1e-12 * max(1.0, abs(c[-1]), abs(c[0]))):
-                mask |= 1 << k
-                twoc[k] = float(c[0] + c[-1])
-                dims.append(k)
-        if not dims:
-            raise NotImplementedError("structured=True with kernel %r needs at least one grid axis with coordinates that are "
-                                      "symmetric about their centre" % (self._kernel_name,))
-        B = 1 << len(dims)
-        fund = tuple(slice(0, (y.shape[k] + 1) // 2) if k in dims else slice(None) for k in range(d))
-        Xq = X[(slice(None),) + fund].reshape(d, -1).T.copy()
-        fshape = y[fund].shape
-        # on_plane[j]: the points of the domain that lie on the mirror plane of the j-th reflected axis (odd length only)
-        idx = np.indices(fshape)
-        on_plane = [(idx[k] == y.shape[k] // 2) & (y.shape[k] % 2 == 1) for k in dims]
-        nplanes = np.sum(on_plane, axis=0) if dims else np.zeros(fshape, dtype=int)
-        w_pt = 2.0 ** (-0.5 * nplanes)                      # 1 / sqrt(|stabiliser|)
-        ys, wts = np.empty((B, Xq.shape[0])), np.empty((B, Xq.shape[0]))
-        for b in range(B):
-            acc = np.zeros(fshape)
-            for g in range(B):
-                axes = tuple(dims[j] for j in range(len(dims)) if (g >> j) & 1)
-                chi = -1.0 if bin(g & b).count("1") & 1 else 1.0
-                acc += chi * (np.flip(y, axis=axes) if axes else y)[fund]
-            present = np.ones(fshape, dtype=bool)
-            for j in range(len(dims)):
-                if (b >> j) & 1:
-                    present &= ~on_plane[j]                 # antisymmetric along an axis: nothing on its mirror plane
-            wb = np.where(present, w_pt, 0.0)
-            ys[b] = (acc * wb).reshape(-1) / np.sqrt(B)
-            wts[b] = wb.reshape(-1)
-        odd = bool(nplanes.any())
-        self._symm = {"mask": mask, "twoc": (ctypes.c_double * 4)(*twoc), "B": B, "Xq": Xq, "ys": ys,
-                      "wts": wts if odd else None, "n_total": int(y.size)}
+        """The symmetry-reduced form of the model (gprutils.reflection_blocks; csrc/engine.hip: kmat_refl_kernel)."""
+        try:
+            S = gprutils.reflection_blocks(X, y, self._axes)
+        except ValueError as e:
+            raise NotImplementedError("structured=True with kernel %r: %s" % (self._kernel_name, e))
+        S["twoc"] = (ctypes.c_double * 4)(*S["twoc"])
+        self._symm = S
 
     def _symm_call(self, fn):
         """fn(Xq, ys, Nq, B, u_b) with the handle in reflection mode; the B parameter slots hold one vector."""

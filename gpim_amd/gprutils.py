@@ -87,3 +87,57 @@ def get_grid_indices(R, dense_x=1.):
     if np.ndim(R) > 3:
         raise NotImplementedError("Currently supports only 2D and 3D arrays")
     return get_full_grid(R, dense_x=np.float64(dense_x)), get_sparse_grid(R)
+
+
+def reflection_blocks(X, y, axes):
+    """Symmetry reduction of an exact GP on a COMPLETE grid (gpim_amd extension; role of the reference's structured class
+    gpim/gpreg/skgpr.py:399-448 for kernels that do not factorise over the axes -- csrc/engine.hip: kmat_refl_kernel).
+
+    X (d, n_1, ..., n_d) grid coordinates, y (n_1, ..., n_d) observations, axes: the d coordinate vectors.  Every axis whose
+    coordinates are symmetric about their centre is reflected; with r such axes the covariance of a stationary kernel that is
+    even in each coordinate difference is block diagonal in the basis
+        v_{s,p} = (|G| |Stab_p|)^-1/2 sum_g chi_s(g) e_{g p}      (p in the fundamental domain, s one of 2^r sign patterns)
+    with blocks  K_s[p, q] = w_p w_q sum_g chi_s(g) k(p, g q),  w_p = |Stab_p|^-1/2.
+    Returns a dict: mask (bit k = axis k reflected), twoc (first + last coordinate per axis), B = 2^r, Xq (the fundamental
+    domain, (Nq, d): the first half of every reflected axis, including the mirror plane of an axis of odd length), ys (B, Nq):
+    y in the adapted basis, wts (B, Nq) or None when no point lies on a mirror plane: w_p, and 0 where the point does not
+    exist in the block (it lies on the mirror plane of an axis whose sign is -1), n_total = y.size.
+    Raises ValueError if no axis is symmetric."""
+    X = np.asarray(X, dtype=np.float64)
+    y = np.asarray(y, dtype=np.float64)
+    d = X.shape[0]
+    mask, twoc, dims = 0, [0.0] * 4, []
+    for k, c in enumerate(axes):
+        c = np.asarray(c, dtype=np.float64)
+        if len(c) >= 2 and np.allclose(c + c[::-1], c[0] + c[-1], rtol=0, atol=1e-12 * max(1.0, abs(c[-1]), abs(c[0]))):
+            mask |= 1 << k
+            twoc[k] = float(c[0] + c[-1])
+            dims.append(k)
+    if not dims:
+        raise ValueError("needs at least one grid axis with coordinates that are symmetric about their centre")
+    B = 1 << len(dims)
+    fund = tuple(slice(0, (y.shape[k] + 1) // 2) if k in dims else slice(None) for k in range(d))
+    Xq = X[(slice(None),) + fund].reshape(d, -1).T.copy()
+    fshape = y[fund].shape
+    idx = np.indices(fshape)
+    # on_plane[j]: the points of the domain on the mirror plane of the j-th reflected axis (odd length only)
+    on_plane = [(idx[k] == y.shape[k] // 2) & (y.shape[k] % 2 == 1) for k in dims]
+    nplanes = np.sum(on_plane, axis=0)
+    w_pt = 2.0 ** (-0.5 * nplanes)                      # 1 / sqrt(|stabiliser|)
+    ys, wts = np.empty((B, Xq.shape[0])), np.empty((B, Xq.shape[0]))
+    for b in range(B):
+        acc = np.zeros(fshape)
+        for g in range(B):
+            ax = tuple(dims[j] for j in range(len(dims)) if (g >> j) & 1)
+            chi = -1.0 if bin(g & b).count("1") & 1 else 1.0
+            acc += chi * (np.flip(y, axis=ax) if ax else y)[fund]
+        present = np.ones(fshape, dtype=bool)
+        for j in range(len(dims)):
+            if (b >> j) & 1:
+                present &= ~on_plane[j]                 # antisymmetric along an axis: nothing on its mirror plane
+        wb = np.where(present, w_pt, 0.0)
+        ys[b] = (acc * wb).reshape(-1) / np.sqrt(B)
+        wts[b] = wb.reshape(-1)
+    return {"mask": mask, "twoc": twoc, "B": B, "Xq": Xq, "ys": ys, "wts": wts if nplanes.any() else None,
+            "n_total": int(y.size), "dims": dims}
+
