@@ -86,6 +86,17 @@ def O_losses(X, R, args):
     return np.asarray(orc.loss_all, dtype=float)
 
 
+def test_skreconstructor_matern(gpim):
+    """The structured class of the reference takes Matern52 (gpim/gpreg/skgpr.py:399-448, gpytorch_kernels.py:65)."""
+    R = _image((14, 10), 2)
+    X = gpim.utils.get_full_grid(R)
+    kw = dict(kernel="Matern52", lengthscale=[[1., 1.], [6., 6.]], learning_rate=0.1, iterations=8, verbose=0)
+    mean, sd, hyper = gpim.skreconstructor(X, R, X, **kw).run()
+    mo, so, ho = O.reconstructor(X, R, X, **kw).run()
+    assert_allclose(np.asarray(hyper["lengthscale"], dtype=float), np.asarray(ho["lengthscale"], dtype=float), rtol=1e-8)
+    assert np.abs(mean - mo).max() < 1e-8 and np.abs(sd - so).max() < 1e-8
+
+
 def test_symmetry_reduced_needs_a_symmetric_axis(gpim):
     R = _image((9, 7), 1)
     X = gpim.utils.get_full_grid(R).astype(np.float64)
