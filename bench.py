@@ -375,6 +375,32 @@ def extra_configs(gpim):
                                   "dtype": "f32 matrices and MFMA; f64 diagonal blocks, vectors, loss, gradient, Adam",
                                   "seconds": dt, "grid_points_per_s": R2.size / dt, "tflops": flop2 / dt / 1e12,
                                   "mfma_frac_of_fp32_peak": flop2 / dt / 1e12 / 157.3}
+    # the complete 64x64x64 cube of config C3 as ONE exact GP (N = 262144; the reference fits whole cubes as one GP,
+    # gpr.py:30-43) through the reflection blocks: eight dense blocks of 32768 points in one lock-step batch, 193 GiB of
+    # the 288 GB.  Last, and guarded: it needs most of the device's memory.
+    try:
+        del rec2
+        gc.collect(); torch.cuda.empty_cache()
+        _, cube_full = hyperspectral_cube()
+        Xc3 = gpim.utils.get_full_grid(cube_full)
+        rec3 = gpim.reconstructor(Xc3, cube_full, Xc3, structured=True, kernel="Matern52",
+                                  lengthscale=[[1., 1., 1.], [20., 20., 20.]], learning_rate=0.1, iterations=1, verbose=0)
+        rec3.train()
+        sync(); t0 = time.perf_counter()
+        rec3.train(iterations=2)
+        sync(); dt = (time.perf_counter() - t0) / 2
+        n3 = cube_full.size
+        out["C3_cube_as_one_GP_structured"] = {
+            "workload": "the complete 64x64x64 cube as ONE exact GP (N = %d), Matern52, reconstructor(structured=True): eight "
+                        "reflection blocks of %d points, one lock-step batch with shared hyper-parameters; exact" % (n3, n3 // 8),
+            "seconds_per_adam_iteration": dt, "blocks_tflops": 8 * float(n3 // 8) ** 3 / dt / 1e12,
+            "dense_equivalent_tflops": float(n3) ** 3 / dt / 1e12,
+            "workspace_gib": rec3._handle.lib.gpimhip_workspace_bytes(rec3._handle.h) / 2 ** 30,
+            "loss": [float(v) for v in rec3.loss_all]}
+        del rec3
+        gc.collect(); torch.cuda.empty_cache()
+    except Exception as e:                      # (a smaller device: report, do not fail the line)
+        out["C3_cube_as_one_GP_structured"] = {"error": "%s: %s" % (type(e).__name__, e)}
     return out
 
 
