@@ -839,7 +839,15 @@ static int predict_cols(gpimhip_ctx* h, const gpimhip_model_t* m, const double* 
                                np * kld));
         GP_TRY(launch_gemv_t(h, h->Ks, kld, np, cpad, h->alpha, h->mean_tmp, 0, np * kld, np, mcap));
         if (!h->refl.mask) GP_TRY(launch_copy_slice(h, h->mean_tmp, mean_out + m0, cnt, mcap, M));
+        // reflection blocks: the variance may be wanted for the first var_count test points only (it is invariant under
+        // the reflections: a caller predicting on the training grid asks for it on the fundamental domain)
+        const int64_t nvar = (h->refl.mask && h->refl.var_count > 0) ? std::max<int64_t>(0, std::min(cnt, h->refl.var_count - m0)) : cnt;
+        if (nvar == 0) {
+            GP_TRY(launch_predict_coupled(h, mcap, nb, m0, cnt, 0, mcap, mean_out, var_out));
+            continue;
+        }
         GemmArgs g = gemm_args(h->A, h->ld, h->Ks, kld, nullptr, 0, 1.0, 0.0, h->pred_tiles, 0, h->np);
+        if (nvar < cnt) g.cj_max = (int)((nvar + NB - 1) / NB);
         g.sB = np * kld;
         g.colpart = h->colpart;
         g.ld_colpart = mcap;
@@ -849,7 +857,7 @@ static int predict_cols(gpimhip_ctx* h, const gpimhip_model_t* m, const double* 
         g.chunk = deal_chunk(g.ntiles);
         g.rag = h->fp32 ? 0 : rag_of(N, np);
         { StageTimer t(h, 3); GP_TRY(launch_gemm(h, false, true, EPI_COLSUMSQ, g)); }
-        if (h->refl.mask) GP_TRY(launch_predict_coupled(h, mcap, nb, m0, cnt, mcap, mean_out, var_out));
+        if (h->refl.mask) GP_TRY(launch_predict_coupled(h, mcap, nb, m0, cnt, nvar, mcap, mean_out, var_out));
         else GP_TRY(launch_predict_var(h, mcap, nb, m0, cnt, var_out, M));
     }
     return GPIMHIP_OK;
@@ -1426,8 +1434,9 @@ int gpimhip_dist_finalize_dev(gpimhip_handle h, const gpimhip_model_t* m, int64_
     return launch_dist_finalize_dev(h, m, N, red, quad, u, t > 0 ? 1 : 0, st, loss_out, grad_out, hist_row);
 }
 
-int gpimhip_set_reflection(gpimhip_handle h, int32_t mask, const double* twoc, const double* wts, int64_t n_total) {
-    if (!h || mask < 0 || mask >= (1 << GPIMHIP_MAX_DIM) || (mask && !twoc) || n_total < 0) return GPIMHIP_E_BADARG;
+int gpimhip_set_reflection(gpimhip_handle h, int32_t mask, const double* twoc, const double* wts, int64_t n_total,
+                           int64_t var_count) {
+    if (!h || mask < 0 || mask >= (1 << GPIMHIP_MAX_DIM) || (mask && !twoc) || n_total < 0 || var_count < 0) return GPIMHIP_E_BADARG;
     if (mask && h->fp32) {
         gpim_set_error("the symmetry-reduced model computes in double precision");
         return GPIMHIP_E_BADARG;
@@ -1436,6 +1445,7 @@ int gpimhip_set_reflection(gpimhip_handle h, int32_t mask, const double* twoc, c
     for (int k = 0; k < GPIMHIP_MAX_DIM; ++k) h->refl.twoc[k] = mask ? twoc[k] : 0.0;
     h->refl.wts = mask ? wts : nullptr;
     h->refl.n_total = mask ? n_total : 0;
+    h->refl.var_count = mask ? var_count : 0;
     return GPIMHIP_OK;
 }
 

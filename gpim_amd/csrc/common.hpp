@@ -110,9 +110,10 @@ struct ReflArgs {
     double twoc[GPIMHIP_MAX_DIM];
     const double* wts;
     int64_t n_total;
+    int64_t var_count;      // > 0: predictions compute the variance for the first var_count test points only
 };
 struct gpimhip_ctx {
-    ReflArgs refl = {0, {0, 0, 0, 0}, nullptr, 0};
+    ReflArgs refl = {0, {0, 0, 0, 0}, nullptr, 0, 0};
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t capture_stream = nullptr; // internal stream used only to capture one iteration into a hipGraph
@@ -239,8 +240,8 @@ int launch_grad_reduce_refl(gpimhip_ctx* h, const gpimhip_model_t* m, const doub
 int launch_finalize_coupled(gpimhip_ctx* h, const gpimhip_model_t* m, int64_t N, int64_t np, double* u, int do_adam,
                             AdamStep st, double* loss_out, double* grad_out, double* hist_row, int32_t* iter,
                             const double* bc, int T, double* hist_base, double* loss_base);
-int launch_predict_coupled(gpimhip_ctx* h, int64_t ldp, int nb, int64_t m0, int64_t mcount, int64_t mean_bs, double* mean_out,
-                           double* var_out);
+int launch_predict_coupled(gpimhip_ctx* h, int64_t ldp, int nb, int64_t m0, int64_t mcount, int64_t nvar, int64_t mean_bs,
+                           double* mean_out, double* var_out);
 int launch_dist_finalize_dev(gpimhip_ctx* h, const gpimhip_model_t* m, int64_t N, const double* red, const double* quad,
                              double* u, int do_adam, AdamStep st, double* loss_out, double* grad_out, double* hist_row);
 int launch_dist_finalize(gpimhip_ctx* h, const gpimhip_model_t* m, int64_t N, const double* S, double q2, double lg,

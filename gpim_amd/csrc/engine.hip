@@ -1237,23 +1237,25 @@ int launch_finalize_coupled(gpimhip_ctx* h, const gpimhip_model_t* m, int64_t N,
     return GPIMHIP_OK;
 }
 // posterior of the coupled blocks: mean_j = sum_b mean_b[j], var_j = clamp(s2 - sum_b sum_ci colpart_b[ci][j], 0) + noise
+// (the variance only for the chunk's first nvar test points: ReflArgs::var_count)
 __global__ void predict_coupled_kernel(const double* __restrict__ colpart, int64_t ldp, int nb, int B, int64_t m0, int64_t mcount,
-                                       const double* __restrict__ mean_tmp, int64_t mean_bs, const ThetaDev* __restrict__ th,
-                                       double* __restrict__ mean_out, double* __restrict__ var_out) {
+                                       int64_t nvar, const double* __restrict__ mean_tmp, int64_t mean_bs,
+                                       const ThetaDev* __restrict__ th, double* __restrict__ mean_out, double* __restrict__ var_out) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= mcount) return;
     double q = 0.0, mu = 0.0;
     for (int b = 0; b < B; ++b) {
-        for (int ci = 0; ci < nb; ++ci) q += colpart[((int64_t)b * nb + ci) * ldp + j];
+        if (j < nvar)
+            for (int ci = 0; ci < nb; ++ci) q += colpart[((int64_t)b * nb + ci) * ldp + j];
         mu += mean_tmp[b * mean_bs + j];
     }
     mean_out[m0 + j] = mu;
-    var_out[m0 + j] = clamp0_nan(th->var - q) + th->noise;
+    if (j < nvar) var_out[m0 + j] = clamp0_nan(th->var - q) + th->noise;
 }
-int launch_predict_coupled(gpimhip_ctx* h, int64_t ldp, int nb, int64_t m0, int64_t mcount, int64_t mean_bs, double* mean_out,
-                           double* var_out) {
+int launch_predict_coupled(gpimhip_ctx* h, int64_t ldp, int nb, int64_t m0, int64_t mcount, int64_t nvar, int64_t mean_bs,
+                           double* mean_out, double* var_out) {
     hipLaunchKernelGGL(predict_coupled_kernel, dim3((unsigned)((mcount + 255) / 256)), dim3(256), 0, h->stream, h->colpart, ldp,
-                       nb, h->nbatch, m0, mcount, h->mean_tmp, mean_bs, h->theta, mean_out, var_out);
+                       nb, h->nbatch, m0, mcount, nvar, h->mean_tmp, mean_bs, h->theta, mean_out, var_out);
     HIP_TRY(hipGetLastError());
     return GPIMHIP_OK;
 }

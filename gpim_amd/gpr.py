@@ -246,18 +246,18 @@ class reconstructor:
         S["twoc"] = (ctypes.c_double * 4)(*S["twoc"])
         self._symm = S
 
-    def _symm_call(self, fn):
+    def _symm_call(self, fn, var_count=0):
         """fn(Xq, ys, Nq, B, u_b) with the handle in reflection mode; the B parameter slots hold one vector."""
         S, lib, h = self._symm, self._handle.lib, self._handle.h
         if "Xq_d" not in S:
             S["Xq_d"], S["ys_d"] = self._to_device(S["Xq"]), self._to_device(S["ys"])
             S["wts_d"] = self._to_device(S["wts"]) if S["wts"] is not None else None
         u_b = self._u.repeat(S["B"]).contiguous()
-        _lib.check(lib.gpimhip_set_reflection(h, S["mask"], S["twoc"], _lib.ptr(S["wts_d"]), S["n_total"]))
+        _lib.check(lib.gpimhip_set_reflection(h, S["mask"], S["twoc"], _lib.ptr(S["wts_d"]), S["n_total"], int(var_count)))
         try:
             rc = fn(S["Xq_d"], S["ys_d"], S["Xq_d"].shape[0], S["B"], u_b)
         finally:
-            _lib.check(lib.gpimhip_set_reflection(h, 0, None, None, 0))
+            _lib.check(lib.gpimhip_set_reflection(h, 0, None, None, 0, 0))
         self._u.copy_(u_b[:self._u.numel()])
         return rc
 
@@ -383,9 +383,28 @@ class reconstructor:
                 _lib.ptr(self._yd), _lib.ptr(self._u), tn, _lib.ptr(self._to_device(np.concatenate(taxes))),
                 _lib.ptr(mean), _lib.ptr(var))
         elif self.do_symm:
-            rc = self._symm_call(lambda Xq, ys, Nq, B, u_b: self._handle.lib.gpimhip_predict_exact_batched(
-                self._handle.h, ctypes.byref(self._mstruct), _lib.ptr(Xq), 0, _lib.ptr(ys), Nq, B, _lib.ptr(u_b),
-                _lib.ptr(self._Xtest_d), M, _lib.ptr(mean), _lib.ptr(var)))
+            S = self._symm
+            on_grid = self._Xtest_d.shape == self._Xd.shape and bool(torch.equal(self._Xtest_d, self._Xd))
+            if on_grid:
+                # the training grid itself: the variance is invariant under the reflections -- computed on the fundamental
+                # domain (ordered first) and mirrored; the mean everywhere
+                if "perm_d" not in S:
+                    rest = np.setdiff1d(np.arange(M), S["fund_flat"], assume_unique=True)
+                    S["perm_d"] = torch.from_numpy(np.concatenate([S["fund_flat"], rest])).to(self._dev)
+                    S["rep_d"] = torch.from_numpy(S["rep"]).to(self._dev)
+                Xt = self._Xtest_d[S["perm_d"]].contiguous()
+                mean_p = torch.empty((M,), dtype=_F64, device=self._dev)
+                var_p = torch.empty((M,), dtype=_F64, device=self._dev)
+                nq = len(S["fund_flat"])
+                rc = self._symm_call(lambda Xq, ys, Nq, B, u_b: self._handle.lib.gpimhip_predict_exact_batched(
+                    self._handle.h, ctypes.byref(self._mstruct), _lib.ptr(Xq), 0, _lib.ptr(ys), Nq, B, _lib.ptr(u_b),
+                    _lib.ptr(Xt), M, _lib.ptr(mean_p), _lib.ptr(var_p)), var_count=nq)
+                mean[S["perm_d"]] = mean_p
+                var = var_p[:nq][S["rep_d"]]
+            else:
+                rc = self._symm_call(lambda Xq, ys, Nq, B, u_b: self._handle.lib.gpimhip_predict_exact_batched(
+                    self._handle.h, ctypes.byref(self._mstruct), _lib.ptr(Xq), 0, _lib.ptr(ys), Nq, B, _lib.ptr(u_b),
+                    _lib.ptr(self._Xtest_d), M, _lib.ptr(mean), _lib.ptr(var)))
         elif not self.do_sparse:
             rc = self._handle.lib.gpimhip_predict_exact(
                 self._handle.h, ctypes.byref(self._mstruct), _lib.ptr(self._Xd), _lib.ptr(self._yd),

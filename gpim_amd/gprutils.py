@@ -138,6 +138,12 @@ def reflection_blocks(X, y, axes):
         wb = np.where(present, w_pt, 0.0)
         ys[b] = (acc * wb).reshape(-1) / np.sqrt(B)
         wts[b] = wb.reshape(-1)
+    # for predictions on the training grid: the domain's points as flat grid indices, and every grid point's representative
+    # in the domain (the posterior variance is invariant under the reflections)
+    full = np.indices(y.shape)
+    fund_flat = np.ravel_multi_index(tuple(full[k][fund] for k in range(d)), y.shape).reshape(-1)
+    rep_idx = tuple(np.minimum(full[k], y.shape[k] - 1 - full[k]) if k in dims else full[k] for k in range(d))
+    rep = np.ravel_multi_index(rep_idx, fshape).reshape(-1)
     return {"mask": mask, "twoc": twoc, "B": B, "Xq": Xq, "ys": ys, "wts": wts if nplanes.any() else None,
-            "n_total": int(y.size), "dims": dims}
+            "n_total": int(y.size), "dims": dims, "fund_flat": fund_flat, "rep": rep}
 

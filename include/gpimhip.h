@@ -360,8 +360,12 @@ int gpimhip_dist_finalize_dev(gpimhip_handle h, const gpimhip_model_t* m, int64_
  * point lies on, and 0 for a point that does not exist in the block (it lies on the mirror plane of an axis whose sign is
  * -1: its combination vanishes) -- such rows are identity rows of the block, and y of the block is 0 there.  n_total = the
  * number of observations of the full model (0: B x N).
+ * var_count > 0: predictions compute the variance for the first var_count test points only (var_out keeps M entries; the
+ * others are not written) -- the posterior variance is invariant under the reflections, so a caller predicting on the
+ * training grid orders the fundamental domain first and mirrors the result (gpim_amd/gpr.py).
  * mask = 0 switches back.  Double precision only. */
-int gpimhip_set_reflection(gpimhip_handle h, int32_t mask, const double* twoc, const double* wts, int64_t n_total);
+int gpimhip_set_reflection(gpimhip_handle h, int32_t mask, const double* twoc, const double* wts, int64_t n_total,
+                           int64_t var_count);
 
 /* Batch thinning of boptimizer.update_points (gpim/gpbayes/boptim.py:326-376): among n <= 1024 ranked
  * candidates (vals, flat grid indices into a d-dimensional grid of the given shape) repeatedly keep the
