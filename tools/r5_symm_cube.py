@@ -20,3 +20,8 @@ N = side ** 3
 print("cube %d^3 (N = %d, 8 blocks of %d): %.3f s per Adam iteration (dense-equivalent %.0f TFLOP/s over N^3; the blocks' own flop %.1f TFLOP/s); loss %s"
       % (side, N, N // 8, dt, float(N) ** 3 / dt / 1e12, 8 * float(N // 8) ** 3 / dt / 1e12, np.round(rec.loss_all, 3)))
 print("workspace GiB %.1f" % (rec._handle.lib.gpimhip_workspace_bytes(rec._handle.h) / 2 ** 30))
+torch.cuda.synchronize(); t = time.perf_counter()
+mean, sd = rec.predict()
+torch.cuda.synchronize(); dp = time.perf_counter() - t
+print("prediction on the whole grid (M = %d): %.2f s; rmse(mean - data) %.4f, median sd %.4f; workspace GiB %.1f"
+      % (N, dp, float(np.sqrt(np.mean((mean - R) ** 2))), float(np.median(sd)), rec._handle.lib.gpimhip_workspace_bytes(rec._handle.h) / 2 ** 30))
