@@ -102,6 +102,9 @@ _PROTOS = {
     "gpimhip_dist_finalize_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ModelStruct), ctypes.c_int64, c_dp, c_dp,
                                                  c_dp, ctypes.c_double, ctypes.c_int32, c_dp, c_dp, c_dp]),
     "gpimhip_set_precision": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32]),
+    "gpimhip_set_reflection_shard": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
+    "gpimhip_refl_sums": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ModelStruct), c_dp, c_dp, ctypes.c_int64, ctypes.c_int32,
+                                         c_dp, c_dp]),
     "gpimhip_set_reflection": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_double), c_dp,
                                               ctypes.c_int64, ctypes.c_int64]),
     "gpimhip_acquire_exact": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ModelStruct), c_dp, c_dp, ctypes.c_int64,

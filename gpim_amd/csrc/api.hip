@@ -833,7 +833,7 @@ static int predict_cols(gpimhip_ctx* h, const gpimhip_model_t* m, const double* 
         // the test grid Xs is shared by all problems of the batch (z stride 0)
         if (h->refl.mask)      // V_s^T k(X, x*): the block's rows against the test point and its mirror images, |G|^-1/2 each
             GP_TRY(launch_kmat_refl(h, m, X, N, Xs + m0 * m->dim, cnt, h->theta, h->Ks, kld, np, cpad, 0, x_bs, 0, np * kld,
-                                    1.0 / sqrt((double)B)));
+                                    1.0 / sqrt((double)(h->refl.nblocks_total > 0 ? h->refl.nblocks_total : B))));
         else
             GP_TRY(launch_kmat(h, m, X, N, Xs + m0 * m->dim, cnt, h->theta, 0.0, 0, h->Ks, kld, np, cpad, 0, 0, x_bs, 0,
                                np * kld));
@@ -1446,7 +1446,34 @@ int gpimhip_set_reflection(gpimhip_handle h, int32_t mask, const double* twoc, c
     h->refl.wts = mask ? wts : nullptr;
     h->refl.n_total = mask ? n_total : 0;
     h->refl.var_count = mask ? var_count : 0;
+    if (!mask) { h->refl.pb_off = 0; h->refl.pb_stride = 1; h->refl.nblocks_total = 0; h->refl.raw = 0; }
     return GPIMHIP_OK;
+}
+
+int gpimhip_set_reflection_shard(gpimhip_handle h, int32_t pb_off, int32_t pb_stride, int32_t nblocks_total, int32_t raw) {
+    if (!h || pb_off < 0 || pb_stride < 1 || nblocks_total < 0 || nblocks_total > (1 << GPIMHIP_MAX_DIM)) return GPIMHIP_E_BADARG;
+    h->refl.pb_off = pb_off;
+    h->refl.pb_stride = pb_stride;
+    h->refl.nblocks_total = nblocks_total;
+    h->refl.raw = raw ? 1 : 0;
+    return GPIMHIP_OK;
+}
+
+int gpimhip_refl_sums(gpimhip_handle h, const gpimhip_model_t* m, const double* X, const double* y, int64_t N, int32_t B,
+                      const double* u, double* sums_out) {
+    if (!h || !X || !y || !u || !sums_out || N < 1 || B < 1 || B > (1 << GPIMHIP_MAX_DIM) || !h->refl.mask) return GPIMHIP_E_BADARG;
+    FP64_ONLY(h);
+    GP_TRY(check_model(m));
+    HIP_TRY(hipSetDevice(h->device));
+    h->nbatch = B;
+    HIP_TRY(hipMemsetAsync(h->info, 0, sizeof(int32_t), h->stream));
+    GP_TRY(ws_ensure_padded(h, N));
+    const int64_t np = h->np;
+    GP_TRY(launch_pad_copy(h, y, N, h->ypad, np));
+    GP_TRY(factor_at_u(h, m, X, 0, N, u));
+    GP_TRY(launch_lauum(h, h->A, h->B, np, h->ld, rag_of(N, np)));
+    GP_TRY(launch_grad_reduce_refl(h, m, h->B, h->ld, X, N, (int)(np / NB), h->alpha, 0));
+    return launch_coupled_sums(h, np, sums_out);
 }
 
 int gpimhip_thin_batch(gpimhip_handle h, const double* vals, const int64_t* flat_idx, int32_t n, int32_t d,

@@ -111,9 +111,13 @@ struct ReflArgs {
     const double* wts;
     int64_t n_total;
     int64_t var_count;      // > 0: predictions compute the variance for the first var_count test points only
+    // blocks dealt to the ranks of a job (gpimhip_set_reflection_shard): problem b of the local batch is the block of sign
+    // pattern pb_off + b * pb_stride; |G| = nblocks_total (the K* scale).  raw: predictions return, instead of the variance,
+    // the blocks' summed quadratic form  sum_s |L_s^-1 K*_s|^2  (the ranks add theirs up before subtracting from sigma^2)
+    int pb_off, pb_stride, nblocks_total, raw;
 };
 struct gpimhip_ctx {
-    ReflArgs refl = {0, {0, 0, 0, 0}, nullptr, 0, 0};
+    ReflArgs refl = {0, {0, 0, 0, 0}, nullptr, 0, 0, 0, 1, 0, 0};
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t capture_stream = nullptr; // internal stream used only to capture one iteration into a hipGraph
@@ -240,6 +244,7 @@ int launch_grad_reduce_refl(gpimhip_ctx* h, const gpimhip_model_t* m, const doub
 int launch_finalize_coupled(gpimhip_ctx* h, const gpimhip_model_t* m, int64_t N, int64_t np, double* u, int do_adam,
                             AdamStep st, double* loss_out, double* grad_out, double* hist_row, int32_t* iter,
                             const double* bc, int T, double* hist_base, double* loss_base);
+int launch_coupled_sums(gpimhip_ctx* h, int64_t np, double* out11);
 int launch_predict_coupled(gpimhip_ctx* h, int64_t ldp, int nb, int64_t m0, int64_t mcount, int64_t nvar, int64_t mean_bs,
                            double* mean_out, double* var_out);
 int launch_dist_finalize_dev(gpimhip_ctx* h, const gpimhip_model_t* m, int64_t N, const double* red, const double* quad,

@@ -999,7 +999,7 @@ __global__ __launch_bounds__(256) void kmat_refl_kernel(const double* __restrict
     __shared__ double xz[128][4];
     __shared__ double wr_s[128], wc_s[128];
     const int tid = threadIdx.x;
-    const int sg = refl_sign_dims(refl.mask, blockIdx.y);
+    const int sg = refl_sign_dims(refl.mask, refl.pb_off + (int)blockIdx.y * refl.pb_stride);
     X += blockIdx.y * x_bs;
     Z += blockIdx.y * z_bs;
     th += blockIdx.y;
@@ -1093,7 +1093,7 @@ __global__ __launch_bounds__(256) void grad_reduce_refl_kernel(const double* __r
     __shared__ double wr_s[128], wc_s[128];
     __shared__ double red[4][8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int sg = refl_sign_dims(refl.mask, blockIdx.y);
+    const int sg = refl_sign_dims(refl.mask, refl.pb_off + (int)blockIdx.y * refl.pb_stride);
     const double* wts = refl.wts ? refl.wts + (int64_t)blockIdx.y * N : nullptr;
     Kinv += blockIdx.y * np * ld;
     X += blockIdx.y * x_bs;
@@ -1236,11 +1236,50 @@ int launch_finalize_coupled(gpimhip_ctx* h, const gpimhip_model_t* m, int64_t N,
     HIP_TRY(hipGetLastError());
     return GPIMHIP_OK;
 }
+// the sums of the LOCAL blocks, for a job that deals the blocks to its ranks (gpimhip_refl_sums): out[0..7] = the gradient
+// sums, out[8] = sum log L_ii, out[9] = 1 if a factorisation failed, out[10] = sum |L^-1 y|^2 -- fixed order, problem by problem
+__global__ __launch_bounds__(256) void coupled_sums_kernel(int64_t np, int nb, int ntile, int B, const double* __restrict__ grad_part,
+                                                           const double* __restrict__ z, const double* __restrict__ logdet_part,
+                                                           const int32_t* __restrict__ info, double* __restrict__ out) {
+    __shared__ double red[256];
+    __shared__ double S[8];
+    const int tid = threadIdx.x;
+    double q2 = 0.0, lg = 0.0;
+    if (tid < 8) S[tid] = 0.0;
+    __syncthreads();
+    for (int b = 0; b < B; ++b) {
+        for (int k = 0; k < 7; ++k) {
+            double v = 0.0;
+            for (int q = tid; q < ntile; q += 256) v += grad_part[((int64_t)b * ntile + q) * 8 + k];
+            v = block_sum_256(v, red);
+            if (tid == 0) S[k] += v;
+        }
+        double qb = 0.0;
+        for (int64_t i = tid; i < np; i += 256) qb = fma(z[b * np + i], z[b * np + i], qb);
+        q2 += block_sum_256(qb, red);
+        double lb = 0.0;
+        for (int k = tid; k < nb; k += 256) lb += logdet_part[(int64_t)b * nb + k];
+        lg += block_sum_256(lb, red);
+    }
+    if (tid != 0) return;
+    for (int k = 0; k < 8; ++k) out[k] = S[k];
+    out[8] = lg;
+    out[9] = (*info != 0) ? 1.0 : 0.0;
+    out[10] = q2;
+}
+int launch_coupled_sums(gpimhip_ctx* h, int64_t np, double* out11) {
+    const int nb = (int)(np / NB);
+    hipLaunchKernelGGL(coupled_sums_kernel, dim3(1), dim3(256), 0, h->stream, np, nb, nb * (nb + 1) / 2, h->nbatch, h->grad_part,
+                       h->z, h->logdet_part, h->info, out11);
+    HIP_TRY(hipGetLastError());
+    return GPIMHIP_OK;
+}
 // posterior of the coupled blocks: mean_j = sum_b mean_b[j], var_j = clamp(s2 - sum_b sum_ci colpart_b[ci][j], 0) + noise
 // (the variance only for the chunk's first nvar test points: ReflArgs::var_count)
 __global__ void predict_coupled_kernel(const double* __restrict__ colpart, int64_t ldp, int nb, int B, int64_t m0, int64_t mcount,
                                        int64_t nvar, const double* __restrict__ mean_tmp, int64_t mean_bs,
-                                       const ThetaDev* __restrict__ th, double* __restrict__ mean_out, double* __restrict__ var_out) {
+                                       const ThetaDev* __restrict__ th, double* __restrict__ mean_out, double* __restrict__ var_out,
+                                       int raw) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= mcount) return;
     double q = 0.0, mu = 0.0;
@@ -1250,12 +1289,12 @@ __global__ void predict_coupled_kernel(const double* __restrict__ colpart, int64
         mu += mean_tmp[b * mean_bs + j];
     }
     mean_out[m0 + j] = mu;
-    if (j < nvar) var_out[m0 + j] = clamp0_nan(th->var - q) + th->noise;
+    if (j < nvar) var_out[m0 + j] = raw ? q : clamp0_nan(th->var - q) + th->noise;
 }
 int launch_predict_coupled(gpimhip_ctx* h, int64_t ldp, int nb, int64_t m0, int64_t mcount, int64_t nvar, int64_t mean_bs,
                            double* mean_out, double* var_out) {
     hipLaunchKernelGGL(predict_coupled_kernel, dim3((unsigned)((mcount + 255) / 256)), dim3(256), 0, h->stream, h->colpart, ldp,
-                       nb, h->nbatch, m0, mcount, nvar, h->mean_tmp, mean_bs, h->theta, mean_out, var_out);
+                       nb, h->nbatch, m0, mcount, nvar, h->mean_tmp, mean_bs, h->theta, mean_out, var_out, h->refl.raw);
     HIP_TRY(hipGetLastError());
     return GPIMHIP_OK;
 }

@@ -367,6 +367,21 @@ int gpimhip_dist_finalize_dev(gpimhip_handle h, const gpimhip_model_t* m, int64_
 int gpimhip_set_reflection(gpimhip_handle h, int32_t mask, const double* twoc, const double* wts, int64_t n_total,
                            int64_t var_count);
 
+/* The blocks of the symmetry-reduced model dealt to the ranks of a job (gpim_amd/dist_symm.py): no data-path collective at
+ * all -- the blocks only share the hyper-parameters, so the ranks exchange eleven doubles per Adam iteration.
+ *   gpimhip_set_reflection_shard  problem b of this handle's batches is the block of sign pattern pb_off + b * pb_stride out
+ *                                 of nblocks_total = 2^r; raw != 0: gpimhip_predict_exact_batched returns in var_out the
+ *                                 local blocks' summed quadratic form instead of the variance (the ranks add theirs up:
+ *                                 var = max(sigma^2 - sum, 0) + noise) and in mean_out their share of the mean.  Reset by
+ *                                 gpimhip_set_reflection(h, 0, ...).
+ *   gpimhip_refl_sums             one evaluation of the local blocks at u (B copies of the parameter vector): kernel
+ *                                 matrices, factorisations, inverses, gradient contraction; sums_out (device, 11 doubles):
+ *                                 [0..7] gradient sums, [8] sum log L_ii, [9] 1 if a factorisation failed, [10] sum
+ *                                 |L^-1 y|^2.  After the all-reduce, gpimhip_dist_finalize_dev takes [0..9] and [10]. */
+int gpimhip_set_reflection_shard(gpimhip_handle h, int32_t pb_off, int32_t pb_stride, int32_t nblocks_total, int32_t raw);
+int gpimhip_refl_sums(gpimhip_handle h, const gpimhip_model_t* m, const double* X, const double* y, int64_t N, int32_t B,
+                      const double* u, double* sums_out);
+
 /* Batch thinning of boptimizer.update_points (gpim/gpbayes/boptim.py:326-376): among n <= 1024 ranked
  * candidates (vals, flat grid indices into a d-dimensional grid of the given shape) repeatedly keep the
  * largest remaining value and drop every candidate within Euclidean index distance <= dscale of it

@@ -97,6 +97,29 @@ def test_skreconstructor_matern(gpim):
     assert np.abs(mean - mo).max() < 1e-8 and np.abs(sd - so).max() < 1e-8
 
 
+def test_sharded_blocks_world_1_equal_the_batched_model(gpim):
+    """gpim_amd.dist_symm (the reflection blocks dealt to the ranks of a job) at world size 1: the histories of
+    reconstructor(structured=True), the dense oracle's posterior.  (World size 2: tests/tools/dist2_worker.py.)"""
+    from gpim_amd.dist_symm import symm_gp_fit, symm_gp_posterior
+    R = _image((12, 9, 4), 3)
+    X = gpim.utils.get_full_grid(R)
+    kw = dict(kernel="Matern52", lengthscale=[[1., 1., 1.], [6., 6., 6.]])
+    T = 8
+    hyper, u = symm_gp_fit(X, R, learning_rate=0.1, iterations=T, **kw)
+    rec = gpim.reconstructor(X, R, X, structured=True, learning_rate=0.1, iterations=T, verbose=0, **kw)
+    rec.train()
+    assert_allclose(hyper["loss"], rec.loss_all, rtol=1e-12)
+    assert_allclose(hyper["lengthscale"], np.asarray(rec.hyperparams["lengthscale"]), rtol=1e-12)
+    orc = O.reconstructor(X, R, X, learning_rate=0.1, iterations=T, verbose=0, **kw)
+    mo, so, _ = orc.run()
+    pts = X.reshape(3, -1).T
+    mean, sd = symm_gp_posterior(X, R, pts, u, **kw)
+    assert np.abs(mean - mo.ravel()).max() < 1e-8 and np.abs(sd - so.ravel()).max() < 1e-8
+    # Xtest=None: the training grid, the variance on the fundamental domain and mirrored (12 even, 9 odd, 4 even)
+    mean_g, sd_g = symm_gp_posterior(X, R, None, u, **kw)
+    assert np.abs(mean_g - mo.ravel()).max() < 1e-8 and np.abs(sd_g - so.ravel()).max() < 1e-8
+
+
 def test_symmetry_reduced_needs_a_symmetric_axis(gpim):
     R = _image((9, 7), 1)
     X = gpim.utils.get_full_grid(R).astype(np.float64)
