@@ -63,6 +63,12 @@ _PROTOS = {
                                        ctypes.c_int64, c_dp, ctypes.c_double, ctypes.c_int32, c_dp, c_dp, c_dp]),
     "gpimhip_predict_vfe": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ModelStruct), c_dp, c_dp, ctypes.c_int64,
                                            ctypes.c_int64, c_dp, c_dp, ctypes.c_int64, c_dp, c_dp]),
+    "gpimhip_fit_vfe_batched": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ModelStruct), c_dp, ctypes.c_int64, c_dp,
+                                               ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, c_dp, ctypes.c_double,
+                                               ctypes.c_int32, c_dp, c_dp, c_dp]),
+    "gpimhip_predict_vfe_batched": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ModelStruct), c_dp, ctypes.c_int64, c_dp,
+                                                   ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, c_dp, c_dp,
+                                                   ctypes.c_int64, ctypes.c_int64, c_dp, c_dp]),
     "gpimhip_kron_nll_grad": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ModelStruct), ctypes.c_int32,
                                              ctypes.POINTER(ctypes.c_int32), c_dp, c_dp, c_dp, c_dp, c_dp]),
     "gpimhip_fit_kron": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ModelStruct), ctypes.c_int32,

@@ -291,6 +291,8 @@ struct GemmArgs {
                                            // inside a strip: 64 consecutive tiles are an 8 x 8 patch (with chunk = 64 one
                                            // patch per XCD at a time: 8 + 8 operand panels for 64 tiles); needs kfix0 / kfix1
     double* colpart; int64_t ld_colpart;   // EPI_COLSUMSQ: colpart[ci*ld + cj*128 + col]
+    int shape_div;                         // > 1: the launch shape is chosen for ntiles * batch / shape_div tiles (the sparse model's
+                                           // lock-step batches: every model gets the tile shapes -- hence the bits -- of its own launch)
     int64_t sA, sB, sC, sColpart;          // per-problem (blockIdx.y) strides in elements
 };
 int launch_gemm(gpimhip_ctx* h, bool a_km, bool b_km, int epi, const GemmArgs& g);

@@ -43,7 +43,7 @@ static int mid_tiles() {
 template <bool A_KM, bool B_KM, int EPI>
 static int launch_one(gpimhip_ctx* h, const GemmArgs& g) {
     if (g.ntiles <= 0) return GPIMHIP_OK;
-    const int64_t total = (int64_t)g.ntiles * h->nbatch;
+    const int64_t total = (int64_t)g.ntiles * h->nbatch / (g.shape_div > 1 ? g.shape_div : 1);
     // up to 640 tiles: 64x64 quadrants, four co-resident workgroups per CU.  A launch of a few hundred tiles whose
     // k-ranges differ by an order of magnitude (triangular inverse, K^-1 product at N ~ 4000) lasts as long as its
     // longest tile; dealt longest-first over 4 x 256 slots, every CU gets a mix (N = 4206: inverse 0.92 -> 0.80 ms,

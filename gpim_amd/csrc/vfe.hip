@@ -15,6 +15,11 @@
 // and G_A', G_B' are contracted with dk/dtheta and dk/dXu by two fused reduction kernels.  All dense
 // products run on the fp64 MFMA tile engine (gemm.hip) with triangular k-ranges; the two Cholesky
 // factorisations and triangular inverses reuse the blocked drivers of the exact path.
+//
+// Lock-step batches (gpimhip_fit_vfe_batched / gpimhip_predict_vfe_batched): B models of equal N and Mu (the slices of
+// config C5) advance together through every launch, blockIdx.y = model.  Mu x Mu matrices and vectors of the B models
+// are stacked; the Mu x N matrices lie side by side as ONE mp x (B nq) matrix (model b = columns b nq ...), so that the
+// k-chunks of P = W W^T of all models are again one linear batch dimension.  B = 1 is the single-model path.
 #include <string.h>
 #include <math.h>
 #include <stdlib.h>
@@ -48,6 +53,7 @@ int vfe_finish_and_check(gpimhip_ctx* h);
 // ------------------------------------------------------------------------------------------
 struct VfeWs {
     int64_t mp = 0, nq = 0;       // padded Mu, padded N
+    int B = 0;                    // models of a lock-step batch (every buffer below holds B of them)
     double *Vc = nullptr, *Cs = nullptr, *Mm = nullptr, *T1 = nullptr, *GA = nullptr;     // mp x mp
     double* Pp = nullptr;         // ksplit x mp x mp: partial sums of P = W W^T over k-chunks (vfe_forward)
     int ksplit = 1;               // number of k-chunks (a divisor of nbq)
@@ -99,31 +105,31 @@ void vfe_release(gpimhip_ctx* h) {
     }
 }
 
-static int vfe_ensure(gpimhip_ctx* h, int64_t Mu, int64_t N, int d, int P, VfeWs** out) {
+static int vfe_ensure(gpimhip_ctx* h, int64_t Mu, int64_t N, int d, int P, int B, VfeWs** out) {
     if (!h->vfe) h->vfe = new VfeWs();
     VfeWs& w = *static_cast<VfeWs*>(h->vfe);
     const int64_t mp = pad_to(Mu, NB), nq = pad_to(N, NB);
     *out = &w;
-    if (w.mp == mp && w.nq == nq) return GPIMHIP_OK;
+    if (w.mp == mp && w.nq == nq && w.B == B) return GPIMHIP_OK;
     HIP_TRY(hipStreamSynchronize(h->stream));
     vfe_free(w);
     const int mb = (int)(mp / NB), nbq = (int)(nq / NB);
-    GP_TRY(valloc(&w.Vc, mp * mp)); GP_TRY(valloc(&w.Cs, mp * mp)); GP_TRY(valloc(&w.Mm, mp * mp));
-    GP_TRY(valloc(&w.T1, mp * mp)); GP_TRY(valloc(&w.GA, mp * mp));
+    GP_TRY(valloc(&w.Vc, B * mp * mp)); GP_TRY(valloc(&w.Cs, B * mp * mp)); GP_TRY(valloc(&w.Mm, B * mp * mp));
+    GP_TRY(valloc(&w.T1, B * mp * mp)); GP_TRY(valloc(&w.GA, B * mp * mp));
     // P = W W^T has few output tiles (15 at Mu = 534) and a long k-range (N / 128 blocks): the k-range is cut into
     // `ksplit` equal chunks that run as the batch dimension of ONE launch (each into its own partial), summed in a fixed
     // order by vfe_cap_kernel.  302 -> 74 us per iteration at N = 6400 (config C5).
     w.ksplit = 1;
     for (int sdiv = 2; sdiv <= 16; ++sdiv)
         if (nbq % sdiv == 0 && nbq / sdiv >= 2) w.ksplit = sdiv;
-    if (w.ksplit > 1) GP_TRY(valloc(&w.Pp, (int64_t)w.ksplit * mp * mp));
-    GP_TRY(valloc(&w.Bm, mp * nq)); GP_TRY(valloc(&w.Wm, mp * nq));
-    GP_TRY(valloc(&w.Y1, mp * nq)); GP_TRY(valloc(&w.Y2, mp * nq));
-    GP_TRY(valloc(&w.yq, nq)); GP_TRY(valloc(&w.wtb, nq));
-    GP_TRY(valloc(&w.v, mp)); GP_TRY(valloc(&w.c1, mp)); GP_TRY(valloc(&w.beta, mp));
-    GP_TRY(valloc(&w.part_rect, (int64_t)mb * nbq * 8)); GP_TRY(valloc(&w.part_sym, (int64_t)mb * mb * 8));
-    GP_TRY(valloc(&w.xu_rect, (int64_t)nbq * mp * 4)); GP_TRY(valloc(&w.xu_sym, (int64_t)mb * mp * 4));
-    GP_TRY(valloc(&w.adam_m, P + mp * GPIMHIP_MAX_DIM)); GP_TRY(valloc(&w.adam_v, P + mp * GPIMHIP_MAX_DIM));
+    if (w.ksplit > 1) GP_TRY(valloc(&w.Pp, (int64_t)B * w.ksplit * mp * mp));
+    GP_TRY(valloc(&w.Bm, B * mp * nq)); GP_TRY(valloc(&w.Wm, B * mp * nq));
+    GP_TRY(valloc(&w.Y1, B * mp * nq)); GP_TRY(valloc(&w.Y2, B * mp * nq));
+    GP_TRY(valloc(&w.yq, B * nq)); GP_TRY(valloc(&w.wtb, B * nq));
+    GP_TRY(valloc(&w.v, B * mp)); GP_TRY(valloc(&w.c1, B * mp)); GP_TRY(valloc(&w.beta, B * mp));
+    GP_TRY(valloc(&w.part_rect, (int64_t)B * mb * nbq * 8)); GP_TRY(valloc(&w.part_sym, (int64_t)B * mb * mb * 8));
+    GP_TRY(valloc(&w.xu_rect, (int64_t)B * nbq * mp * 4)); GP_TRY(valloc(&w.xu_sym, (int64_t)B * mb * mp * 4));
+    GP_TRY(valloc(&w.adam_m, B * (P + mp * GPIMHIP_MAX_DIM))); GP_TRY(valloc(&w.adam_v, B * (P + mp * GPIMHIP_MAX_DIM)));
     std::vector<TileDesc> tl;
     auto mark = [&](int& off, int& n, size_t s) { off = (int)s; n = (int)(tl.size() - s); };
     size_t s = tl.size();
@@ -151,6 +157,7 @@ static int vfe_ensure(gpimhip_ctx* h, int64_t Mu, int64_t N, int d, int P, VfeWs
     HIP_TRY(hipStreamSynchronize(h->stream));
     w.mp = mp;
     w.nq = nq;
+    w.B = B;
     (void)d;
     return GPIMHIP_OK;
 }
@@ -163,6 +170,25 @@ static GemmArgs vg(const double* A, int64_t lda, const double* B, int64_t ldb, d
     g.alpha = alpha; g.beta = beta; g.tiles = t; g.ntiles = n; g.chunk = 64;
     return g;
 }
+// ... with the per-model strides of a lock-step batch; the tile engine picks the launch shape (whole tiles, quadrants, 4 or
+// 8 waves -- which differ in the order of their k-steps) from the tiles of ONE model, so that a model's bits do not depend
+// on the batch it runs in (nmodels = B)
+static GemmArgs vgb(int nmodels, const double* A, int64_t lda, int64_t sA, const double* B, int64_t ldb, int64_t sB, double* C, int64_t ldc,
+                    int64_t sC, const TileDesc* t, int n) {
+    GemmArgs g = vg(A, lda, B, ldb, C, ldc, 1.0, 0.0, t, n);
+    g.sA = sA; g.sB = sB; g.sC = sC;
+    g.shape_div = nmodels;
+    return g;
+}
+
+// u -> theta for B models whose parameter vectors are ustride doubles apart ([u_theta | Xu] each)
+__global__ void theta_kernel_strided(gpimhip_model_t m, const double* __restrict__ u, int64_t ustride, ThetaDev* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        ThetaDev t;
+        theta_from_u(m, u + blockIdx.y * ustride, t);
+        out[blockIdx.y] = t;
+    }
+}
 
 // ------------------------------------------------------------------------------------------
 // small kernels
@@ -173,6 +199,10 @@ __global__ void vfe_cap_kernel(double* __restrict__ Pm, double* __restrict__ Cs,
                                const ThetaDev* __restrict__ th, const double* __restrict__ Pp, int nsplit) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= mp * mp) return;
+    Pm += blockIdx.y * mp * mp;
+    Cs += blockIdx.y * mp * mp;
+    if (Pp) Pp += (int64_t)blockIdx.y * nsplit * mp * mp;
+    th += blockIdx.y;
     const int64_t i = idx / mp, j = idx % mp;
     if (j > i) return;
     double pv;
@@ -191,10 +221,13 @@ __global__ void vfe_cap_kernel(double* __restrict__ Pm, double* __restrict__ Cs,
 // out[i] = sum_j A[i][j] x[j] (j < ncols), one wave per row
 __global__ __launch_bounds__(256) void gemv_n_kernel(const double* __restrict__ A, int64_t ld, int64_t nrows,
                                                      int64_t ncols, const double* __restrict__ x,
-                                                     double* __restrict__ out) {
+                                                     double* __restrict__ out, int64_t a_bs, int64_t x_bs, int64_t o_bs) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t i = (int64_t)blockIdx.x * 4 + wave;
     if (i >= nrows) return;
+    A += blockIdx.y * a_bs;
+    x += blockIdx.y * x_bs;
+    out += blockIdx.y * o_bs;
     const double* row = A + i * ld;
     double s = 0.0;
     for (int64_t j = lane * 2; j < ncols; j += 128) {
@@ -211,16 +244,22 @@ __global__ __launch_bounds__(256) void gemv_n_kernel(const double* __restrict__ 
 // v <- v / s
 __global__ void vfe_scale_kernel(double* __restrict__ v, int64_t n, const ThetaDev* __restrict__ th) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    v += blockIdx.y * n;
+    th += blockIdx.y;
     if (i < n) v[i] = v[i] / th->noise;
 }
 
 // Y2 <- Y2 - W - beta (y - W^T beta)^T      (s * dF/dW)
 __global__ void vfe_gw_kernel(double* __restrict__ Y2, const double* __restrict__ W, const double* __restrict__ beta,
-                              const double* __restrict__ yq, const double* __restrict__ wtb, int64_t mp, int64_t nq) {
+                              const double* __restrict__ yq, const double* __restrict__ wtb, int64_t mp, int64_t nq,
+                              int64_t ld) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= mp * nq) return;
-    const int64_t m = idx / nq, n = idx % nq;
-    Y2[idx] = Y2[idx] - W[idx] - beta[m] * (yq[n] - wtb[n]);
+    const int64_t m = idx / nq, n = idx % nq, e = m * ld + blockIdx.y * nq + n;      // model b: columns b nq ...
+    beta += blockIdx.y * mp;
+    yq += blockIdx.y * nq;
+    wtb += blockIdx.y * nq;
+    Y2[e] = Y2[e] - W[e] - beta[m] * (yq[n] - wtb[n]);
 }
 
 // Mm = Cc^-1 + Cc - 2I + beta beta^T   (full, symmetric; Vc holds the lower triangle of Cc^-1)
@@ -228,6 +267,10 @@ __global__ void vfe_mmat_kernel(const double* __restrict__ Vc, const double* __r
                                 const double* __restrict__ beta, double* __restrict__ Mm, int64_t mp) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= mp * mp) return;
+    Vc += blockIdx.y * mp * mp;
+    Cs += blockIdx.y * mp * mp;
+    Mm += blockIdx.y * mp * mp;
+    beta += blockIdx.y * mp;
     const int64_t i = idx / mp, j = idx % mp;
     const double cinv = (j <= i) ? Vc[i * mp + j] : Vc[j * mp + i];
     Mm[idx] = cinv + Cs[idx] - ((i == j) ? 2.0 : 0.0) + beta[i] * beta[j];
@@ -246,14 +289,20 @@ __global__ __launch_bounds__(256) void vfe_grad_kernel(const double* __restrict_
                                                        const double* __restrict__ Z, int64_t Nz, int d,
                                                        const ThetaDev* __restrict__ th, int ntc,
                                                        double* __restrict__ part, double* __restrict__ xu_part,
-                                                       int64_t mp) {
+                                                       int64_t mp, int64_t g_bs, int64_t xu_bs, int64_t z_bs,
+                                                       int64_t part_bs, int64_t xup_bs) {
     __shared__ double xa[128][5];
     __shared__ double xz[128][5];
     __shared__ double red[4][8];
     __shared__ double rowacc[128][4][4];      // [row][column-lane-group tx&3][k]  (fixed-order combine below)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ci = blockIdx.x / ntc, cj = blockIdx.x % ntc;
-    const ThetaDev t = *th;
+    G += blockIdx.y * g_bs;
+    Xu += blockIdx.y * xu_bs;
+    Z += blockIdx.y * z_bs;
+    part += blockIdx.y * part_bs;
+    xu_part += blockIdx.y * xup_bs;
+    const ThetaDev t = th[blockIdx.y];
     {
         const bool isrow = tid < 128;
         const int loc = tid & 127;
@@ -355,6 +404,7 @@ struct VfeFinalArgs {
     int32_t* iter; const double* bc; int32_t T;
     double *hist_theta, *hist_xu, *loss_out, *grad_out;
     int32_t* info;                  // [0] factorisation status, [1] iterations completed at the first failure
+    int64_t ustride, na;            // lock-step batch (blockIdx.x = model): doubles per model in u / in the Adam state
 };
 
 __device__ double vfe_block_sum(double v, double* red) {
@@ -376,6 +426,23 @@ __global__ __launch_bounds__(256) void vfe_finalize_kernel(VfeFinalArgs a) {
     const int tid = threadIdx.x;
     const int d = a.m.dim;
     const int P = 2 + a.m.n_ls + (a.m.kernel == GPIMHIP_KERNEL_RQ ? 1 : 0);
+    {   // this workgroup's model
+        const int64_t b = blockIdx.x;
+        a.part_rect += b * a.mb * a.nbq * 8; a.part_sym += b * a.mb * a.mb * 8;
+        a.yq += b * a.nq; a.wtb += b * a.nq;
+        a.v += b * a.mp; a.c1 += b * a.mp; a.beta += b * a.mp;
+        a.Cs += b * a.mp * a.mp; a.Vc += b * a.mp * a.mp;
+        a.logdet_part += b * a.mb; a.th += b;
+        a.u += b * a.ustride; a.adam_m += b * a.na; a.adam_v += b * a.na;
+        if (a.iter) {
+            a.iter += b;
+            if (a.hist_theta) a.hist_theta += b * a.T * P;
+            if (a.loss_out) a.loss_out += b * a.T;
+        } else if (a.loss_out) {
+            a.loss_out += b;
+        }
+        if (a.grad_out) a.grad_out += b * a.ustride;
+    }
     // a factorisation of this training loop failed: freeze u, Xu, the Adam state and the histories at
     // the failing iteration (the reference raises there, gpr.py:192) and record how far the loop got
     if (a.iter && *a.info != 0) {
@@ -482,11 +549,20 @@ struct VfeXuArgs {
     const int32_t* iter; const double* bc; int32_t T;
     double *hist_xu, *grad_out;
     const int32_t* info;
+    int64_t ustride, na;            // lock-step batch (blockIdx.y = model)
 };
 __global__ __launch_bounds__(256) void vfe_xu_kernel(VfeXuArgs a) {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= a.Mu * a.d) return;
     if (a.iter && *a.info != 0) return;         // a factorisation of this loop failed: everything stays frozen
+    {
+        const int64_t b = blockIdx.y;
+        a.xu_rect += b * a.nbq * a.mp * 4; a.xu_sym += b * a.mb * a.mp * 4;
+        a.th += b; a.u += b * a.ustride; a.adam_m += b * a.na; a.adam_v += b * a.na;
+        if (a.iter) a.iter += b;
+        if (a.hist_xu) a.hist_xu += b * a.T * a.Mu * a.d;
+        if (a.grad_out) a.grad_out += b * a.ustride;
+    }
     const ThetaDev t = *a.th;
     const double s = t.noise;
     const int64_t mrow = e / a.d;
@@ -518,9 +594,15 @@ __global__ __launch_bounds__(256) void vfe_xu_kernel(VfeXuArgs a) {
 __global__ void vfe_predict_cols_kernel(const double* __restrict__ Ws, const double* __restrict__ LW, int64_t ld,
                                         const double* __restrict__ c1, int64_t mp, int64_t cnt,
                                         const ThetaDev* __restrict__ th, double* __restrict__ mean,
-                                        double* __restrict__ var) {
+                                        double* __restrict__ var, int64_t w_bs, int64_t o_bs) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= cnt) return;
+    Ws += blockIdx.y * w_bs;
+    LW += blockIdx.y * w_bs;
+    c1 += blockIdx.y * mp;
+    th += blockIdx.y;
+    mean += blockIdx.y * o_bs;
+    var += blockIdx.y * o_bs;
     double mu = 0.0, q1 = 0.0, q2 = 0.0;
     for (int64_t m = 0; m < mp; ++m) {
         const double w = Ws[m * ld + j], l = LW[m * ld + j];
@@ -535,13 +617,14 @@ __global__ void vfe_predict_cols_kernel(const double* __restrict__ Ws, const dou
 // ------------------------------------------------------------------------------------------
 // host driver
 // ------------------------------------------------------------------------------------------
-static int launch_grad(gpimhip_ctx* h, const gpimhip_model_t* m, const double* G, int64_t ld, const double* Xu,
-                       int64_t Mu, const double* Z, int64_t Nz, int ntr, int ntc, double* part, double* xu_part,
-                       int64_t mp) {
-    dim3 grid(ntr * ntc), block(256);
+static int launch_grad(gpimhip_ctx* h, const gpimhip_model_t* m, const double* G, int64_t ld, int64_t g_bs, const double* Xu,
+                       int64_t xu_bs, int64_t Mu, const double* Z, int64_t z_bs, int64_t Nz, int ntr, int ntc, double* part,
+                       double* xu_part, int64_t mp, int B) {
+    dim3 grid(ntr * ntc, B), block(256);
+    const int64_t part_bs = (int64_t)ntr * ntc * 8, xup_bs = (int64_t)ntc * mp * 4;
 #define VG_LAUNCH(KIND)                                                                                    \
     hipLaunchKernelGGL((vfe_grad_kernel<KIND>), grid, block, 0, h->stream, G, ld, Xu, Mu, Z, Nz, m->dim,   \
-                       h->theta, ntc, part, xu_part, mp)
+                       h->theta, ntc, part, xu_part, mp, g_bs, xu_bs, z_bs, part_bs, xup_bs)
     switch (m->kernel) {
         case GPIMHIP_KERNEL_RBF: VG_LAUNCH(GPIMHIP_KERNEL_RBF); break;
         case GPIMHIP_KERNEL_MATERN52: VG_LAUNCH(GPIMHIP_KERNEL_MATERN52); break;
@@ -552,37 +635,41 @@ static int launch_grad(gpimhip_ctx* h, const gpimhip_model_t* m, const double* G
     return GPIMHIP_OK;
 }
 
+// The B models of a call: u holds B vectors [u_theta (P) | Xu (Mu x d)] one after the other, X advances by x_bs doubles per
+// model (0: shared inputs).  h->nbatch == w.B throughout (vfe_prepare).
+struct VfeProb { const double* X; int64_t x_bs; int64_t N, Mu; int P; int64_t ustride; };
+
 // theta, Luu^-1 (h->A), W (w.Wm), Cc (w.Cs full), Lc^-1 (h->B), v, c1: shared by loss/grad and predict
-static int vfe_forward(gpimhip_ctx* h, VfeWs& w, const gpimhip_model_t* m, const double* X, int64_t N, int64_t Mu,
-                       const double* u, int P) {
-    const int64_t mp = w.mp, nq = w.nq;
-    const double* Xu = u + P;
-    GP_TRY(launch_theta(h, m, u));
-    GP_TRY(launch_kmat(h, m, Xu, Mu, nullptr, Mu, h->theta, m->jitter, 0, h->A, mp, mp, mp, 1, 1, 0, 0, 0));
+static int vfe_forward(gpimhip_ctx* h, VfeWs& w, const gpimhip_model_t* m, const VfeProb& q, const double* u) {
+    const int64_t mp = w.mp, nq = w.nq, mm = mp * mp;
+    const int B = w.B;
+    const int64_t ldw = (int64_t)B * nq;
+    const double* Xu = u + q.P;
+    hipLaunchKernelGGL(theta_kernel_strided, dim3(1, B), dim3(64), 0, h->stream, *m, u, q.ustride, h->theta);
+    GP_TRY(launch_kmat(h, m, Xu, q.Mu, nullptr, q.Mu, h->theta, m->jitter, 0, h->A, mp, mp, mp, 1, 1, q.ustride, q.ustride, mm));
     GP_TRY(launch_potrf_inv(h, h->A, h->Tm, mp, mp, h->info, 0));
-    GP_TRY(launch_kmat(h, m, Xu, Mu, X, N, h->theta, 0.0, 0, w.Bm, nq, mp, nq, 0, 0, 0, 0, 0));
+    GP_TRY(launch_kmat(h, m, Xu, q.Mu, q.X, q.N, h->theta, 0.0, 0, w.Bm, ldw, mp, nq, 0, 0, q.ustride, q.x_bs, nq));
     {   // W = Luu^-1 B
-        GemmArgs g = vg(h->A, mp, w.Bm, nq, w.Wm, nq, 1.0, 0.0, w.tiles + w.off_lowtri_rect, w.n_lowtri_rect);
+        GemmArgs g = vgb(B, h->A, mp, mm, w.Bm, ldw, nq, w.Wm, ldw, nq, w.tiles + w.off_lowtri_rect, w.n_lowtri_rect);
         GP_TRY(launch_gemm(h, false, true, EPI_STORE, g));
     }
-    {   // P = W W^T (lower) -> h->B, then Cc = I + P/s
-        GemmArgs g = vg(w.Wm, nq, w.Wm, nq, w.ksplit > 1 ? w.Pp : h->B, mp, 1.0, 0.0, w.tiles + w.off_syrk, w.n_syrk);
+    {   // P = W W^T (lower) -> h->B, then Cc = I + P/s.  k-chunk c of model b = "problem" b S + c of the launch: the
+        // operands advance by one chunk of columns (model b starts at column b nq = b S chunks)
         const int S = w.ksplit;
-        if (S > 1) {            // k-chunk c = "problem" c of the launch: operands advance by one chunk of columns
-            g.sA = g.sB = (nq / NB / S) * NB;
-            g.sC = mp * mp;
-        }
-        h->nbatch = S;
+        GemmArgs g = vgb(B, w.Wm, ldw, (nq / NB / S) * NB, w.Wm, ldw, (nq / NB / S) * NB, S > 1 ? w.Pp : h->B, mp, mm,
+                         w.tiles + w.off_syrk, w.n_syrk);
+        h->nbatch = B * S;
         const int rc = launch_gemm(h, false, false, EPI_STORE, g);
-        h->nbatch = 1;
+        h->nbatch = B;
         GP_TRY(rc);
-        hipLaunchKernelGGL(vfe_cap_kernel, dim3((unsigned)((mp * mp + 255) / 256)), dim3(256), 0, h->stream, h->B, w.Cs,
+        hipLaunchKernelGGL(vfe_cap_kernel, dim3((unsigned)((mm + 255) / 256), B), dim3(256), 0, h->stream, h->B, w.Cs,
                            mp, h->theta, (const double*)w.Pp, S);
     }
     GP_TRY(launch_potrf_inv(h, h->B, h->Tm, mp, mp, h->info, 0));   // h->B = Lc^-1, logdet_part <- log diag Lc
     // v = W y / s ; c1 = Lc^-1 v
-    hipLaunchKernelGGL(gemv_n_kernel, dim3((unsigned)((mp + 3) / 4)), dim3(256), 0, h->stream, w.Wm, nq, mp, nq, w.yq, w.v);
-    hipLaunchKernelGGL(vfe_scale_kernel, dim3((unsigned)((mp + 255) / 256)), dim3(256), 0, h->stream, w.v, mp, h->theta);
+    hipLaunchKernelGGL(gemv_n_kernel, dim3((unsigned)((mp + 3) / 4), B), dim3(256), 0, h->stream, w.Wm, ldw, mp, nq, w.yq, w.v,
+                       nq, nq, mp);
+    hipLaunchKernelGGL(vfe_scale_kernel, dim3((unsigned)((mp + 255) / 256), B), dim3(256), 0, h->stream, w.v, mp, h->theta);
     GP_TRY(launch_trmv_lower(h, h->B, mp, mp, w.v, w.c1));
     HIP_TRY(hipGetLastError());
     return GPIMHIP_OK;
@@ -590,62 +677,73 @@ static int vfe_forward(gpimhip_ctx* h, VfeWs& w, const gpimhip_model_t* m, const
 
 struct VfeIter { int32_t* iter; const double* bc; int T; double* hist_theta; double* hist_xu; double* loss; };
 
-static int vfe_loss_grad(gpimhip_ctx* h, VfeWs& w, const gpimhip_model_t* m, const double* X, int64_t N, int64_t Mu,
-                         double* u, int P, int do_adam, const VfeIter* it, double* loss_out, double* grad_out) {
-    const int64_t mp = w.mp, nq = w.nq;
+static int vfe_loss_grad(gpimhip_ctx* h, VfeWs& w, const gpimhip_model_t* m, const VfeProb& q, double* u, int do_adam,
+                         const VfeIter* it, double* loss_out, double* grad_out) {
+    const int64_t mp = w.mp, nq = w.nq, mm = mp * mp;
     const int mb = (int)(mp / NB), nbq = (int)(nq / NB);
+    const int B = w.B, P = q.P;
+    const int64_t ldw = (int64_t)B * nq;
     const double* Xu = u + P;
-    GP_TRY(vfe_forward(h, w, m, X, N, Mu, u, P));
+    GP_TRY(vfe_forward(h, w, m, q, u));
     GP_TRY(launch_lauum(h, h->B, w.Vc, mp, mp, 0));              // Cc^-1 (lower)
-    GP_TRY(launch_gemv_t(h, h->B, mp, mp, mp, w.c1, w.beta, 1, 0, 0, 0));          // beta = Lc^-T c1
-    GP_TRY(launch_gemv_t(h, w.Wm, nq, mp, nq, w.beta, w.wtb, 0, 0, 0, 0));         // W^T beta
+    GP_TRY(launch_gemv_t(h, h->B, mp, mp, mp, w.c1, w.beta, 1, mm, mp, mp));           // beta = Lc^-T c1
+    GP_TRY(launch_gemv_t(h, w.Wm, ldw, mp, nq, w.beta, w.wtb, 0, nq, mp, nq));         // W^T beta
     {   // Y1 = Lc^-1 W ; Y2 = Lc^-T Y1 = Cc^-1 W
-        GemmArgs g1 = vg(h->B, mp, w.Wm, nq, w.Y1, nq, 1.0, 0.0, w.tiles + w.off_lowtri_rect, w.n_lowtri_rect);
+        GemmArgs g1 = vgb(B, h->B, mp, mm, w.Wm, ldw, nq, w.Y1, ldw, nq, w.tiles + w.off_lowtri_rect, w.n_lowtri_rect);
         GP_TRY(launch_gemm(h, false, true, EPI_STORE, g1));
-        GemmArgs g2 = vg(h->B, mp, w.Y1, nq, w.Y2, nq, 1.0, 0.0, w.tiles + w.off_uptri_rect, w.n_uptri_rect);
+        GemmArgs g2 = vgb(B, h->B, mp, mm, w.Y1, ldw, nq, w.Y2, ldw, nq, w.tiles + w.off_uptri_rect, w.n_uptri_rect);
         GP_TRY(launch_gemm(h, true, true, EPI_STORE, g2));
     }
-    hipLaunchKernelGGL(vfe_gw_kernel, dim3((unsigned)((mp * nq + 255) / 256)), dim3(256), 0, h->stream, w.Y2, w.Wm,
-                       w.beta, w.yq, w.wtb, mp, nq);
+    hipLaunchKernelGGL(vfe_gw_kernel, dim3((unsigned)((mp * nq + 255) / 256), B), dim3(256), 0, h->stream, w.Y2, w.Wm,
+                       w.beta, w.yq, w.wtb, mp, nq, ldw);
     {   // G_B' = Luu^-T (s dF/dW) -> Y1
-        GemmArgs g = vg(h->A, mp, w.Y2, nq, w.Y1, nq, 1.0, 0.0, w.tiles + w.off_uptri_rect, w.n_uptri_rect);
+        GemmArgs g = vgb(B, h->A, mp, mm, w.Y2, ldw, nq, w.Y1, ldw, nq, w.tiles + w.off_uptri_rect, w.n_uptri_rect);
         GP_TRY(launch_gemm(h, true, true, EPI_STORE, g));
     }
-    hipLaunchKernelGGL(vfe_mmat_kernel, dim3((unsigned)((mp * mp + 255) / 256)), dim3(256), 0, h->stream, w.Vc, w.Cs,
+    hipLaunchKernelGGL(vfe_mmat_kernel, dim3((unsigned)((mm + 255) / 256), B), dim3(256), 0, h->stream, w.Vc, w.Cs,
                        w.beta, w.Mm, mp);
     {   // G_A' = Luu^-T Mm Luu^-1 (full)
-        GemmArgs g1 = vg(w.Mm, mp, h->A, mp, w.T1, mp, 1.0, 0.0, w.tiles + w.off_sq_colge, w.n_sq_colge);
+        GemmArgs g1 = vgb(B, w.Mm, mp, mm, h->A, mp, mm, w.T1, mp, mm, w.tiles + w.off_sq_colge, w.n_sq_colge);
         GP_TRY(launch_gemm(h, false, true, EPI_STORE, g1));
-        GemmArgs g2 = vg(h->A, mp, w.T1, mp, w.GA, mp, 1.0, 0.0, w.tiles + w.off_sq_rowge, w.n_sq_rowge);
+        GemmArgs g2 = vgb(B, h->A, mp, mm, w.T1, mp, mm, w.GA, mp, mm, w.tiles + w.off_sq_rowge, w.n_sq_rowge);
         GP_TRY(launch_gemm(h, true, true, EPI_STORE, g2));
     }
-    GP_TRY(launch_grad(h, m, w.Y1, nq, Xu, Mu, X, N, mb, nbq, w.part_rect, w.xu_rect, mp));
-    GP_TRY(launch_grad(h, m, w.GA, mp, Xu, Mu, Xu, Mu, mb, mb, w.part_sym, w.xu_sym, mp));
+    GP_TRY(launch_grad(h, m, w.Y1, ldw, nq, Xu, q.ustride, q.Mu, q.X, q.x_bs, q.N, mb, nbq, w.part_rect, w.xu_rect, mp, B));
+    GP_TRY(launch_grad(h, m, w.GA, mp, mm, Xu, q.ustride, q.Mu, Xu, q.ustride, q.Mu, mb, mb, w.part_sym, w.xu_sym, mp, B));
+    const int64_t na = P + mp * GPIMHIP_MAX_DIM;
     VfeFinalArgs a;
     memset(&a, 0, sizeof(a));
-    a.m = *m; a.N = N; a.Mu = Mu; a.mp = mp; a.nq = nq; a.mb = mb; a.nbq = nbq;
+    a.m = *m; a.N = q.N; a.Mu = q.Mu; a.mp = mp; a.nq = nq; a.mb = mb; a.nbq = nbq;
     a.part_rect = w.part_rect; a.part_sym = w.part_sym; a.xu_rect = w.xu_rect; a.xu_sym = w.xu_sym;
     a.yq = w.yq; a.wtb = w.wtb; a.v = w.v; a.c1 = w.c1; a.beta = w.beta; a.Cs = w.Cs; a.Vc = w.Vc;
     a.logdet_part = h->logdet_part; a.th = h->theta; a.u = u; a.adam_m = w.adam_m; a.adam_v = w.adam_v;
     a.do_adam = do_adam;
     a.info = h->info;
+    a.ustride = q.ustride; a.na = na;
     if (it) { a.iter = it->iter; a.bc = it->bc; a.T = it->T; a.hist_theta = it->hist_theta; a.hist_xu = it->hist_xu; a.loss_out = it->loss; }
     else { a.loss_out = loss_out; a.grad_out = grad_out; }
     VfeXuArgs x;
     memset(&x, 0, sizeof(x));
-    x.d = m->dim; x.P = P; x.mb = mb; x.nbq = nbq; x.Mu = Mu; x.mp = mp;
+    x.d = m->dim; x.P = P; x.mb = mb; x.nbq = nbq; x.Mu = q.Mu; x.mp = mp;
     x.xu_rect = w.xu_rect; x.xu_sym = w.xu_sym; x.th = h->theta; x.u = u; x.adam_m = w.adam_m; x.adam_v = w.adam_v;
     x.do_adam = do_adam; x.iter = a.iter; x.bc = a.bc; x.T = a.T; x.hist_xu = a.hist_xu; x.grad_out = a.grad_out;
     x.info = h->info;
-    hipLaunchKernelGGL(vfe_xu_kernel, dim3((unsigned)((Mu * m->dim + 255) / 256)), dim3(256), 0, h->stream, x);
-    hipLaunchKernelGGL(vfe_finalize_kernel, dim3(1), dim3(256), 0, h->stream, a);
+    x.ustride = q.ustride; x.na = na;
+    hipLaunchKernelGGL(vfe_xu_kernel, dim3((unsigned)((q.Mu * m->dim + 255) / 256), B), dim3(256), 0, h->stream, x);
+    hipLaunchKernelGGL(vfe_finalize_kernel, dim3(B), dim3(256), 0, h->stream, a);
     HIP_TRY(hipGetLastError());
     return GPIMHIP_OK;
 }
 
 int check_model(const gpimhip_model_t* m);
 
-static int vfe_prepare(gpimhip_ctx* h, const gpimhip_model_t* m, const double* y, int64_t N, int64_t Mu, int P,
+// workspace for B models, h->nbatch = B until the call returns (VfeBatchScope), y (B x N) padded into w.yq
+struct VfeBatchScope {
+    gpimhip_ctx* h;
+    explicit VfeBatchScope(gpimhip_ctx* h_) : h(h_) {}
+    ~VfeBatchScope() { h->nbatch = 1; }
+};
+static int vfe_prepare(gpimhip_ctx* h, const gpimhip_model_t* m, const double* y, int64_t N, int64_t Mu, int P, int B,
                        VfeWs** w) {
     GP_TRY(check_model(m));
     if (Mu > N) {
@@ -653,49 +751,36 @@ static int vfe_prepare(gpimhip_ctx* h, const gpimhip_model_t* m, const double* y
         return GPIMHIP_E_BADARG;
     }
     HIP_TRY(hipSetDevice(h->device));
-    h->nbatch = 1;
+    h->nbatch = B;
     GP_TRY(ws_ensure(h, Mu));                                  // mp x mp blocked-algorithm workspace
-    GP_TRY(vfe_ensure(h, Mu, N, m->dim, P, w));
+    GP_TRY(vfe_ensure(h, Mu, N, m->dim, P, B, w));
     HIP_TRY(hipMemsetAsync(h->info, 0, sizeof(int32_t), h->stream));
     GP_TRY(launch_pad_copy(h, y, N, (*w)->yq, (*w)->nq));
     return GPIMHIP_OK;
 }
 
-extern "C" {
-
-int gpimhip_vfe_nll_grad(gpimhip_handle h, const gpimhip_model_t* m, const double* X, const double* y, int64_t N,
-                         int64_t Mu, const double* u, double* loss_out, double* grad_out) {
-    FP64_ONLY(h);
-    if (!h || !m || !X || !y || !u || N < 1 || Mu < 1) return GPIMHIP_E_BADARG;
+static int fit_vfe_impl(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X, int64_t x_bs, const double* y, int64_t N,
+                        int64_t Mu, int B, double* u_inout, double lr, int32_t T, double* hist_theta, double* hist_xu,
+                        double* loss_out) {
     const int P = 2 + m->n_ls + (m->kernel == GPIMHIP_KERNEL_RQ ? 1 : 0);
     VfeWs* w;
-    GP_TRY(vfe_prepare(h, m, y, N, Mu, P, &w));
-    GP_TRY(vfe_loss_grad(h, *w, m, X, N, Mu, const_cast<double*>(u), P, 0, nullptr, loss_out, grad_out));
-    return vfe_finish_and_check(h);
-}
-
-int gpimhip_fit_vfe(gpimhip_handle h, const gpimhip_model_t* m, const double* X, const double* y, int64_t N,
-                    int64_t Mu, double* u_inout, double lr, int32_t T, double* hist_theta, double* hist_xu,
-                    double* loss_out) {
-    FP64_ONLY(h);
-    if (!h || !m || !X || !y || !u_inout || N < 1 || Mu < 1 || T < 0) return GPIMHIP_E_BADARG;
-    const int P = 2 + m->n_ls + (m->kernel == GPIMHIP_KERNEL_RQ ? 1 : 0);
-    VfeWs* w;
-    GP_TRY(vfe_prepare(h, m, y, N, Mu, P, &w));
+    VfeBatchScope scope(h);
+    GP_TRY(vfe_prepare(h, m, y, N, Mu, P, B, &w));
+    const VfeProb q{X, x_bs, N, Mu, P, P + Mu * m->dim};
     HIP_TRY(hipMemsetAsync(h->info + 1, 0x7f, sizeof(int32_t), h->stream));
     h->fit_completed = T;
     if (T == 0) return GPIMHIP_OK;
-    const int64_t na = P + w->mp * GPIMHIP_MAX_DIM;
+    const int64_t na = (int64_t)B * (P + w->mp * GPIMHIP_MAX_DIM);
     HIP_TRY(hipMemsetAsync(w->adam_m, 0, na * sizeof(double), h->stream));
     HIP_TRY(hipMemsetAsync(w->adam_v, 0, na * sizeof(double), h->stream));
-    HIP_TRY(hipMemsetAsync(h->iter, 0, sizeof(int32_t), h->stream));
+    HIP_TRY(hipMemsetAsync(h->iter, 0, B * sizeof(int32_t), h->stream));
     // Adam bias-correction table (same libm pow() values as every other path)
     if (h->bc_cap < 2 * (int64_t)T) {
         HIP_TRY(hipStreamSynchronize(h->stream));
         if (h->bc) { (void)hipFree(h->bc); h->bytes -= h->bc_cap * (int64_t)sizeof(double); h->bc = nullptr; }
-        void* q = nullptr;
-        if (hipMalloc(&q, 2 * (size_t)T * sizeof(double)) != hipSuccess) return GPIMHIP_E_NOMEM;
-        h->bc = (double*)q;
+        void* qq = nullptr;
+        if (hipMalloc(&qq, 2 * (size_t)T * sizeof(double)) != hipSuccess) return GPIMHIP_E_NOMEM;
+        h->bc = (double*)qq;
         h->bc_cap = 2 * (int64_t)T;
         h->bytes += h->bc_cap * (int64_t)sizeof(double);
     }
@@ -717,7 +802,7 @@ int gpimhip_fit_vfe(gpimhip_handle h, const gpimhip_model_t* m, const double* X,
         hipError_t e = hipStreamBeginCapture(h->capture_stream, hipStreamCaptureModeRelaxed);
         int rc = GPIMHIP_OK;
         if (e == hipSuccess) {
-            rc = vfe_loss_grad(h, *w, m, X, N, Mu, u_inout, P, 1, &it, nullptr, nullptr);
+            rc = vfe_loss_grad(h, *w, m, q, u_inout, 1, &it, nullptr, nullptr);
             e = hipStreamEndCapture(h->capture_stream, &graph);
         }
         capture_unlock(h);
@@ -733,24 +818,24 @@ int gpimhip_fit_vfe(gpimhip_handle h, const gpimhip_model_t* m, const double* X,
         if (graph) (void)hipGraphDestroy(graph);
         (void)hipGetLastError();
     }
-    for (int t = 0; t < T; ++t) GP_TRY(vfe_loss_grad(h, *w, m, X, N, Mu, u_inout, P, 1, &it, nullptr, nullptr));
+    for (int t = 0; t < T; ++t) GP_TRY(vfe_loss_grad(h, *w, m, q, u_inout, 1, &it, nullptr, nullptr));
     return vfe_finish_and_check(h);
 }
 
-int gpimhip_predict_vfe(gpimhip_handle h, const gpimhip_model_t* m, const double* X, const double* y, int64_t N,
-                        int64_t Mu, const double* u, const double* Xs, int64_t M, double* mean_out,
-                        double* var_out) {
-    FP64_ONLY(h);
-    if (!h || !m || !X || !y || !u || !Xs || N < 1 || Mu < 1 || M < 1 || !mean_out || !var_out) return GPIMHIP_E_BADARG;
+static int predict_vfe_impl(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X, int64_t x_bs, const double* y, int64_t N,
+                            int64_t Mu, int B, const double* u, const double* Xs, int64_t xs_bs, int64_t M, double* mean_out,
+                            double* var_out) {
     const int P = 2 + m->n_ls + (m->kernel == GPIMHIP_KERNEL_RQ ? 1 : 0);
     VfeWs* wp;
-    GP_TRY(vfe_prepare(h, m, y, N, Mu, P, &wp));
+    VfeBatchScope scope(h);
+    GP_TRY(vfe_prepare(h, m, y, N, Mu, P, B, &wp));
     VfeWs& w = *wp;
-    const int64_t mp = w.mp;
+    const VfeProb q{X, x_bs, N, Mu, P, P + Mu * m->dim};
+    const int64_t mp = w.mp, mm = mp * mp;
     const int mb = (int)(mp / NB);
-    GP_TRY(vfe_forward(h, w, m, X, N, Mu, u, P));
-    // test points in slabs of mc columns
-    int64_t mc = std::min<int64_t>(pad_to(M, NB), std::max<int64_t>(NB, ((int64_t)1 << 26) / mp / NB * NB));
+    GP_TRY(vfe_forward(h, w, m, q, u));
+    // test points in slabs of mc columns per model (the slabs of the B models side by side, like the Mu x N matrices)
+    int64_t mc = std::min<int64_t>(pad_to(M, NB), std::max<int64_t>(NB, ((int64_t)1 << 26) / mp / B / NB * NB));
     if (w.mc != mc) {
         HIP_TRY(hipStreamSynchronize(h->stream));
         if (w.Ks) (void)hipFree(w.Ks);
@@ -758,7 +843,7 @@ int gpimhip_predict_vfe(gpimhip_handle h, const gpimhip_model_t* m, const double
         if (w.LW) (void)hipFree(w.LW);
         if (w.ptiles) (void)hipFree(w.ptiles);
         w.Ks = w.Ws = w.LW = nullptr; w.ptiles = nullptr; w.mc = 0;
-        GP_TRY(valloc(&w.Ks, mp * mc)); GP_TRY(valloc(&w.Ws, mp * mc)); GP_TRY(valloc(&w.LW, mp * mc));
+        GP_TRY(valloc(&w.Ks, B * mp * mc)); GP_TRY(valloc(&w.Ws, B * mp * mc)); GP_TRY(valloc(&w.LW, B * mp * mc));
         std::vector<TileDesc> tl;
         for (int ci = mb - 1; ci >= 0; --ci)
             for (int cj = 0; cj < (int)(mc / NB); ++cj) tl.push_back({ci, cj, 0, ci + 1});
@@ -769,18 +854,68 @@ int gpimhip_predict_vfe(gpimhip_handle h, const gpimhip_model_t* m, const double
         w.mc = mc;
     }
     const double* Xu = u + P;
+    const int64_t ldk = (int64_t)B * mc;
     for (int64_t m0 = 0; m0 < M; m0 += mc) {
         const int64_t cnt = std::min(mc, M - m0), cpad = pad_to(cnt, NB);
-        GP_TRY(launch_kmat(h, m, Xu, Mu, Xs + m0 * m->dim, cnt, h->theta, 0.0, 0, w.Ks, mc, mp, cpad, 0, 0, 0, 0, 0));
-        GemmArgs g1 = vg(h->A, mp, w.Ks, mc, w.Ws, mc, 1.0, 0.0, w.ptiles, w.n_ptiles);     // Ws = Luu^-1 Kus
+        GP_TRY(launch_kmat(h, m, Xu, Mu, Xs + m0 * m->dim, cnt, h->theta, 0.0, 0, w.Ks, ldk, mp, cpad, 0, 0, q.ustride, xs_bs, mc));
+        GemmArgs g1 = vgb(B, h->A, mp, mm, w.Ks, ldk, mc, w.Ws, ldk, mc, w.ptiles, w.n_ptiles);     // Ws = Luu^-1 Kus
         GP_TRY(launch_gemm(h, false, true, EPI_STORE, g1));
-        GemmArgs g2 = vg(h->B, mp, w.Ws, mc, w.LW, mc, 1.0, 0.0, w.ptiles, w.n_ptiles);     // Lc^-1 Ws
+        GemmArgs g2 = vgb(B, h->B, mp, mm, w.Ws, ldk, mc, w.LW, ldk, mc, w.ptiles, w.n_ptiles);     // Lc^-1 Ws
         GP_TRY(launch_gemm(h, false, true, EPI_STORE, g2));
-        hipLaunchKernelGGL(vfe_predict_cols_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, h->stream, w.Ws,
-                           w.LW, mc, w.c1, mp, cnt, h->theta, mean_out + m0, var_out + m0);
+        hipLaunchKernelGGL(vfe_predict_cols_kernel, dim3((unsigned)((cnt + 255) / 256), B), dim3(256), 0, h->stream, w.Ws,
+                           w.LW, ldk, w.c1, mp, cnt, h->theta, mean_out + m0, var_out + m0, mc, M);
     }
     HIP_TRY(hipGetLastError());
     return vfe_finish_and_check(h);
+}
+
+extern "C" {
+
+int gpimhip_vfe_nll_grad(gpimhip_handle h, const gpimhip_model_t* m, const double* X, const double* y, int64_t N,
+                         int64_t Mu, const double* u, double* loss_out, double* grad_out) {
+    FP64_ONLY(h);
+    if (!h || !m || !X || !y || !u || N < 1 || Mu < 1) return GPIMHIP_E_BADARG;
+    const int P = 2 + m->n_ls + (m->kernel == GPIMHIP_KERNEL_RQ ? 1 : 0);
+    VfeWs* w;
+    VfeBatchScope scope(h);
+    GP_TRY(vfe_prepare(h, m, y, N, Mu, P, 1, &w));
+    const VfeProb q{X, 0, N, Mu, P, P + Mu * m->dim};
+    GP_TRY(vfe_loss_grad(h, *w, m, q, const_cast<double*>(u), 0, nullptr, loss_out, grad_out));
+    return vfe_finish_and_check(h);
+}
+
+int gpimhip_fit_vfe(gpimhip_handle h, const gpimhip_model_t* m, const double* X, const double* y, int64_t N,
+                    int64_t Mu, double* u_inout, double lr, int32_t T, double* hist_theta, double* hist_xu,
+                    double* loss_out) {
+    FP64_ONLY(h);
+    if (!h || !m || !X || !y || !u_inout || N < 1 || Mu < 1 || T < 0) return GPIMHIP_E_BADARG;
+    return fit_vfe_impl(h, m, X, 0, y, N, Mu, 1, u_inout, lr, T, hist_theta, hist_xu, loss_out);
+}
+
+int gpimhip_fit_vfe_batched(gpimhip_handle h, const gpimhip_model_t* m, const double* X, int64_t x_stride, const double* y,
+                            int64_t N, int64_t Mu, int32_t B, double* u_inout, double lr, int32_t T, double* hist_theta,
+                            double* hist_xu, double* loss_out) {
+    FP64_ONLY(h);
+    if (!h || !m || !X || !y || !u_inout || N < 1 || Mu < 1 || T < 0 || B < 1 || B > 4096 || x_stride < 0) return GPIMHIP_E_BADARG;
+    return fit_vfe_impl(h, m, X, x_stride, y, N, Mu, B, u_inout, lr, T, hist_theta, hist_xu, loss_out);
+}
+
+int gpimhip_predict_vfe(gpimhip_handle h, const gpimhip_model_t* m, const double* X, const double* y, int64_t N,
+                        int64_t Mu, const double* u, const double* Xs, int64_t M, double* mean_out,
+                        double* var_out) {
+    FP64_ONLY(h);
+    if (!h || !m || !X || !y || !u || !Xs || N < 1 || Mu < 1 || M < 1 || !mean_out || !var_out) return GPIMHIP_E_BADARG;
+    return predict_vfe_impl(h, m, X, 0, y, N, Mu, 1, u, Xs, 0, M, mean_out, var_out);
+}
+
+int gpimhip_predict_vfe_batched(gpimhip_handle h, const gpimhip_model_t* m, const double* X, int64_t x_stride, const double* y,
+                                int64_t N, int64_t Mu, int32_t B, const double* u, const double* Xs, int64_t xs_stride,
+                                int64_t M, double* mean_out, double* var_out) {
+    FP64_ONLY(h);
+    if (!h || !m || !X || !y || !u || !Xs || N < 1 || Mu < 1 || M < 1 || !mean_out || !var_out || B < 1 || B > 4096 ||
+        x_stride < 0 || xs_stride < 0)
+        return GPIMHIP_E_BADARG;
+    return predict_vfe_impl(h, m, X, x_stride, y, N, Mu, B, u, Xs, xs_stride, M, mean_out, var_out);
 }
 
 }  // extern "C"

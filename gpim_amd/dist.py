@@ -149,14 +149,19 @@ def run_units(units, unit_fn, out_shape, device=None, concurrency=1):
 
 
 def reconstruct_slices(cube, axis=-1, batch=16, return_hyperparams=False, handle=None, sparse_concurrency=4,
-                       batch_concurrency=1, **recon_kwargs):
+                       batch_concurrency=1, sparse_batch="auto", **recon_kwargs):
     """Independent GP reconstruction of every slice of a 3D / 4D cube along `axis` (configs C3 and
     C5 of SURVEY 8(d)).  Slices are sharded over the ranks; on each GPU the owned slices with the same
     number of observations advance in lock-step, `batch` at a time, through the batched engine
     (gpim_amd.batch) -- a single ~1000-point fit is latency-bound and leaves most of the chip idle.
     Per-slice results are those of ``reconstructor(X_slice, R_slice, X_full, **recon_kwargs).run()``.
     handle: an existing ``_lib.Handle`` for the batched fits (its workspace is reused between calls).
-    sparse_concurrency: how many sparse (inducing-point) slices are fitted at the same time on one GPU.
+    sparse_batch: sparse (inducing-point) slices with the same number of observations advance in lock-step too, up to
+        this many at a time (gpim_amd.batch.fit_predict_batch_sparse); 0 / 1: one reconstructor per slice; "auto": half
+        of the owned slices (at most 8), so that two batches overlap (config C5 on one MI355X, tools/r5_c5_conc.py: one
+        reconstructor per slice on four threads 0.585 s, one batch of 5 0.569, batches of 3 + 2 on two threads 0.485).
+    sparse_concurrency: how many sparse batches (or single sparse slices) are fitted at the same time on one GPU (host
+        threads, each with its own stream and handle).
     batch_concurrency: how many lock-step batches of exact GPs run at the same time on one GPU (own streams).
     batch="auto" picks both from the number of slices this rank owns.
     Returns (mean, sd) cubes on rank 0 (None elsewhere)."""
@@ -183,6 +188,55 @@ def reconstruct_slices(cube, axis=-1, batch=16, return_hyperparams=False, handle
         # throughput), so several slices run CONCURRENTLY, each on its own host thread with its own HIP stream and
         # library handle (the C ABI call that runs the whole training loop releases the GIL); every slice's
         # arithmetic is that of its stand-alone reconstructor.
+        # Slices of equal size go through the lock-step batch of the sparse model (every launch carries all of them: the two
+        # five-block factorisation chains per iteration are shared, the skinny products become chip-sized launches).
+        kw_b = {k: v for k, v in recon_kwargs.items() if k not in ("sparse", "use_gpu")}
+        if sparse_batch == "auto":
+            sparse_batch = len(owned) if len(owned) < 3 else min(8, (len(owned) + 1) // 2)
+        if sparse_batch and int(sparse_batch) > 1 and kw_b.get("precision", "double") == "double":
+            from .batch import fit_predict_batch_sparse
+            by_size = {}
+            for i in owned:
+                by_size.setdefault(int(np.count_nonzero(~np.isnan(cube[i]))), []).append(i)
+            rest, sgroups = [], []
+            for n_obs, idxs in sorted(by_size.items()):
+                for s0 in range(0, len(idxs), int(sparse_batch)):
+                    grp = idxs[s0:s0 + int(sparse_batch)]
+                    if len(grp) < 2:
+                        rest.extend(grp)
+                    else:
+                        sgroups.append(grp)
+
+            def one_sparse_group(grp, own_stream):
+                args = ([grid_of(cube[i]) for i in grp], [cube[i] for i in grp], Xf)
+                if own_stream:
+                    with torch.cuda.device(dev), torch.cuda.stream(torch.cuda.Stream(device=dev)):
+                        out = fit_predict_batch_sparse(*args, **kw_b)
+                        torch.cuda.current_stream().synchronize()
+                else:
+                    out = fit_predict_batch_sparse(*args, handle=handle, **kw_b)
+                return (grp,) + tuple(out)
+
+            # several batches at a time (own host thread / stream / handle each): the two factorisation chains per
+            # iteration of one batch run beside the products of another
+            if int(sparse_concurrency) > 1 and len(sgroups) > 1 and handle is None:
+                from concurrent.futures import ThreadPoolExecutor
+                with ThreadPoolExecutor(max_workers=min(int(sparse_concurrency), len(sgroups))) as pool:
+                    sdone = list(pool.map(lambda g: one_sparse_group(g, True), sgroups))
+            else:
+                sdone = [one_sparse_group(g, False) for g in sgroups]
+            for grp, mean, sd, hist, hist_xu in sdone:
+                hist_h, xu_h = hist.cpu().numpy(), hist_xu.cpu().numpy()
+                n_ls = hist_h.shape[2] - 2 - (1 if str(kw_b.get("kernel", "RBF")) == "RationalQuadratic" else 0)
+                iso = bool(kw_b.get("isotropic"))
+                for k, i in enumerate(grp):
+                    mine[i] = torch.stack([mean[k], sd[k]])
+                    hyper[i] = {"lengthscale": [float(r[1]) if iso else r[1:1 + n_ls].tolist() for r in hist_h[k]],
+                                "noise": [float(r[1 + n_ls]) for r in hist_h[k]],
+                                "variance": [float(r[0]) for r in hist_h[k]],
+                                "inducing_points": list(xu_h[k])}
+            owned = rest
+
         def one_sparse(i):
             with torch.cuda.device(dev), torch.cuda.stream(torch.cuda.Stream(device=dev)):
                 rec = reconstructor(grid_of(cube[i]), cube[i], Xf, verbose=0, **recon_kwargs)
@@ -191,8 +245,10 @@ def reconstruct_slices(cube, axis=-1, batch=16, return_hyperparams=False, handle
                 out = torch.stack(list(rec._last_pred)).reshape((2,) + tuple(cube.shape[1:]))
                 torch.cuda.current_stream().synchronize()
                 return i, out, rec.hyperparams
-        nthreads = max(1, min(int(sparse_concurrency), len(owned)))
-        if nthreads > 1:
+        nthreads = max(1, min(int(sparse_concurrency), len(owned))) if owned else 0
+        if nthreads == 0:
+            results = []
+        elif nthreads > 1:
             from concurrent.futures import ThreadPoolExecutor
             with ThreadPoolExecutor(max_workers=nthreads) as pool:
                 results = list(pool.map(one_sparse, owned))

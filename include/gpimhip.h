@@ -184,6 +184,20 @@ int gpimhip_predict_vfe(gpimhip_handle h, const gpimhip_model_t* m,
                         const double* X, const double* y, int64_t N, int64_t Mu,
                         const double* u, const double* Xs, int64_t M,
                         double* mean_out, double* var_out);
+/* B sparse models of equal N and Mu in lock-step (the slices of a 4D cube, gpim/gpreg/gpr.py:145-155 once per slice):
+ * every launch of the training loop carries all of them (blockIdx.y = model); each model's arithmetic is that of its own
+ * gpimhip_fit_vfe / gpimhip_predict_vfe call.  X: B x N x d with x_stride doubles between models (0: shared inputs),
+ * y: B x N, u: B x (P + Mu*d), hist_theta: B x T x P, hist_xu: B x T x Mu x d, loss_out: B x T (each may be NULL);
+ * Xs: test points, xs_stride doubles between models (0: shared); mean_out / var_out: B x M.  A factorisation that fails in
+ * any model freezes the whole batch at that iteration (GPIMHIP_E_NOT_PD, gpimhip_fit_completed). */
+int gpimhip_fit_vfe_batched(gpimhip_handle h, const gpimhip_model_t* m,
+                            const double* X, int64_t x_stride, const double* y, int64_t N, int64_t Mu, int32_t B,
+                            double* u_inout, double lr, int32_t T,
+                            double* hist_theta, double* hist_xu, double* loss_out);
+int gpimhip_predict_vfe_batched(gpimhip_handle h, const gpimhip_model_t* m,
+                                const double* X, int64_t x_stride, const double* y, int64_t N, int64_t Mu, int32_t B,
+                                const double* u, const double* Xs, int64_t xs_stride, int64_t M,
+                                double* mean_out, double* var_out);
 
 /* ---- exact GP on a fully observed regular grid (Kronecker-structured covariance) ---------------
  * Takes the role of the reference's structured-kernel reconstructor (gpim/gpreg/skgpr.py:399-448, there

@@ -130,7 +130,50 @@ def test_c5_shaped_4d_cube_slices_sparse(gpim):
     R = cube[..., 1]
     Xf = gpim.utils.get_full_grid(R)
     m1, s1, _ = gpim.reconstructor(Xf, R, Xf, verbose=0, **kw).run()
-    np.testing.assert_array_equal(mean[..., 1], m1)
+    np.testing.assert_array_equal(mean[..., 1], m1)      # (the slices run as a lock-step batch: the same bits)
     mo, so, _ = O.reconstructor(Xf, R, Xf, verbose=0, **kw).run()
     assert_allclose(mean[..., 1], mo, atol=1e-7)
     assert_allclose(sd[..., 1], so, atol=1e-7)
+
+
+def test_sparse_lock_step_batch_equals_stand_alone_models(gpim):
+    """gpimhip_fit_vfe_batched / gpimhip_predict_vfe_batched (B sparse models in every launch) against B stand-alone
+    reconstructor(sparse=True) runs: histories of the hyper-parameters and of the inducing inputs, posterior -- the same
+    bits (the tile engine picks its launch shapes from the tiles of one model, GemmArgs::shape_div)."""
+    from gpim_amd.batch import fit_predict_batch_sparse
+    rng = np.random.default_rng(11)
+    i, j, v = np.meshgrid(np.arange(20), np.arange(18), np.arange(6), indexing="ij")
+    Rs = [np.sin(i / 4.0 + 0.7 * b) * np.cos(j / 3.0) * np.exp(-((v - 2.5) / 2.0) ** 2) + 0.02 * rng.standard_normal(i.shape)
+          for b in range(3)]
+    Xf = gpim.utils.get_full_grid(Rs[0])
+    kw = dict(kernel="Matern52", lengthscale=[[1., 1., 1.], [10., 10., 10.]], indpoints=300, learning_rate=0.05, iterations=12)
+    mean, sd, hist, hist_xu = fit_predict_batch_sparse(Xf, Rs, Xf, **kw)
+    assert hist.shape == (3, 12, 5) and hist_xu.shape[:2] == (3, 12)
+    for b in (0, 2):
+        rec = gpim.reconstructor(Xf, Rs[b], Xf, sparse=True, verbose=0, **kw)
+        m1, s1, h1 = rec.run()
+        assert hist_xu.shape[2] == rec._n_ind
+        np.testing.assert_array_equal(hist[b, :, 0].cpu().numpy(), np.asarray(h1["variance"]))
+        np.testing.assert_array_equal(hist[b, :, 1:4].cpu().numpy(), np.asarray(h1["lengthscale"]))
+        np.testing.assert_array_equal(hist[b, :, 4].cpu().numpy(), np.asarray(h1["noise"]))
+        np.testing.assert_array_equal(hist_xu[b, -1].cpu().numpy(), h1["inducing_points"][-1])
+        np.testing.assert_array_equal(mean[b].cpu().numpy(), m1)
+        np.testing.assert_array_equal(sd[b].cpu().numpy(), s1)
+
+
+def test_sparse_slices_batched_and_one_by_one_agree(gpim):
+    """dist.reconstruct_slices(sparse=True): the lock-step batch (default) and one reconstructor per slice (sparse_batch=0)."""
+    from gpim_amd import dist as gd
+    rng = np.random.default_rng(6)
+    i, j, v = np.meshgrid(np.arange(7), np.arange(6), np.arange(9), indexing="ij")
+    cube = np.stack([np.cos(i / 2.0 - s) * np.sin(j / 2.0 + 0.3) * np.exp(-((v - 4.0) / 3.0) ** 2) for s in range(5)], -1)
+    cube = cube + 0.01 * rng.standard_normal(cube.shape)
+    kw = dict(kernel="RBF", sparse=True, indpoints=40, learning_rate=0.05, iterations=15)
+    mb, sb, hb = gd.reconstruct_slices(cube, axis=-1, return_hyperparams=True, **kw)
+    m1, s1, h1 = gd.reconstruct_slices(cube, axis=-1, return_hyperparams=True, sparse_batch=0, **kw)
+    np.testing.assert_array_equal(mb, m1)
+    np.testing.assert_array_equal(sb, s1)
+    for k in range(5):
+        np.testing.assert_array_equal(np.asarray(hb[k]["noise"]), np.asarray(h1[k]["noise"]))
+        np.testing.assert_array_equal(np.asarray(hb[k]["lengthscale"]), np.asarray(h1[k]["lengthscale"]))
+        np.testing.assert_array_equal(hb[k]["inducing_points"][-1], h1[k]["inducing_points"][-1])
