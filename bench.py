@@ -480,7 +480,7 @@ def main():
                 return gdist.gather_to_root({rank: torch.stack([mean_d, sd_d])}, world, (2, M), device=dev)
             return torch.stack([mean_d, sd_d]).unsqueeze(0)
     elif args.workload == "c3cube":
-        from gpim_amd.dist_symm import symm_gp_fit, symm_gp_posterior
+        from gpim_amd.dist_symm import symm_gp_fit, symm_gp_posterior, symm_shard
         T = args.iterations or 3
         _, cube_full = hyperspectral_cube()
         Xc = gpim_amd.utils.get_full_grid(cube_full)
@@ -491,8 +491,9 @@ def main():
         kwc = dict(kernel="Matern52", lengthscale=[[1., 1., 1.], [20., 20., 20.]])
 
         def step():
-            hyp, uc = symm_gp_fit(Xc, cube_full, learning_rate=0.1, iterations=T, **kwc)
-            mean_c, sd_c = symm_gp_posterior(Xc, cube_full, None, uc, **kwc)
+            sh = symm_shard(Xc, cube_full, **kwc)               # the rank's blocks: set-up and workspace are part of the step
+            hyp, uc = symm_gp_fit(Xc, cube_full, learning_rate=0.1, iterations=T, shard=sh, **kwc)
+            mean_c, sd_c = symm_gp_posterior(Xc, cube_full, None, uc, shard=sh, **kwc)
             return mean_c, sd_c, hyp
     elif args.workload == "c2full":
         from gpim_amd.dist_chol import exact_gp_posterior

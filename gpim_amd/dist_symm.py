@@ -72,17 +72,18 @@ class _Shard:
 
 
 def symm_gp_fit(X, y, kernel="Matern52", lengthscale=None, learning_rate=5e-2, iterations=100, seed=0, jitter=1e-5,
-                amplitude=None, group=None, verbose=0, u0=None):
+                amplitude=None, group=None, verbose=0, u0=None, shard=None):
     """Trains ONE exact GP on the complete grid X (d, n_1, ..., n_d) / y (n_1, ..., n_d) across the ranks of the process
     group: the training loop of ``reconstructor.train`` (gpim/gpreg/gpr.py:170-217).  Every rank passes the same arguments
-    and ends with the same hyper-parameters.  Returns (hyperparams, u) like ``dist_chol.exact_gp_fit``."""
+    and ends with the same hyper-parameters.  Returns (hyperparams, u) like ``dist_chol.exact_gp_fit``.
+    shard: a ``symm_shard(X, y, ...)`` of the same model, to share the rank's blocks and workspace with the posterior."""
     rank, world = _world()
     y = np.asarray(y, dtype=np.float64)
     d = y.ndim
     if lengthscale is None:
         lengthscale = [[0.0] * d, [float(np.mean(y.shape) / 2)] * d]
     spec = KernelSpec(kernel, d, lengthscale, amplitude=amplitude, jitter=jitter)
-    sh = _Shard(X, y, spec, rank, world)
+    sh = shard if shard is not None else _Shard(X, y, spec, rank, world)
     lib, H, dev, P = sh.H.lib, sh.H, sh.dev, sh.P
     u = (spec.draw_initial_u(torch.Generator().manual_seed(seed)) if u0 is None
          else torch.as_tensor(u0, dtype=_F64).clone()).to(dev).contiguous()
@@ -121,7 +122,18 @@ def symm_gp_fit(X, y, kernel="Matern52", lengthscale=None, learning_rate=5e-2, i
     return hyper, u
 
 
-def symm_gp_posterior(X, y, Xtest, u, kernel="Matern52", lengthscale=None, jitter=1e-5, amplitude=None, group=None):
+def symm_shard(X, y, kernel="Matern52", lengthscale=None, jitter=1e-5, amplitude=None):
+    """This rank's share of the model (its reflection blocks on its GPU, one library handle): pass it to ``symm_gp_fit`` and
+    ``symm_gp_posterior`` as ``shard=`` so that both use the same workspace (24 GiB per block of the 64^3 cube)."""
+    rank, world = _world()
+    y = np.asarray(y, dtype=np.float64)
+    d = y.ndim
+    if lengthscale is None:
+        lengthscale = [[0.0] * d, [float(np.mean(y.shape) / 2)] * d]
+    return _Shard(X, y, KernelSpec(kernel, d, lengthscale, amplitude=amplitude, jitter=jitter), rank, world)
+
+
+def symm_gp_posterior(X, y, Xtest, u, kernel="Matern52", lengthscale=None, jitter=1e-5, amplitude=None, group=None, shard=None):
     """Posterior mean and standard deviation (noise included) of the same model at the points Xtest (M, d) for the
     unconstrained parameters u (as returned by ``symm_gp_fit``): every rank adds its blocks' shares, one all-reduce of 2 M
     doubles.  Xtest=None predicts on the training grid itself (row-major order of y): the variance is invariant under the
@@ -133,7 +145,7 @@ def symm_gp_posterior(X, y, Xtest, u, kernel="Matern52", lengthscale=None, jitte
     if lengthscale is None:
         lengthscale = [[0.0] * d, [float(np.mean(y.shape) / 2)] * d]
     spec = KernelSpec(kernel, d, lengthscale, amplitude=amplitude, jitter=jitter)
-    sh = _Shard(X, y, spec, rank, world)
+    sh = shard if shard is not None else _Shard(X, y, spec, rank, world)
     lib, H, dev = sh.H.lib, sh.H, sh.dev
     perm = None
     if Xtest is None:

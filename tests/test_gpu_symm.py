@@ -118,6 +118,13 @@ def test_sharded_blocks_world_1_equal_the_batched_model(gpim):
     # Xtest=None: the training grid, the variance on the fundamental domain and mirrored (12 even, 9 odd, 4 even)
     mean_g, sd_g = symm_gp_posterior(X, R, None, u, **kw)
     assert np.abs(mean_g - mo.ravel()).max() < 1e-8 and np.abs(sd_g - so.ravel()).max() < 1e-8
+    # one shard for fit and posterior (shared workspace): the same numbers
+    from gpim_amd.dist_symm import symm_shard
+    sh = symm_shard(X, R, **kw)
+    hyper2, u2 = symm_gp_fit(X, R, learning_rate=0.1, iterations=T, shard=sh, **kw)
+    assert np.array_equal(hyper2["loss"], hyper["loss"])
+    mean_s, sd_s = symm_gp_posterior(X, R, None, u2, shard=sh, **kw)
+    assert np.array_equal(mean_s, mean_g) and np.array_equal(sd_s, sd_g)
 
 
 def test_symmetry_reduced_needs_a_symmetric_axis(gpim):
