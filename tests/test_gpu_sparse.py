@@ -177,3 +177,26 @@ def test_sparse_slices_batched_and_one_by_one_agree(gpim):
         np.testing.assert_array_equal(np.asarray(hb[k]["noise"]), np.asarray(h1[k]["noise"]))
         np.testing.assert_array_equal(np.asarray(hb[k]["lengthscale"]), np.asarray(h1[k]["lengthscale"]))
         np.testing.assert_array_equal(hb[k]["inducing_points"][-1], h1[k]["inducing_points"][-1])
+
+
+def test_sparse_lock_step_batch_with_different_inputs_per_model(gpim):
+    """Slices with different NaN patterns of the same size: every model of the batch has its own inputs (x_stride != 0)
+    and its own initial inducing inputs."""
+    from gpim_amd.batch import fit_predict_batch_sparse
+    rng = np.random.default_rng(21)
+    i, j = np.meshgrid(np.arange(30), np.arange(28), indexing="ij")
+    Rs = []
+    for b in range(3):
+        R = np.sin(i / 5.0 + b) * np.cos(j / 4.0) + 0.02 * rng.standard_normal(i.shape)
+        R.ravel()[rng.permutation(R.size)[:240]] = np.nan          # 600 of 840 pixels observed, a different set per slice
+        Rs.append(R)
+    Xs = [gpim.utils.get_sparse_grid(R) for R in Rs]
+    Xf = gpim.utils.get_full_grid(Rs[0])
+    kw = dict(kernel="RBF", lengthscale=[[1., 1.], [10., 10.]], indpoints=150, learning_rate=0.05, iterations=10)
+    mean, sd, hist, hist_xu = fit_predict_batch_sparse(Xs, Rs, Xf, **kw)
+    for b in range(3):
+        m1, s1, h1 = gpim.reconstructor(Xs[b], Rs[b], Xf, sparse=True, verbose=0, **kw).run()
+        np.testing.assert_array_equal(hist[b, :, 3].cpu().numpy(), np.asarray(h1["noise"]))
+        np.testing.assert_array_equal(hist_xu[b, -1].cpu().numpy(), h1["inducing_points"][-1])
+        np.testing.assert_array_equal(mean[b].cpu().numpy(), m1)
+        np.testing.assert_array_equal(sd[b].cpu().numpy(), s1)
