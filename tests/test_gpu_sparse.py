@@ -200,3 +200,36 @@ def test_sparse_lock_step_batch_with_different_inputs_per_model(gpim):
         np.testing.assert_array_equal(hist_xu[b, -1].cpu().numpy(), h1["inducing_points"][-1])
         np.testing.assert_array_equal(mean[b].cpu().numpy(), m1)
         np.testing.assert_array_equal(sd[b].cpu().numpy(), s1)
+
+
+def test_sparse_batch_non_pd_freezes_the_batch(gpim):
+    """A factorisation that fails in ONE model of a lock-step batch (two identical inducing inputs, no jitter: k(Xu, Xu) is
+    exactly singular) makes the batched fit return GPIMHIP_E_NOT_PD with no iteration completed, like the stand-alone
+    call; the other model's parameters are left as they were."""
+    from gpim_amd import _lib
+    from gpim_amd.kernels import KernelSpec
+    H = _lib.Handle()
+    rng = np.random.default_rng(31)
+    N, Mu, d, B = 300, 40, 2, 2
+    X = torch.from_numpy(rng.uniform(0, 20, size=(N, d)))
+    y = torch.from_numpy(np.sin(X.numpy().sum(1) / 4.0) + 0.05 * rng.standard_normal((B, N)))
+    spec = KernelSpec("RBF", d, [[1.0] * d, [10.0] * d], jitter=0.0)
+    u0 = spec.draw_initial_u(torch.Generator().manual_seed(0))
+    Xu = X[::N // Mu][:Mu].clone()
+    Xu_bad = Xu.clone()
+    Xu_bad[7] = Xu_bad[3]                                # model 1: a repeated inducing input
+    u = torch.stack([torch.cat([u0, Xu.reshape(-1)]), torch.cat([u0, Xu_bad.reshape(-1)])]).cuda().contiguous()
+    u_before = u.clone()
+    m = spec.struct()
+    Xd, yd = X.cuda().contiguous(), y.cuda().contiguous()
+    rc = H.lib.gpimhip_fit_vfe_batched(H.h, ctypes.byref(m), _lib.ptr(Xd), 0, _lib.ptr(yd), N, Mu, B, _lib.ptr(u), 0.05, 20,
+                                       None, None, None)
+    assert rc == _lib.E_NOT_PD
+    assert int(H.lib.gpimhip_fit_completed(H.h)) == 0
+    assert torch.equal(u, u_before)
+    # the good model alone trains
+    u1 = u_before[0].clone().contiguous()
+    _lib.check(H.lib.gpimhip_fit_vfe(H.h, ctypes.byref(m), _lib.ptr(Xd), _lib.ptr(yd), N, Mu, _lib.ptr(u1), 0.05, 20, None, None,
+                                     None))
+    assert torch.isfinite(u1).all() and not torch.equal(u1, u_before[0])
+    H.close()
