@@ -9,6 +9,8 @@
 // Trainable: the kernel parameters (as in the exact GP) AND the inducing inputs Xu.
 // The gradient is analytic (no autograd):  with  beta = Cc^-1 W y / s,  r = y - W^T beta,
 //   dF/dW = (1/s) [ Cc^-1 W - W - beta r^T ]          G_B' = Luu^-T (s dF/dW)       (dF/dB = G_B'/s)
+//         G_B' is formed as  Q W - (Luu^-T beta) r^T  with the small matrix  Q = Luu^-T (Cc^-1 - I):  one Mu x Mu x N product
+//         instead of three
 //   dF/dA = 1/2 Luu^-T [ Cc^-1 + Cc - 2I + beta beta^T ] Luu^-1 = 1/2 G_A'
 //   dF/ds = 1/2 [ -(Mu - tr Cc^-1)/s + N/s - y^T y/s^2 + 2 v^T beta/s - |W^T beta|^2/s^2 ]
 //           - (N s2 - |W|^2)/(2 s^2),   v = W y / s
@@ -57,18 +59,18 @@ struct VfeWs {
     double *Vc = nullptr, *Cs = nullptr, *Mm = nullptr, *T1 = nullptr, *GA = nullptr;     // mp x mp
     double* Pp = nullptr;         // ksplit x mp x mp: partial sums of P = W W^T over k-chunks (vfe_forward)
     int ksplit = 1;               // number of k-chunks (a divisor of nbq)
-    double *Bm = nullptr, *Wm = nullptr, *Y1 = nullptr, *Y2 = nullptr;                      // mp x nq
+    double *Bm = nullptr, *Wm = nullptr, *Y1 = nullptr;                                     // mp x nq
     double *yq = nullptr, *wtb = nullptr;                                                   // nq
-    double *v = nullptr, *c1 = nullptr, *beta = nullptr;                                    // mp
+    double *v = nullptr, *c1 = nullptr, *beta = nullptr, *bt = nullptr;                     // mp
     double *part_rect = nullptr, *part_sym = nullptr;    // per-tile theta sums [tiles][8]
     double *xu_rect = nullptr, *xu_sym = nullptr;        // [nbq][mp][4], [mb][mp][4]
     double *adam_m = nullptr, *adam_v = nullptr;         // P + Mu*d
     TileDesc* tiles = nullptr;
     int n_lowtri_rect = 0, off_lowtri_rect = 0;   // (ci, cj<nbq, kb in [0,ci])      W = Linv B
     int n_syrk = 0, off_syrk = 0;                 // (ci>=cj, kb in [0,nbq))         P = W W^T
-    int n_uptri_rect = 0, off_uptri_rect = 0;     // (ci, cj<nbq, kb in [ci,mb))     Linv^T (.)
     int n_sq_colge = 0, off_sq_colge = 0;         // (ci, cj<mb, kb in [cj,mb))      Mm Linv
     int n_sq_rowge = 0, off_sq_rowge = 0;         // (ci, cj<mb, kb in [ci,mb))      Linv^T T1
+    int n_full_rect = 0, off_full_rect = 0;       // (ci, cj<nbq, kb in [0,mb))      Cc^-1 W
     // predict slab
     int64_t mc = 0;
     double *Ks = nullptr, *Ws = nullptr, *LW = nullptr;   // mp x mc
@@ -89,7 +91,7 @@ static int valloc(T** p, int64_t n) {
     return GPIMHIP_OK;
 }
 static void vfe_free(VfeWs& w) {
-    void* ps[] = {w.Pp, w.Vc, w.Cs, w.Mm, w.T1, w.GA, w.Bm, w.Wm, w.Y1, w.Y2, w.yq, w.wtb, w.v, w.c1, w.beta,
+    void* ps[] = {w.Pp, w.Vc, w.Cs, w.Mm, w.T1, w.GA, w.Bm, w.Wm, w.Y1, w.bt, w.yq, w.wtb, w.v, w.c1, w.beta,
                   w.part_rect, w.part_sym, w.xu_rect, w.xu_sym, w.adam_m, w.adam_v, w.tiles, w.Ks, w.Ws, w.LW,
                   w.ptiles};
     for (void* p : ps)
@@ -124,7 +126,7 @@ static int vfe_ensure(gpimhip_ctx* h, int64_t Mu, int64_t N, int d, int P, int B
         if (nbq % sdiv == 0 && nbq / sdiv >= 2) w.ksplit = sdiv;
     if (w.ksplit > 1) GP_TRY(valloc(&w.Pp, (int64_t)B * w.ksplit * mp * mp));
     GP_TRY(valloc(&w.Bm, B * mp * nq)); GP_TRY(valloc(&w.Wm, B * mp * nq));
-    GP_TRY(valloc(&w.Y1, B * mp * nq)); GP_TRY(valloc(&w.Y2, B * mp * nq));
+    GP_TRY(valloc(&w.Y1, B * mp * nq)); GP_TRY(valloc(&w.bt, B * mp));
     GP_TRY(valloc(&w.yq, B * nq)); GP_TRY(valloc(&w.wtb, B * nq));
     GP_TRY(valloc(&w.v, B * mp)); GP_TRY(valloc(&w.c1, B * mp)); GP_TRY(valloc(&w.beta, B * mp));
     GP_TRY(valloc(&w.part_rect, (int64_t)B * mb * nbq * 8)); GP_TRY(valloc(&w.part_sym, (int64_t)B * mb * mb * 8));
@@ -141,10 +143,6 @@ static int vfe_ensure(gpimhip_ctx* h, int64_t Mu, int64_t N, int d, int P, int B
         for (int cj = 0; cj <= ci; ++cj) tl.push_back({ci, cj, 0, nbq / w.ksplit});
     mark(w.off_syrk, w.n_syrk, s);
     s = tl.size();
-    for (int ci = 0; ci < mb; ++ci)
-        for (int cj = 0; cj < nbq; ++cj) tl.push_back({ci, cj, ci, mb});
-    mark(w.off_uptri_rect, w.n_uptri_rect, s);
-    s = tl.size();
     for (int cj = 0; cj < mb; ++cj)
         for (int ci = 0; ci < mb; ++ci) tl.push_back({ci, cj, cj, mb});
     mark(w.off_sq_colge, w.n_sq_colge, s);
@@ -152,6 +150,10 @@ static int vfe_ensure(gpimhip_ctx* h, int64_t Mu, int64_t N, int d, int P, int B
     for (int ci = 0; ci < mb; ++ci)
         for (int cj = 0; cj < mb; ++cj) tl.push_back({ci, cj, ci, mb});
     mark(w.off_sq_rowge, w.n_sq_rowge, s);
+    s = tl.size();
+    for (int ci = 0; ci < mb; ++ci)
+        for (int cj = 0; cj < nbq; ++cj) tl.push_back({ci, cj, 0, mb});
+    mark(w.off_full_rect, w.n_full_rect, s);
     GP_TRY(valloc(&w.tiles, (int64_t)tl.size()));
     HIP_TRY(hipMemcpyAsync(w.tiles, tl.data(), tl.size() * sizeof(TileDesc), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -249,30 +251,31 @@ __global__ void vfe_scale_kernel(double* __restrict__ v, int64_t n, const ThetaD
     if (i < n) v[i] = v[i] / th->noise;
 }
 
-// Y2 <- Y2 - W - beta (y - W^T beta)^T      (s * dF/dW)
-__global__ void vfe_gw_kernel(double* __restrict__ Y2, const double* __restrict__ W, const double* __restrict__ beta,
-                              const double* __restrict__ yq, const double* __restrict__ wtb, int64_t mp, int64_t nq,
-                              int64_t ld) {
+// G <- G - bt (y - W^T beta)^T      (the rank-one part of G_B' = Luu^-T (s dF/dW); bt = Luu^-T beta)
+__global__ void vfe_gw_kernel(double* __restrict__ G, const double* __restrict__ bt, const double* __restrict__ yq,
+                              const double* __restrict__ wtb, int64_t mp, int64_t nq, int64_t ld) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= mp * nq) return;
     const int64_t m = idx / nq, n = idx % nq, e = m * ld + blockIdx.y * nq + n;      // model b: columns b nq ...
-    beta += blockIdx.y * mp;
+    bt += blockIdx.y * mp;
     yq += blockIdx.y * nq;
     wtb += blockIdx.y * nq;
-    Y2[e] = Y2[e] - W[e] - beta[m] * (yq[n] - wtb[n]);
+    G[e] = G[e] - bt[m] * (yq[n] - wtb[n]);
 }
 
-// Mm = Cc^-1 + Cc - 2I + beta beta^T   (full, symmetric; Vc holds the lower triangle of Cc^-1)
+// Mm = Cc^-1 + Cc - 2I + beta beta^T   (full, symmetric; Vc holds the lower triangle of Cc^-1); Vs = Cc^-1 - I as a full matrix
 __global__ void vfe_mmat_kernel(const double* __restrict__ Vc, const double* __restrict__ Cs,
-                                const double* __restrict__ beta, double* __restrict__ Mm, int64_t mp) {
+                                const double* __restrict__ beta, double* __restrict__ Mm, double* __restrict__ Vs, int64_t mp) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= mp * mp) return;
     Vc += blockIdx.y * mp * mp;
     Cs += blockIdx.y * mp * mp;
     Mm += blockIdx.y * mp * mp;
+    Vs += blockIdx.y * mp * mp;
     beta += blockIdx.y * mp;
     const int64_t i = idx / mp, j = idx % mp;
     const double cinv = (j <= i) ? Vc[i * mp + j] : Vc[j * mp + i];
+    Vs[idx] = cinv - ((i == j) ? 1.0 : 0.0);
     Mm[idx] = cinv + Cs[idx] - ((i == j) ? 2.0 : 0.0) + beta[i] * beta[j];
 }
 
@@ -688,20 +691,20 @@ static int vfe_loss_grad(gpimhip_ctx* h, VfeWs& w, const gpimhip_model_t* m, con
     GP_TRY(launch_lauum(h, h->B, w.Vc, mp, mp, 0));              // Cc^-1 (lower)
     GP_TRY(launch_gemv_t(h, h->B, mp, mp, mp, w.c1, w.beta, 1, mm, mp, mp));           // beta = Lc^-T c1
     GP_TRY(launch_gemv_t(h, w.Wm, ldw, mp, nq, w.beta, w.wtb, 0, nq, mp, nq));         // W^T beta
-    {   // Y1 = Lc^-1 W ; Y2 = Lc^-T Y1 = Cc^-1 W
-        GemmArgs g1 = vgb(B, h->B, mp, mm, w.Wm, ldw, nq, w.Y1, ldw, nq, w.tiles + w.off_lowtri_rect, w.n_lowtri_rect);
-        GP_TRY(launch_gemm(h, false, true, EPI_STORE, g1));
-        GemmArgs g2 = vgb(B, h->B, mp, mm, w.Y1, ldw, nq, w.Y2, ldw, nq, w.tiles + w.off_uptri_rect, w.n_uptri_rect);
-        GP_TRY(launch_gemm(h, true, true, EPI_STORE, g2));
-    }
-    hipLaunchKernelGGL(vfe_gw_kernel, dim3((unsigned)((mp * nq + 255) / 256), B), dim3(256), 0, h->stream, w.Y2, w.Wm,
-                       w.beta, w.yq, w.wtb, mp, nq, ldw);
-    {   // G_B' = Luu^-T (s dF/dW) -> Y1
-        GemmArgs g = vgb(B, h->A, mp, mm, w.Y2, ldw, nq, w.Y1, ldw, nq, w.tiles + w.off_uptri_rect, w.n_uptri_rect);
-        GP_TRY(launch_gemm(h, true, true, EPI_STORE, g));
-    }
+    // Mm (for G_A') and Cc^-1 - I as a full matrix (in T1, which G_A' overwrites below)
     hipLaunchKernelGGL(vfe_mmat_kernel, dim3((unsigned)((mm + 255) / 256), B), dim3(256), 0, h->stream, w.Vc, w.Cs,
-                       w.beta, w.Mm, mp);
+                       w.beta, w.Mm, w.T1, mp);
+    {   // G_B' = Luu^-T (Cc^-1 W - W - beta r^T) = Q W - bt r^T,  Q = Luu^-T (Cc^-1 - I) (Mu x Mu, in GA until G_A' needs
+        // it), bt = Luu^-T beta: ONE Mu x Mu x N product for what were three (Lc^-1 W, Lc^-T (.), Luu^-T (.)) -- 1250 instead
+        // of 2250 tile k-blocks per model at config C5's size
+        GemmArgs gq = vgb(B, h->A, mp, mm, w.T1, mp, mm, w.GA, mp, mm, w.tiles + w.off_sq_rowge, w.n_sq_rowge);
+        GP_TRY(launch_gemm(h, true, true, EPI_STORE, gq));
+        GP_TRY(launch_gemv_t(h, h->A, mp, mp, mp, w.beta, w.bt, 1, mm, mp, mp));
+        GemmArgs g = vgb(B, w.GA, mp, mm, w.Wm, ldw, nq, w.Y1, ldw, nq, w.tiles + w.off_full_rect, w.n_full_rect);
+        GP_TRY(launch_gemm(h, false, true, EPI_STORE, g));
+    }
+    hipLaunchKernelGGL(vfe_gw_kernel, dim3((unsigned)((mp * nq + 255) / 256), B), dim3(256), 0, h->stream, w.Y1, w.bt, w.yq,
+                       w.wtb, mp, nq, ldw);
     {   // G_A' = Luu^-T Mm Luu^-1 (full)
         GemmArgs g1 = vgb(B, w.Mm, mp, mm, h->A, mp, mm, w.T1, mp, mm, w.tiles + w.off_sq_colge, w.n_sq_colge);
         GP_TRY(launch_gemm(h, false, true, EPI_STORE, g1));

@@ -159,7 +159,7 @@ def reconstruct_slices(cube, axis=-1, batch=16, return_hyperparams=False, handle
     sparse_batch: sparse (inducing-point) slices with the same number of observations advance in lock-step too, up to
         this many at a time (gpim_amd.batch.fit_predict_batch_sparse); 0 / 1: one reconstructor per slice; "auto": half
         of the owned slices (at most 8), so that two batches overlap (config C5 on one MI355X, tools/r5_c5_conc.py: one
-        reconstructor per slice on four threads 0.585 s, one batch of 5 0.569, batches of 3 + 2 on two threads 0.485).
+        reconstructor per slice on four threads 0.54 s, one batch of 5 0.48, batches of 3 + 2 on two threads 0.40).
     sparse_concurrency: how many sparse batches (or single sparse slices) are fitted at the same time on one GPU (host
         threads, each with its own stream and handle).
     batch_concurrency: how many lock-step batches of exact GPs run at the same time on one GPU (own streams).
