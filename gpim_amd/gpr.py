@@ -204,7 +204,6 @@ class reconstructor:
         if self.do_structured:
             self._axes_d = self._to_device(np.concatenate(self._axes))
             self._taxes = self._grid_axes(Xtest) if Xtest is not None else (self._axes, self._axes_n)
-        self.model = _ModelView(self)
         self.learning_rate = learning_rate
         self.iterations = iterations
         self.indpoints_all = []
@@ -217,6 +216,14 @@ class reconstructor:
             "inducing_points": self.indpoints_all
         }
         self._last_pred = None       # (mean, sd) device tensors of the latest predict()
+
+    @property
+    def model(self):
+        """The ``model`` facade of the reference object (``model.X`` / ``model.y`` settable, ``model.kernel``).  Built per
+        access: a stored view would close a reference cycle with this object, and the library handle -- with its N x N
+        workspaces -- would then live until the cyclic collector happens to run (seen as a 50-65 ms hipFree inside the NEXT
+        Bayesian-optimisation run's first training, tools/r5_c4_steps.py)."""
+        return _ModelView(self)
 
     # ------------------------------------------------------------------ helpers
     @staticmethod
