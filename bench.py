@@ -540,6 +540,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    _settle_interpreter()          # (a full pass of the cyclic collector inside the timed region is harness time, see there)
     tot, cnt = ctypes.c_double(), ctypes.c_int64()
     # c2 (large N) is enqueued launch by launch, never graph-captured: its stage timers sit inside the timed region.  c1 / c3 replay one captured iteration per Adam step, which the timers would switch off: their
     # stage breakdown comes from ONE extra step after the timed ones.
