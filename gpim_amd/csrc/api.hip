@@ -95,6 +95,7 @@ static void ws_release_matrix(gpimhip_ctx* h) {
     dev_free(h, &h->Tm, mat_doubles(h, B * np * h->ld));
     dev_free(h, &h->dinv, mat_doubles(h, B * nb * NB * NB));
     dev_free(h, &h->dinvB, B * nb * NB * NB);
+    dev_free(h, &h->pcopy, B * NB * NB);
     dev_free(h, &h->ypad, B * np);
     dev_free(h, &h->z, B * np);
     dev_free(h, &h->alpha, B * np);
@@ -135,6 +136,7 @@ static int ws_ensure_b(gpimhip_ctx* h, int64_t N, int B, int padded, bool matric
                       (rc = dev_alloc(h, &h->Tm, mat_doubles(h, B * np * ld))))) ||
         (rc = dev_alloc(h, &h->dinv, mat_doubles(h, B * nb * NB * NB))) ||
         (rc = dev_alloc(h, &h->dinvB, B * nb * NB * NB)) ||
+        (rc = dev_alloc(h, &h->pcopy, (int64_t)B * NB * NB)) ||
         (rc = dev_alloc(h, &h->ypad, B * np)) || (rc = dev_alloc(h, &h->z, B * np)) ||
         (rc = dev_alloc(h, &h->alpha, B * np)) || (rc = dev_alloc(h, &h->logdet_part, B * nb)) ||
         (rc = dev_alloc(h, &h->grad_part, B * nb * (nb + 1) / 2 * 8)) || (rc = dev_alloc(h, &h->gemv_part, B * 8 * np)) || (rc = dev_alloc(h, &h->theta, (int64_t)B)) ||

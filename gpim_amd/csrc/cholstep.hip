@@ -32,6 +32,9 @@
 #define STEP_W 4
 #endif
 
+// flag in the kb1 field of a hosted update tile (beside its kind, bits 16-18): store the result in StepArgs::Pcopy as well
+#define TILE_COPY (1 << 19)
+
 struct StepArgs {
     double* A; int64_t ld; int kblk; int nb;
     double* dinv_all; double* dinvB_all; double* logdet; int32_t* info;
@@ -44,6 +47,8 @@ struct StepArgs {
     int pb_off, pb_cnt, hb_off, hb_cnt, swap;
     double* Tm;                 // != nullptr: fused inverse -- temporary of the T phases; the factorisation role writes
                                 // the INVERSE of its block into A's diagonal block (a leaf of the inverse) instead of dinv_all
+    double* Pcopy;              // B x 128 x 128: the update tile flagged TILE_COPY (tile (kblk+1, kblk) of the column update) is
+                                // stored here too -- what panel_solve_diag_kernel reads instead of the block row it overwrites
     GemmArgs g;                 // hosted tiles; trailing-update tiles are NT with alpha = -1, beta = 1
 };
 
@@ -71,10 +76,17 @@ __global__ __launch_bounds__(NTH, 4) void chol_step_kernel(StepArgs a) {
         int quad;
         const int pos = gemm_tile_pos<FTM, FTN>(a.g.ntiles, a.g.chunk, b - 8, quad);
         TileDesc t = a.g.tiles[pos];
-        const int kind = t.kb1 >> 16;
+        const int kind = (t.kb1 >> 16) & 7;
+        const bool copy = (t.kb1 & TILE_COPY) != 0;
         t.kb1 &= 0xffff;
         if (kind == 0) {
-            gemm_tile_core<false, false, EPI_STORE, 8, FTM, FTN, 2, RAG>(a.g, t, quad, pb, smem);
+            if (copy && a.Pcopy) {
+                GemmArgs g = a.g;
+                g.C2 = a.Pcopy + (int64_t)pb * (NB * NB);
+                gemm_tile_core<false, false, EPI_STORE, 8, FTM, FTN, 2, RAG>(g, t, quad, pb, smem);
+            } else {
+                gemm_tile_core<false, false, EPI_STORE, 8, FTM, FTN, 2, RAG>(a.g, t, quad, pb, smem);
+            }
         } else {
             GemmArgs g = a.g;
             if (kind <= 2) { g.C = a.Tm; g.alpha = 1.0; g.beta = kind == 2 ? 1.0 : 0.0; }
@@ -190,6 +202,130 @@ __global__ __launch_bounds__(256, 2) void diag_update_kernel(double* __restrict_
     d4 acc0 = (d4){0.0, 0.0, 0.0, 0.0}, acc1 = acc0;      // two chains: a lone dependent fp64 MFMA chain issues at half rate
     const double* Sa = S + (wm * 16 + (lane & 15)) * LDS_LD + (lane >> 4);
     const double* Sb = S + (32 + wn * 16 + (lane & 15)) * LDS_LD + (lane >> 4);
+#pragma unroll
+    for (int s = 0; s < 32; s += 2) {
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Sa[4 * s], Sb[4 * s], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Sa[4 * s + 4], Sb[4 * s + 4], acc1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) C[(int64_t)(4 * rg) * ld] = cv[rg] - (acc0[rg] + acc1[rg]);
+}
+
+// F_j and D_j in ONE launch (double precision, the next diagonal tile only).  512 threads: waves 0-3 and waves 4-7 each
+// solve one 32-row strip (the arithmetic of panel_solve_kernel, so the same bits).  Workgroups 0..9: the ten 32x32 blocks
+// (a, b), a >= b, of the next diagonal tile; each solves the strips a and b of block row kblk+1 ITSELF, keeps the results in
+// LDS and applies its block of  A[jj,jj] -= S S^T  (waves 0-3, the arithmetic of diag_update_kernel); block (a, a) also
+// stores strip a of L.  Workgroups 10..: two strips each of the block rows below.  The strips of block row kblk+1 are read
+// from Pcopy -- the copy the step launch made of A[kblk+1, kblk] -- because several workgroups read a strip that one of them
+// overwrites.  One launch boundary and one kernel start-up less per block column.
+__global__ __launch_bounds__(512, 2) void panel_solve_diag_kernel(double* __restrict__ A, int64_t ld, int kblk, int nb,
+                                                                  const double* __restrict__ dinvB_all,
+                                                                  const double* __restrict__ Pcopy, int b_off) {
+    constexpr int LDS_LD = 130, ROWS = 32, MTS = 2;
+    __shared__ __attribute__((aligned(16))) double S[2 * ROWS * LDS_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, half = tid >> 8;
+    const int by = blockIdx.y + b_off;
+    A += (int64_t)by * nb * NB * ld;
+    Pcopy += (int64_t)by * (NB * NB);
+    const d2* DB = reinterpret_cast<const d2*>(dinvB_all + ((int64_t)by * nb + kblk) * (NB * NB));
+    const bool diag = blockIdx.x < 10;
+    int a = 0, b = 0;
+    if (diag) {
+        const int q = blockIdx.x;
+        a = q < 1 ? 0 : q < 3 ? 1 : q < 6 ? 2 : 3;
+        b = q - a * (a + 1) / 2;
+    }
+    const int jj = kblk + 1;
+    // this half's strip: strip a / b of block row jj (blocks of the diagonal tile), or one of the strips below
+    const int strip = diag ? (half == 0 ? a : b) : 4 + 2 * (int)(blockIdx.x - 10) + half;
+    const bool work = !diag || half == 0 || b != a;           // (block (a, a): the second half has nothing to solve)
+    double* P = A + ((int64_t)jj * NB + strip * ROWS) * ld + (int64_t)kblk * NB;
+    double* Ss = S + half * ROWS * LDS_LD;
+    // the strip: one 1 KB row per wave-wide load, global -> LDS directly
+    if (work) {
+#pragma unroll
+        for (int i = 0; i < ROWS / 4; ++i) {
+            const int row = wave * (ROWS / 4) + i;
+            const double* src = diag ? Pcopy + (strip * ROWS + row) * NB + lane * 2 : P + (int64_t)row * ld + lane * 2;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(Ss + row * LDS_LD), 16, 0, 0);
+        }
+    }
+    // B fragments of both column tiles of this wave (panel_solve_kernel)
+    const int t0 = wave, t1 = 7 - wave, n0 = 2 * t0 + 2;
+    d2 bf[18];
+    if (work) {
+#pragma unroll
+        for (int q = 0; q < 18; ++q) {
+            const int t = q < n0 ? t0 : t1, s2 = q < n0 ? q : q - n0;
+            bf[q] = DB[(t * 16 + s2) * 64 + lane];
+        }
+    }
+    // the block of the diagonal tile this workgroup updates (waves 0-3: one 16x16 MFMA tile each)
+    const int wm = wave >> 1, wn = wave & 1;
+    double* C = A + ((int64_t)jj * NB + a * 32 + wm * 16 + (lane >> 4)) * ld + (int64_t)jj * NB + b * 32 + wn * 16 + (lane & 15);
+    double cv[4] = {0.0, 0.0, 0.0, 0.0};
+    if (diag && half == 0) {
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) cv[rg] = C[(int64_t)(4 * rg) * ld];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const d4 zero = (d4){0.0, 0.0, 0.0, 0.0};
+    d4 acc[2][MTS];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int mt = 0; mt < MTS; ++mt) acc[x][mt] = zero;
+    if (work) {
+        const double* Sa = Ss + (lane & 15) * LDS_LD + (lane >> 4);
+#pragma unroll
+        for (int q = 0; q < 18; ++q) {
+            const bool first = q < n0;          // wave-uniform
+            const int s2 = first ? q : q - n0;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int s = 2 * s2 + e;
+#pragma unroll
+                for (int mt = 0; mt < MTS; ++mt) {
+                    const double av = Sa[mt * 16 * LDS_LD + 4 * s];
+                    if (first) acc[0][mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bf[q][e], acc[0][mt], 0, 0, 0);
+                    else acc[1][mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bf[q][e], acc[1][mt], 0, 0, 0);
+                }
+            }
+        }
+        // the solved strip: to L (the strips below, and strip a from block (a, a)) ...
+        if (!diag || (a == b && half == 0)) {
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                const int t = x == 0 ? t0 : t1;
+#pragma unroll
+                for (int mt = 0; mt < MTS; ++mt)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg)
+                        P[(int64_t)(mt * 16 + (lane >> 4) + 4 * rg) * ld + t * 16 + (lane & 15)] = acc[x][mt][rg];
+            }
+        }
+    }
+    if (!diag) return;                          // (the whole workgroup)
+    // ... and over the strip it came from in LDS (every wave of the half has read all of it: barrier first)
+    __syncthreads();
+    if (work) {
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            const int t = x == 0 ? t0 : t1;
+#pragma unroll
+            for (int mt = 0; mt < MTS; ++mt)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg)
+                    Ss[(mt * 16 + (lane >> 4) + 4 * rg) * LDS_LD + t * 16 + (lane & 15)] = acc[x][mt][rg];
+        }
+    }
+    __syncthreads();
+    if (half != 0) return;
+    d4 acc0 = zero, acc1 = zero;                // two chains, as diag_update_kernel
+    const double* Sa = S + (wm * 16 + (lane & 15)) * LDS_LD + (lane >> 4);
+    const double* Sb = S + ((b != a ? ROWS : 0) + wn * 16 + (lane & 15)) * LDS_LD + (lane >> 4);
 #pragma unroll
     for (int s = 0; s < 32; s += 2) {
         acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Sa[4 * s], Sb[4 * s], acc0, 0, 0, 0);
@@ -595,7 +731,13 @@ static int step_plan_build(gpimhip_ctx* h, int nb, StepPlan& P, bool with_invers
     P.diag.assign(nb, {0, 0});
     P.bulk_rest.assign(npanel, {0, 0});
     P.post.clear();
+    P.copy.assign(nb, 0);
     for (int j = 0; j < nb; ++j) {
+        // the column update's tile (j+1, j) -- the last operation on it, in the step launch of column j (both halves of a
+        // split batch host it before their F_j) -- also goes to the copy that panel_solve_diag_kernel reads
+        if (!fp32)
+            for (TileDesc& t : fill[j])
+                if ((t.kb1 >> 16) == TK_UPDATE && t.ci == j + 1 && t.cj == j) { t.kb1 |= TILE_COPY; P.copy[j] = 1; }
         P.fill[j] = put(fill[j]);
         const int p1 = std::min((j / W) * W + W, nb);
         // diagonal tiles D_j updates (count): double precision the next one only (the others receive column j through
@@ -694,8 +836,15 @@ static int launch_step(gpimhip_ctx* h, StepArgs& a, bool potf2, int n, int q, co
 }
 
 // F_j and D_j for the problems b_off .. b_off + cnt - 1 of the batch
-static int launch_solve_diag(gpimhip_ctx* h, double* A, int64_t ld, int j, int nb, int ndiag, int b_off, int cnt) {
+static int launch_solve_diag(gpimhip_ctx* h, double* A, int64_t ld, int j, int nb, int ndiag, int b_off, int cnt,
+                             bool fused = false) {
     if (j + 1 >= nb || cnt <= 0) return GPIMHIP_OK;
+    if (fused) {        // the step launch of column j left a copy of A[j+1, j] in h->pcopy (TILE_COPY)
+        hipLaunchKernelGGL(panel_solve_diag_kernel, dim3(10 + 2 * (nb - j - 2), cnt), dim3(512), 0, h->stream, A, ld, j, nb,
+                           (const double*)h->dinvB, (const double*)h->pcopy, b_off);
+        HIP_TRY(hipGetLastError());
+        return GPIMHIP_OK;
+    }
     if (cnt > 4)        // (C3, four concurrent batches of 16: 0.924 -> 0.912 s; same bits)
         hipLaunchKernelGGL(panel_solve_kernel<4>, dim3(4 * (nb - j - 1), cnt), dim3(256), 0, h->stream, A, ld, j, nb,
                            (const double*)h->dinvB, b_off);
@@ -729,6 +878,11 @@ int launch_potrf_steps(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_
     a.A = A; a.ld = ld; a.nb = nb; a.Tm = Tm;
     a.dinv_all = h->dinv; a.dinvB_all = h->dinvB; a.logdet = h->logdet_part; a.info = info;
     a.col_off = 0;
+    a.Pcopy = h->pcopy;
+    // F_j + D_j as one launch where the step launch left the copy it reads (not for the ragged last block row, whose
+    // padding rows the hosted tile skips)
+    const bool no_fused = getenv("GPIMHIP_NO_FUSED_FD") != nullptr;     // (run-time knob: F_j and D_j as two launches)
+    auto fused = [&](int j) { return !no_fused && h->pcopy && P.copy[j] && P.diag[j].n == 1 && !(rag && j + 2 == nb); };
     {
         StageTimer t(h, 0);
         auto hosted_list = [&](int j, int problems, int& q) {
@@ -758,11 +912,11 @@ int launch_potrf_steps(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_
                 nf = hosted_list(j, c1, q);
                 const int sa[4] = {0, c0, c0, c1};                             // factor half 0 || pending tiles of half 1
                 GP_TRY(launch_step(h, a, true, nf, q, sa));
-                GP_TRY(launch_solve_diag(h, A, ld, j, nb, P.diag[j].n, 0, c0));
+                GP_TRY(launch_solve_diag(h, A, ld, j, nb, P.diag[j].n, 0, c0, fused(j)));
                 nf = j + 1 < nb ? hosted_list(j + 1, c0, q) : 0;
                 const int sb[4] = {c0, c1, 0, c0};                             // factor half 1 || pending tiles of half 0, next step
                 GP_TRY(launch_step(h, a, true, nf, q, sb));
-                GP_TRY(launch_solve_diag(h, A, ld, j, nb, P.diag[j].n, c0, c1));
+                GP_TRY(launch_solve_diag(h, A, ld, j, nb, P.diag[j].n, c0, c1, fused(j)));
             }
         } else {
             for (int j = 0; j < nb; ++j) {
@@ -770,7 +924,7 @@ int launch_potrf_steps(gpimhip_ctx* h, double* A, int64_t np, int64_t ld, int32_
                 int q;
                 const int nf = hosted_list(j, B, q);
                 GP_TRY(launch_step(h, a, true, nf, q, nullptr, P.pair[j] != 0));
-                GP_TRY(launch_solve_diag(h, A, ld, j, nb, P.diag[j].n, 0, B));
+                GP_TRY(launch_solve_diag(h, A, ld, j, nb, P.diag[j].n, 0, B, fused(j)));
             }
         }
     }
@@ -803,6 +957,7 @@ int launch_panel_chain(gpimhip_ctx* h, double* A, int64_t ld, int p0, int p1, in
     a.A = A; a.ld = ld; a.nb = nb; a.Tm = nullptr;
     a.dinv_all = h->dinv; a.dinvB_all = h->dinvB; a.logdet = h->logdet_part; a.info = info;
     a.col_off = 0;
+    a.Pcopy = nullptr;
     for (int j = p0; j < p1; ++j) {
         a.kblk = j;
         const PlanRange f = colfill[j - p0];

@@ -83,6 +83,7 @@ struct StepPlan {
     std::vector<int32_t> n_update;      // per block column: k-blocks of trailing update among fill[] (sets the hosted shape)
     std::vector<int32_t> n_all;         // per block column: all hosted k-blocks (shape of the launches of a large batch)
     std::vector<uint8_t> pair;          // per block column: its step launch runs hosted quadrants two per CU (cholstep.hip)
+    std::vector<uint8_t> copy;          // per block column: its step launch leaves a copy of A[j+1, j] (TILE_COPY): F_j and D_j fuse
 };
 
 // Launch plans of the distributed (block-column-cyclic, 1 x P) factorisation for one rank (api.hip: gpimhip_dist_*)
@@ -134,6 +135,7 @@ struct gpimhip_ctx {
     double* Tm = nullptr;           // np x np : trtri temporary
     double* dinv = nullptr;         // nb x 128 x 128 inverses of diagonal blocks
     double* dinvB = nullptr;        // the same in MFMA B-operand order (panel solve of cholstep.hip); fp64 handles
+    double* pcopy = nullptr;        // B x 128 x 128: A[j+1, j] as the step launch of column j left it (cholstep.hip: panel_solve_diag_kernel)
     double* ypad = nullptr;         // np
     double* z = nullptr;            // np  (L^-1 y)
     double* alpha = nullptr;        // np  (K^-1 y)
@@ -291,6 +293,8 @@ struct GemmArgs {
                                            // inside a strip: 64 consecutive tiles are an 8 x 8 patch (with chunk = 64 one
                                            // patch per XCD at a time: 8 + 8 operand panels for 64 tiles); needs kfix0 / kfix1
     double* colpart; int64_t ld_colpart;   // EPI_COLSUMSQ: colpart[ci*ld + cj*128 + col]
+    double* C2;                            // != nullptr: the output tile is ALSO stored here as a dense 128 x 128 block (set per tile by
+                                           // the Cholesky step kernel: the copy of A[j+1, j] that the fused panel-solve / diagonal-update launch reads)
     int shape_div;                         // > 1: the launch shape is chosen for ntiles * batch / shape_div tiles (the sparse model's
                                            // lock-step batches: every model gets the tile shapes -- hence the bits -- of its own launch)
     int64_t sA, sB, sC, sColpart;          // per-problem (blockIdx.y) strides in elements

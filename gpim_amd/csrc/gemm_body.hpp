@@ -418,8 +418,12 @@ __device__ __forceinline__ void gemm_tile_core(GemmArgs g, TileDesc t, const int
 #pragma unroll
                 for (int j = 0; j < NTL; ++j)
 #pragma unroll
-                    for (int rg = 0; rg < 4; ++rg)
-                        g.C[(crow0 + i * 16 + 4 * rg) * g.ldc + ccol0 + j * 16] = alpha * acc[i][j][rg] + beta * cv[j][rg];
+                    for (int rg = 0; rg < 4; ++rg) {
+                        const double v = alpha * acc[i][j][rg] + beta * cv[j][rg];
+                        g.C[(crow0 + i * 16 + 4 * rg) * g.ldc + ccol0 + j * 16] = v;
+                        if (g.C2)       // (uniform: one tile of a launch at most)
+                            g.C2[(qi + wm * WROWS + (lane >> 4) + i * 16 + 4 * rg) * NB + qj + wn * WCOLS + (lane & 15) + j * 16] = v;
+                    }
             }
         } else {
 #pragma unroll

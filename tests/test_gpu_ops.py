@@ -67,6 +67,53 @@ def test_potrf(eng, n):
         assert out[0, n - 1].item() == 123.0
 
 
+@pytest.mark.parametrize("n", [300, 700, 1207, 2100])
+def test_fused_panel_solve_and_diagonal_update_same_bits(eng, n, monkeypatch):
+    """F_j and D_j as ONE launch (panel_solve_diag_kernel: the diagonal tile's workgroups solve the strips they need
+    themselves, from the copy the step launch left) against the two launches (GPIMHIP_NO_FUSED_FD): the same bits in the
+    factor, and in a lock-step batch that runs as two halves (exact fits, six problems)."""
+    _lib, H = eng
+    g = torch.Generator().manual_seed(n)
+    Bm = torch.randn(n, n, generator=g, dtype=torch.float64)
+    A = Bm @ Bm.T / n + 0.5 * torch.eye(n, dtype=torch.float64)
+    outs = []
+    for knob in (None, "1"):
+        if knob:
+            monkeypatch.setenv("GPIMHIP_NO_FUSED_FD", knob)
+        else:
+            monkeypatch.delenv("GPIMHIP_NO_FUSED_FD", raising=False)
+        Ad = A.cuda().contiguous()
+        info = torch.zeros(1, dtype=torch.int32, device="cuda")
+        _lib.check(H.lib.gpimhip_potrf(H.h, _lib.ptr(Ad), n, n, _lib.ptr(info)))
+        torch.cuda.synchronize()
+        assert info.item() == 0
+        outs.append(torch.tril(Ad.cpu()))
+    assert torch.equal(outs[0], outs[1])
+    if n == 700:
+        from gpim_amd.batch import fit_predict_batch
+        rng = np.random.default_rng(3)
+        ii, jj = np.meshgrid(np.arange(24), np.arange(20), indexing="ij")
+        Rs = []
+        for b in range(6):
+            R = np.sin(ii / 4.0 + b) * np.cos(jj / 3.0) + 0.05 * rng.standard_normal(ii.shape)
+            R.ravel()[rng.permutation(R.size)[:180]] = np.nan          # 300 points each: three block columns
+            Rs.append(R)
+        import gpim_amd
+        Xs = [gpim_amd.utils.get_sparse_grid(R) for R in Rs]
+        Xf = gpim_amd.utils.get_full_grid(Rs[0])
+        res = []
+        for knob in (None, "1"):
+            if knob:
+                monkeypatch.setenv("GPIMHIP_NO_FUSED_FD", knob)
+            else:
+                monkeypatch.delenv("GPIMHIP_NO_FUSED_FD", raising=False)
+            mean, sd, hist = fit_predict_batch(Xs, Rs, Xf, kernel="RBF", lengthscale=[[1., 1.], [10., 10.]], learning_rate=0.1,
+                                               iterations=6)
+            res.append((mean.cpu(), sd.cpu(), hist.cpu()))
+        for x, y in zip(res[0], res[1]):
+            assert torch.equal(x, y)
+
+
 @pytest.mark.parametrize("n,col", [(200, 150), (1, 0), (40, 0), (40, 1), (40, 6), (40, 15), (40, 16), (40, 39),
                                    (300, 127), (300, 128), (300, 131), (300, 299), (700, 513)])
 def test_potrf_not_pd(eng, n, col):
