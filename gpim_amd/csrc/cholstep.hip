@@ -839,7 +839,11 @@ static int launch_step(gpimhip_ctx* h, StepArgs& a, bool potf2, int n, int q, co
 static int launch_solve_diag(gpimhip_ctx* h, double* A, int64_t ld, int j, int nb, int ndiag, int b_off, int cnt,
                              bool fused = false) {
     if (j + 1 >= nb || cnt <= 0) return GPIMHIP_OK;
-    if (fused) {        // the step launch of column j left a copy of A[j+1, j] in h->pcopy (TILE_COPY)
+    // the step launch of column j left a copy of A[j+1, j] in h->pcopy (TILE_COPY).  Not for more than four problems at a time:
+    // the ten workgroups of a diagonal tile solve sixteen strips where F_j solves four -- free on the chain of one problem,
+    // 65 % more panel-solve work at ten block columns, and a lock-step batch of eight is bound by throughput (C3 in four
+    // batches of 16: 0.902 s fused against 0.897; its per-rank share, batches of 4: 0.216 against 0.220)
+    if (fused && cnt <= 4) {
         hipLaunchKernelGGL(panel_solve_diag_kernel, dim3(10 + 2 * (nb - j - 2), cnt), dim3(512), 0, h->stream, A, ld, j, nb,
                            (const double*)h->dinvB, (const double*)h->pcopy, b_off);
         HIP_TRY(hipGetLastError());
