@@ -212,32 +212,38 @@ __global__ __launch_bounds__(256, 2) void diag_update_kernel(double* __restrict_
 }
 
 // F_j and D_j in ONE launch (double precision, the next diagonal tile only).  512 threads: waves 0-3 and waves 4-7 each
-// solve one 32-row strip (the arithmetic of panel_solve_kernel, so the same bits).  Workgroups 0..9: the ten 32x32 blocks
-// (a, b), a >= b, of the next diagonal tile; each solves the strips a and b of block row kblk+1 ITSELF, keeps the results in
-// LDS and applies its block of  A[jj,jj] -= S S^T  (waves 0-3, the arithmetic of diag_update_kernel); block (a, a) also
-// stores strip a of L.  Workgroups 10..: two strips each of the block rows below.  The strips of block row kblk+1 are read
-// from Pcopy -- the copy the step launch made of A[kblk+1, kblk] -- because several workgroups read a strip that one of them
-// overwrites.  One launch boundary and one kernel start-up less per block column.
+// solve one ROWS-row strip (the arithmetic of panel_solve_kernel element by element, so the same bits).  The first NDIAG
+// workgroups: the lower ROWS x ROWS blocks (a, b), a >= b, of the next diagonal block; each solves the strips a and b of
+// block row kblk+1 ITSELF, keeps the results in LDS and applies its block of  A[jj,jj] -= S S^T  (one wave per 16x16 tile, the
+// arithmetic of diag_update_kernel); block (a, a) also stores strip a of L.  The other workgroups: two strips each of the
+// block rows below.  The strips of block row kblk+1 are read from Pcopy -- the copy the step launch made of A[kblk+1, kblk]
+// -- because several workgroups read a strip that one of them overwrites.
+//   ROWS = 16 (36 blocks): every workgroup has the MFMA work of ONE 32-row strip of panel_solve_kernel; the redundant solves run
+//              on CUs that a chain-bound launch leaves idle: 12.1 us + a boundary -> 8 us per block column (N = 4212: 2.41 ->
+//              2.33 ms per Adam iteration);
+//   ROWS = 32 (10 blocks): half the workgroups, for the launches with many block rows below (one round of the chip at
+//              N = 16384), where what counts is that the chip no longer idles through D_j: 72.2 -> 71.85 ms.
+template <int ROWS>
 __global__ __launch_bounds__(512, 2) void panel_solve_diag_kernel(double* __restrict__ A, int64_t ld, int kblk, int nb,
                                                                   const double* __restrict__ dinvB_all,
                                                                   const double* __restrict__ Pcopy, int b_off) {
-    constexpr int LDS_LD = 130, ROWS = 32, MTS = 2;
+    constexpr int LDS_LD = 130, MTS = ROWS / 16, NS = NB / ROWS, NDIAG = NS * (NS + 1) / 2;
     __shared__ __attribute__((aligned(16))) double S[2 * ROWS * LDS_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, half = tid >> 8;
     const int by = blockIdx.y + b_off;
     A += (int64_t)by * nb * NB * ld;
     Pcopy += (int64_t)by * (NB * NB);
     const d2* DB = reinterpret_cast<const d2*>(dinvB_all + ((int64_t)by * nb + kblk) * (NB * NB));
-    const bool diag = blockIdx.x < 10;
+    const bool diag = blockIdx.x < NDIAG;
     int a = 0, b = 0;
     if (diag) {
         const int q = blockIdx.x;
-        a = q < 1 ? 0 : q < 3 ? 1 : q < 6 ? 2 : 3;
+        while ((a + 1) * (a + 2) / 2 <= q) ++a;
         b = q - a * (a + 1) / 2;
     }
     const int jj = kblk + 1;
-    // this half's strip: strip a / b of block row jj (blocks of the diagonal tile), or one of the strips below
-    const int strip = diag ? (half == 0 ? a : b) : 4 + 2 * (int)(blockIdx.x - 10) + half;
+    // this half's strip: strip a / b of block row jj, or one of the strips of the rows below
+    const int strip = diag ? (half == 0 ? a : b) : NS + 2 * (int)(blockIdx.x - NDIAG) + half;
     const bool work = !diag || half == 0 || b != a;           // (block (a, a): the second half has nothing to solve)
     double* P = A + ((int64_t)jj * NB + strip * ROWS) * ld + (int64_t)kblk * NB;
     double* Ss = S + half * ROWS * LDS_LD;
@@ -261,11 +267,12 @@ __global__ __launch_bounds__(512, 2) void panel_solve_diag_kernel(double* __rest
             bf[q] = DB[(t * 16 + s2) * 64 + lane];
         }
     }
-    // the block of the diagonal tile this workgroup updates (waves 0-3: one 16x16 MFMA tile each)
-    const int wm = wave >> 1, wn = wave & 1;
-    double* C = A + ((int64_t)jj * NB + a * 32 + wm * 16 + (lane >> 4)) * ld + (int64_t)jj * NB + b * 32 + wn * 16 + (lane & 15);
+    // the 16x16 tile of the diagonal block this wave updates (the first MTS x MTS waves of the workgroup)
+    const int wt = tid >> 6, wm = wt / MTS, wn = wt % MTS;
+    const bool syrk = diag && wt < MTS * MTS;
+    double* C = A + ((int64_t)jj * NB + a * ROWS + wm * 16 + (lane >> 4)) * ld + (int64_t)jj * NB + b * ROWS + wn * 16 + (lane & 15);
     double cv[4] = {0.0, 0.0, 0.0, 0.0};
-    if (diag && half == 0) {
+    if (syrk) {
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) cv[rg] = C[(int64_t)(4 * rg) * ld];
     }
@@ -322,7 +329,7 @@ __global__ __launch_bounds__(512, 2) void panel_solve_diag_kernel(double* __rest
         }
     }
     __syncthreads();
-    if (half != 0) return;
+    if (!syrk) return;
     d4 acc0 = zero, acc1 = zero;                // two chains, as diag_update_kernel
     const double* Sa = S + (wm * 16 + (lane & 15)) * LDS_LD + (lane >> 4);
     const double* Sb = S + ((b != a ? ROWS : 0) + wn * 16 + (lane & 15)) * LDS_LD + (lane >> 4);
@@ -840,12 +847,18 @@ static int launch_solve_diag(gpimhip_ctx* h, double* A, int64_t ld, int j, int n
                              bool fused = false) {
     if (j + 1 >= nb || cnt <= 0) return GPIMHIP_OK;
     // the step launch of column j left a copy of A[j+1, j] in h->pcopy (TILE_COPY).  Not for more than four problems at a time:
-    // the ten workgroups of a diagonal tile solve sixteen strips where F_j solves four -- free on the chain of one problem,
-    // 65 % more panel-solve work at ten block columns, and a lock-step batch of eight is bound by throughput (C3 in four
-    // batches of 16: 0.902 s fused against 0.897; its per-rank share, batches of 4: 0.216 against 0.220)
+    // the workgroups of a diagonal block solve strips redundantly -- free on the chain of one problem, but a lock-step batch
+    // of eight is bound by throughput (C3 in four batches of 16: 0.902 s fused against 0.897; its per-rank share, batches
+    // of 4: 0.216 against 0.220).  16-row blocks while the launch fits one round of the chip (137 registers: one 512-thread
+    // workgroup per CU), 32-row blocks beyond.
     if (fused && cnt <= 4) {
-        hipLaunchKernelGGL(panel_solve_diag_kernel, dim3(10 + 2 * (nb - j - 2), cnt), dim3(512), 0, h->stream, A, ld, j, nb,
-                           (const double*)h->dinvB, (const double*)h->pcopy, b_off);
+        const int below = nb - j - 2;
+        if ((36 + 4 * below) * cnt <= 256)
+            hipLaunchKernelGGL(panel_solve_diag_kernel<16>, dim3(36 + 4 * below, cnt), dim3(512), 0, h->stream, A, ld, j, nb,
+                               (const double*)h->dinvB, (const double*)h->pcopy, b_off);
+        else
+            hipLaunchKernelGGL(panel_solve_diag_kernel<32>, dim3(10 + 2 * below, cnt), dim3(512), 0, h->stream, A, ld, j, nb,
+                               (const double*)h->dinvB, (const double*)h->pcopy, b_off);
         HIP_TRY(hipGetLastError());
         return GPIMHIP_OK;
     }
