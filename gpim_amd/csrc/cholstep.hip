@@ -848,7 +848,7 @@ static int launch_solve_diag(gpimhip_ctx* h, double* A, int64_t ld, int j, int n
     if (j + 1 >= nb || cnt <= 0) return GPIMHIP_OK;
     // the step launch of column j left a copy of A[j+1, j] in h->pcopy (TILE_COPY).  Not for more than four problems at a time:
     // the workgroups of a diagonal block solve strips redundantly -- free on the chain of one problem, but a lock-step batch
-    // of eight is bound by throughput (C3 in four batches of 16: 0.902 s fused against 0.897; its per-rank share, batches
+    // of eight is bound by throughput (C3 in four batches of 16: 0.967 s with the 16-row blocks, 0.902 with the 32-row ones, against 0.897; its per-rank share, batches
     // of 4: 0.216 against 0.220).  16-row blocks while the launch fits one round of the chip (137 registers: one 512-thread
     // workgroup per CU), 32-row blocks beyond.
     if (fused && cnt <= 4) {
