@@ -27,6 +27,14 @@ def fit_predict_batch(Xs_list, ys_list, Xtest, kernel='RBF', lengthscale=None, l
     observations.  Returns (mean, sd, hist): arrays (B, *Xtest.shape[1:]) and the hyper-parameter
     history (B, iterations, P) in the order [variance, lengthscale.., noise(, alpha)]."""
     H = handle or _lib.Handle(precision=kwargs.get("precision", "double"))
+    try:
+        return _fit_predict_batch(H, Xs_list, ys_list, Xtest, kernel, lengthscale, learning_rate, iterations, seed, **kwargs)
+    finally:
+        if handle is None:
+            H.close()
+
+
+def _fit_predict_batch(H, Xs_list, ys_list, Xtest, kernel, lengthscale, learning_rate, iterations, seed, **kwargs):
     dev = H.device
     B = len(ys_list)
     y0 = np.asarray(ys_list[0])
@@ -80,6 +88,16 @@ def fit_predict_batch_sparse(Xs_list, ys_list, Xtest, indpoints=None, kernel='RB
     Returns (mean, sd, hist, hist_xu): (B, *Xtest.shape[1:]) twice, the hyper-parameter history (B, T, P) and the
     inducing inputs after every iteration (B, T, Mu, d)."""
     H = handle or _lib.Handle()
+    try:
+        return _fit_predict_batch_sparse(H, Xs_list, ys_list, Xtest, indpoints, kernel, lengthscale, learning_rate, iterations,
+                                         seed, **kwargs)
+    finally:
+        if handle is None:
+            H.close()        # the workspaces of B models go now, not when the collector gets to the object
+
+
+def _fit_predict_batch_sparse(H, Xs_list, ys_list, Xtest, indpoints, kernel, lengthscale, learning_rate, iterations, seed,
+                              **kwargs):
     dev = H.device
     B = len(ys_list)
     y0 = np.asarray(ys_list[0])

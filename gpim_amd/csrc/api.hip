@@ -1420,10 +1420,13 @@ int gpimhip_dist_finalize_dev(gpimhip_handle h, const gpimhip_model_t* m, int64_
                               const double* quad, double lr, int32_t t, double* loss_out, double* grad_out,
                               double* hist_row) {
     FP64_ONLY(h);
-    if (!h || !u || !red || !quad || N < 1 || t < 0 || !h->np) return GPIMHIP_E_BADARG;
+    if (!h || !u || !red || !quad || N < 1 || t < 0) return GPIMHIP_E_BADARG;
     GP_TRY(check_model(m));
     HIP_TRY(hipSetDevice(h->device));
     h->nbatch = 1;
+    // a rank that holds no block of the model (world size > number of reflection blocks) never built a workspace:
+    // the parameters and the Adam state are all this call needs
+    if (!h->np) GP_TRY(ws_ensure_b(h, 1, 1, 0, false));
     GP_TRY(launch_theta(h, m, u));
     AdamStep st;
     st.beta1 = 0.9; st.beta2 = 0.999; st.eps = 1e-8;

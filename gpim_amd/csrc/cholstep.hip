@@ -719,12 +719,18 @@ static int step_plan_build(gpimhip_ctx* h, int nb, StepPlan& P, bool with_invers
     for (int j = 0; j < nb; ++j)
         for (auto& t : fill[j]) P.n_update[j] += t.kb1 - t.kb0;
     P.pair.assign(nb, 0);
-    if (with_inverse && !plan_inverse(nb, fill, post, P.pair)) {
-        gpim_set_error("step plan: the inverse's tile operations did not all find a launch (nb = " + std::to_string(nb) + ")");
-        return GPIMHIP_E_BADARG;
-    }
-    else
+    if (with_inverse) {
+        // plan_inverse decides pair[] from the update tiles alone (before it adds its own) and budgets its chunks for
+        // the launch as it will then run: keep ITS decision
+        if (!plan_inverse(nb, fill, post, P.pair)) {
+            gpim_set_error("step plan: the inverse's tile operations did not all find a launch (nb = " + std::to_string(nb) + ")");
+            return GPIMHIP_E_BADARG;
+        }
+        if (getenv("GPIMHIP_AB_PAIR_OLD"))   // TEMPORARY A/B knob (round 6): the rule as it ran in round 5
+            for (int j = 0; j < nb; ++j) P.pair[j] = host_shape(P.n_update[j]) == 4 && pair_rule(fill[j].size(), P.n_update[j]);
+    } else {
         for (int j = 0; j < nb; ++j) P.pair[j] = host_shape(P.n_update[j]) == 4 && pair_rule(fill[j].size(), P.n_update[j]);
+    }
     P.n_all.assign(nb, 0);
     for (int j = 0; j < nb; ++j)
         for (auto& t : fill[j]) P.n_all[j] += (t.kb1 & 0xffff) - t.kb0;

@@ -5,7 +5,14 @@
 // as the reference so that round-off behaves alike:
 //   a = x / l, b = z / l;  r2 = max((|a|^2 - 2 a.b) + |b|^2, 0)   (NaN propagates like torch.clamp)
 //   RBF       k = s2 * exp(-r2/2)
-//   Matern52  r = sqrt(r2 + 1e-12);  k = s2 * (1 + sqrt5*r + (5/3) r^2) * exp(-sqrt5*r)
+//   Matern52  r = sqrt(r2 + 1e-12);  k = s2 * (1 + sqrt5*r + (5/3) r2) * exp(-sqrt5*r)
+//             The reading followed (pyro-ppl 1.x, pyro/contrib/gp/kernels/isotropic.py, unchanged since 0.3; the package is
+//             not in this image and the reference declares it unpinned, setup.py:30): Matern52.forward computes
+//               r2 = self._square_scaled_dist(X, Z);  r = _torch_sqrt(r2)   # (r2 + 1e-12).sqrt()
+//               sqrt5_r = 5**0.5 * r;  return variance * (1 + sqrt5_r + (5/3) * r2) * exp(-sqrt5_r)
+//             i.e. the shift enters through r only and the (5/3) term takes the UN-shifted squared distance (rounds 1-5
+//             used r*r there: <= 1.7e-12 s2 per entry, below every bar; oracle, mpmath fixtures and this file changed
+//             together in round 6).  dk/dr2 = -(5/6) (1 + sqrt5 r2 / r) exp(-sqrt5 r).
 //   RQ        k = s2 * (1 + r2/(2*alpha))^(-alpha)
 #pragma once
 #include "common.hpp"
@@ -24,7 +31,7 @@ __device__ __forceinline__ double kfun_value(double r2, double alpha) {
     if (KIND == GPIMHIP_KERNEL_MATERN52) {
         const double r = sqrt(r2 + 1e-12);
         const double s5r = SQRT5 * r;
-        return (1.0 + s5r + (5.0 / 3.0) * (r * r)) * exp(-s5r);
+        return (1.0 + s5r + (5.0 / 3.0) * r2) * exp(-s5r);
     }
     return pow(1.0 + (0.5 / alpha) * r2, -alpha);
 }
@@ -40,8 +47,8 @@ __device__ __forceinline__ KVal kfun_grad(double r2, double alpha) {
         const double r = sqrt(r2 + 1e-12);
         const double s5r = SQRT5 * r;
         const double ex = exp(-s5r);
-        v.e = (1.0 + s5r + (5.0 / 3.0) * (r * r)) * ex;
-        v.h = (5.0 / 3.0) * (1.0 + s5r) * ex;
+        v.e = (1.0 + s5r + (5.0 / 3.0) * r2) * ex;
+        v.h = (5.0 / 3.0) * (1.0 + SQRT5 * (r2 / r)) * ex;
     } else {
         const double t = (0.5 / alpha) * r2;
         const double base = 1.0 + t;

@@ -17,6 +17,8 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+from . import _lib
+
 
 def init_from_env(backend=None):
     """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun contract).
@@ -209,12 +211,17 @@ def reconstruct_slices(cube, axis=-1, batch=16, return_hyperparams=False, handle
 
             def one_sparse_group(grp, own_stream):
                 args = ([grid_of(cube[i]) for i in grp], [cube[i] for i in grp], Xf)
-                if own_stream:
-                    with torch.cuda.device(dev), torch.cuda.stream(torch.cuda.Stream(device=dev)):
-                        out = fit_predict_batch_sparse(*args, **kw_b)
-                        torch.cuda.current_stream().synchronize()
-                else:
-                    out = fit_predict_batch_sparse(*args, handle=handle, **kw_b)
+                try:
+                    if own_stream:
+                        with torch.cuda.device(dev), torch.cuda.stream(torch.cuda.Stream(device=dev)):
+                            out = fit_predict_batch_sparse(*args, **kw_b)      # (its own handle, closed on return)
+                            torch.cuda.current_stream().synchronize()
+                    else:
+                        out = fit_predict_batch_sparse(*args, handle=handle, **kw_b)
+                except _lib.NotPositiveDefiniteError:
+                    # one slice's factorisation failed and froze the whole lock-step batch: the slices of this group go
+                    # through one reconstructor each, so that only the failing slice raises (as in the reference's loop)
+                    return (grp, None)
                 return (grp,) + tuple(out)
 
             # several batches at a time (own host thread / stream / handle each): the two factorisation chains per
@@ -225,7 +232,11 @@ def reconstruct_slices(cube, axis=-1, batch=16, return_hyperparams=False, handle
                     sdone = list(pool.map(lambda g: one_sparse_group(g, True), sgroups))
             else:
                 sdone = [one_sparse_group(g, False) for g in sgroups]
-            for grp, mean, sd, hist, hist_xu in sdone:
+            for res in sdone:
+                if res[1] is None:
+                    rest.extend(res[0])
+                    continue
+                grp, mean, sd, hist, hist_xu = res
                 hist_h, xu_h = hist.cpu().numpy(), hist_xu.cpu().numpy()
                 n_ls = hist_h.shape[2] - 2 - (1 if str(kw_b.get("kernel", "RBF")) == "RationalQuadratic" else 0)
                 iso = bool(kw_b.get("isotropic"))

@@ -214,6 +214,14 @@ class DistributedCholesky:
         self._panel = [self.engine.empty(self.layout.np + NB, PW) for _ in range(2)]
         self._X = self._Wt = None                      # workspaces of ``inverse``
         self._wide = None                              # two panels side by side (``_stream_pairs``), two such buffers
+        self._factored = False                         # ``local`` holds a factor (set by factor(), cleared by kinv(out=local))
+
+    def _need_factor(self, what):
+        """``kinv(X, out=self.local)`` writes K^-1's lower tiles over the factor (tiles above the diagonal keep what
+        they held): every consumer of the factor refuses to run on that."""
+        if not self._factored:
+            raise RuntimeError("DistributedCholesky.%s: `local` does not hold a factor (call factor() first; "
+                               "kinv(..., out=self.local) overwrites it)" % what)
 
     def _matrix(self, rows, cols):
         """A rows x cols workspace matrix whose leading dimension is NOT a large power of two: with 512 * owned-panels
@@ -285,6 +293,7 @@ class DistributedCholesky:
                 work = self._factor_and_send(nxt)
             if rest < L.npanel:
                 eng.update(buf, p, self.local, rest, L.npanel)
+        self._factored = True
         if not check:
             return self
         bad = torch.tensor([eng.failed_column()], dtype=torch.int64)
@@ -299,6 +308,7 @@ class DistributedCholesky:
     # ------------------------------------------------------------------ what the factor is for
     def logdet(self):
         """log det of the matrix = 2 sum log L_ii (every rank returns the same number)."""
+        self._need_factor("logdet")
         s = self.engine.half_logdet_owned().clone()
         if self.layout.world > 1:
             dist.all_reduce(s, group=self.group)
@@ -308,6 +318,7 @@ class DistributedCholesky:
         """alpha = (L L^T)^-1 y, replicated on every rank.  Two panel-by-panel triangular solves, O(N^2) work: the owner
         of a panel solves with its diagonal triangle and multiplies the rows below (engine.vec_forward / vec_backward);
         per panel one all-reduce of the 512 partial sums (forward only) and one broadcast of the 512 solved entries."""
+        self._need_factor("solve")
         L, eng = self.layout, self.engine
         dev = self.local.device
         rhs_full = torch.zeros((L.npanel * PW,), dtype=torch.float64, device=dev)
@@ -396,6 +407,7 @@ class DistributedCholesky:
 
     def _stream_factor(self):
         """The factored panels once more (packed with the inverses of their diagonal blocks)."""
+        self._need_factor("_stream_factor")
         return self._stream(lambda p: (lambda buf: self.engine.pack(self.local, p, buf)))
 
     def _stream_pairs(self, fill_of):
@@ -412,6 +424,7 @@ class DistributedCholesky:
             yield p, wide, second
 
     def _stream_factor_pairs(self):
+        self._need_factor("_stream_factor_pairs")
         return self._stream_pairs(lambda p: (lambda buf: self.engine.pack(self.local, p, buf)))
 
     def inverse(self):
@@ -450,9 +463,14 @@ class DistributedCholesky:
         """K^-1 = X^T X (lower tiles) for the owned block columns, np x 512 * owned panels: every owner broadcasts
         its block columns of X in turn (the next one in flight while the current one is consumed) and each rank forms
         the rows of that panel against its own columns on the MFMA tile engine (gpimhip_dist_kinv_update).
-        out: where to (default: a new matrix); the training loop passes ``self.local`` -- the factor is dead by then."""
+        out: where to (default: a new matrix); the training loop passes ``self.local`` -- the factor is dead by then.
+        Only the LOWER tiles of the result are written: with ``out=self.local`` the tiles above the diagonal keep
+        factor / K values, and this object no longer holds a factor (solve / logdet / inverse / gather_lower raise until
+        the next factor()).  Xl (the workspace ``inverse`` returned) is valid until the next ``inverse`` call."""
         L, eng = self.layout, self.engine
         Kl = out if out is not None else self._matrix(L.np, L.local_cols)
+        if out is not None and out.data_ptr() == self.local.data_ptr():
+            self._factored = False
 
         def fill_of(c):
             def fill(buf):
@@ -471,6 +489,7 @@ class DistributedCholesky:
 
     def gather_lower(self):
         """The whole factor on every rank (tests and small problems only)."""
+        self._need_factor("gather_lower")
         L = self.layout
         full = torch.zeros((L.np, L.np), dtype=torch.float64, device=self.local.device)
         for p in range(L.npanel):

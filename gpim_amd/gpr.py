@@ -76,6 +76,7 @@ class _ModelView:
 
     @X.setter
     def X(self, value):
+        self._o._no_swap("X")
         self._o._Xd = self._o._to_device(value)
 
     @property
@@ -84,6 +85,7 @@ class _ModelView:
 
     @y.setter
     def y(self, value):
+        self._o._no_swap("y")
         self._o._yd = self._o._to_device(value)
 
     @property
@@ -268,6 +270,14 @@ class reconstructor:
         self._u.copy_(u_b[:self._u.numel()])
         return rc
 
+    def _no_swap(self, what):
+        """structured=True models are built from the complete grid once (coordinate vectors of the Kronecker solver, the
+        reflection blocks and projected observations of the symmetry-reduced one): swapping the training data through
+        ``model.X`` / ``model.y`` would leave them stale and train / predict on the old observations silently."""
+        if self.do_symm or self.do_structured:
+            raise NotImplementedError("structured=True: the training data cannot be replaced through model.%s "
+                                      "(build a new reconstructor for new observations)" % what)
+
     def _to_device(self, t):
         if isinstance(t, np.ndarray):
             t = torch.from_numpy(t)
@@ -439,7 +449,12 @@ class reconstructor:
         var = torch.empty((M,), dtype=_F64, device=self._dev)
         if self.do_structured:
             raise NotImplementedError("structured models predict on product grids (use predict())")
-        if not self.do_sparse:
+        if self.do_symm:
+            # the reflection blocks, not the dense O(N^3) model of the same data
+            rc = self._symm_call(lambda Xq, ys, Nq, B, u_b: self._handle.lib.gpimhip_predict_exact_batched(
+                self._handle.h, ctypes.byref(self._mstruct), _lib.ptr(Xq), 0, _lib.ptr(ys), Nq, B, _lib.ptr(u_b),
+                _lib.ptr(Xrows_d), M, _lib.ptr(mean), _lib.ptr(var)))
+        elif not self.do_sparse:
             rc = self._handle.lib.gpimhip_predict_exact(
                 self._handle.h, ctypes.byref(self._mstruct), _lib.ptr(self._Xd), _lib.ptr(self._yd),
                 self._Xd.shape[0], _lib.ptr(self._u), _lib.ptr(Xrows_d), M, _lib.ptr(mean), _lib.ptr(var))

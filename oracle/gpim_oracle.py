@@ -41,6 +41,18 @@ custom acquisition (fp64, CPU generator).  Matern52 / RationalQuadratic exact GP
 are pinned to an independent high-precision evaluation of the published formulas (above), not to a Pyro run.
 Isotropic lengthscale and batch_update are parity-UNPINNED by anything but this file's reading of Pyro's
 documented behaviour (the reference tests them for shape/NaN only, test/test_gpreg.py:24-36).
+
+The Pyro reading followed for Matern52 (pyro-ppl 1.x -- 1.8.x at the time of writing; the formula is unchanged since
+0.3 -- ``pyro/contrib/gp/kernels/isotropic.py``; the package is absent from this image, so this is restated from the
+published source, not executed):
+    def _torch_sqrt(x, eps=1e-12): return (x + eps).sqrt()
+    Matern52.forward:  r2 = self._square_scaled_dist(X, Z)          # clamp(min=0) of the GEMM-expansion form
+                       r = _torch_sqrt(r2);  sqrt5_r = 5**0.5 * r
+                       return self.variance * (1 + sqrt5_r + (5/3) * r2) * torch.exp(-sqrt5_r)
+i.e. the 1e-12 shift enters through r only; the (5/3) term takes the UN-shifted squared distance.  Rounds 1-5 of this
+restatement (and with it the HIP kernel and the mpmath fixture generator) used (5/3) * r**2 = (5/3) (r2 + 1e-12) there:
+a difference of <= 1.7e-12 * variance per entry, below every parity bar; all three were changed together in round 6
+(gpim_amd/csrc/kfun.hpp, tests/tools/make_highprec_fixtures.py) and the bars did not move.
 """
 
 import math
@@ -205,9 +217,12 @@ class KernelParams:
         if self.kind == "RBF":
             return self.variance * torch.exp(-0.5 * r2)
         if self.kind == "Matern52":
+            # pyro/contrib/gp/kernels/isotropic.py (pyro-ppl 1.x): r2 = _square_scaled_dist; r = _torch_sqrt(r2) =
+            # (r2 + 1e-12).sqrt(); variance * (1 + sqrt5_r + (5/3) * r2) * exp(-sqrt5_r) -- the shift enters through r
+            # only, the (5/3) term takes the un-shifted r2 (see the header)
             r = (r2 + 1e-12).sqrt()
             s5r = 5 ** 0.5 * r
-            return self.variance * (1 + s5r + (5.0 / 3) * r ** 2) * torch.exp(-s5r)
+            return self.variance * (1 + s5r + (5.0 / 3) * r2) * torch.exp(-s5r)
         a = self.scale_mixture
         return self.variance * (1 + (0.5 / a) * r2).pow(-a)
 

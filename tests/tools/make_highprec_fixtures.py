@@ -16,7 +16,8 @@ form, no autograd) and central finite differences at step 1e-20 for every gradie
              pyro.contrib.gp.models.SparseGPRegression(approx="VFE"))
              posterior  S = (Kuu' + Kuf Kfu / noise)^-1,  mean = K*u S Kuf y / noise,
                         var = k** - K*u Kuu'^-1 Ku* + K*u S Ku* + noise              (Titsias 2009, eq. 6)
-  kernels    RBF s2 exp(-r2/2);  Matern52 s2 (1 + sqrt5 r + 5/3 r^2) exp(-sqrt5 r), r = sqrt(r2 + 1e-12) as Pyro;
+  kernels    RBF s2 exp(-r2/2);  Matern52 s2 (1 + sqrt5 r + 5/3 r2) exp(-sqrt5 r), r = sqrt(r2 + 1e-12) as Pyro
+             (pyro-ppl 1.x isotropic.py: the shift enters through r only, the 5/3 term takes the un-shifted r2);
              RationalQuadratic s2 (1 + r2 / (2 alpha))^-alpha;   r2 = sum_k ((x_k - z_k) / l_k)^2
   parameters variance = lo + (hi - lo) sigmoid(u_0), lengthscale_k likewise, noise = exp(u), alpha = exp(u)
              (torch.distributions transform_to(interval / positive))
@@ -54,7 +55,7 @@ def kfun(kind, var, ls, alpha, x, z):
     if kind == "Matern52":
         r = mp.sqrt(r2 + mp.mpf("1e-12"))
         s5r = mp.sqrt(5) * r
-        return var * (1 + s5r + mp.mpf(5) / 3 * r * r) * mp.e ** (-s5r)
+        return var * (1 + s5r + mp.mpf(5) / 3 * r2) * mp.e ** (-s5r)
     return var * (1 + r2 / (2 * alpha)) ** (-alpha)
 
 
