@@ -246,6 +246,64 @@ def rmse_vs_oracle_c3(cube, iterations=5, slices=(0, 31, 63)):
 
 
 # ------------------------------------------------------------------------------------------------
+# per-stage rooflines from the library's HIP-event stage timers
+# ------------------------------------------------------------------------------------------------
+STAGE_NAMES = ["potrf", "trtri", "lauum", "predict_var"]
+
+
+def timers_clear(lib, h):
+    tot, cnt = ctypes.c_double(), ctypes.c_int64()
+    for s in range(4):
+        lib.gpimhip_timing_read(h, s, ctypes.byref(tot), ctypes.byref(cnt))
+
+
+def timers_read(lib, h):
+    tot, cnt = ctypes.c_double(), ctypes.c_int64()
+    out = {}
+    for s, name in enumerate(STAGE_NAMES):
+        lib.gpimhip_timing_read(h, s, ctypes.byref(tot), ctypes.byref(cnt))
+        out[name] = (tot.value, cnt.value)
+    return out
+
+
+def stage_breakdown(stage_ms, n_obs, nprob_, M, ms_step, stage_steps):
+    """roofline.stages from the HIP-event stage timers: per blocked-algorithm stage the calls, ms per call,
+    flop per call (all `nprob_` problems of a lock-step batch), TFLOP/s, fraction of the fp64 MFMA peak and
+    share of the time of the step(s) the timers covered."""
+    n3 = float(n_obs) ** 3 * nprob_
+    # The triangular inverse rides in the launches of the factorisation (cholstep.hip: plan_inverse); the two
+    # timers are "the step launches" (timer 0) and "what is left of the inverse afterwards" (timer 1), so the
+    # stage that can be priced is their sum: 2 N^3 / 3 flop.
+    pm, pn = stage_ms["potrf"]
+    tm, tn = stage_ms["trtri"]
+    per_call = {"factor_inverse": 2 * n3 / 3, "lauum": n3 / 3}
+    label = {"factor_inverse": "potrf + trtri (L^-1 in one pass: inverse tiles hosted by the factorisation's launches)",
+             "lauum": "lauum (K^-1 = L^-T L^-1)", "predict_var": "predict_var (L^-1 K*)"}
+    stage_ms_ = dict(stage_ms, factor_inverse=(pm + tm, pn))
+    stages = []
+    for name in ("factor_inverse", "lauum", "predict_var"):
+        ms, n = stage_ms_[name]
+        if not n:
+            continue
+        # predict_var: one launch per slab of test points, N^2*M flop per problem over all slabs of a step
+        fl = per_call.get(name, float(n_obs) ** 2 * M * nprob_ * stage_steps / n)
+        tf = fl / (ms / n * 1e-3) / 1e12
+        stages.append({"stage": label[name], "calls": n, "ms_per_call": ms / n, "flop_per_call": fl,
+                       "tflops": tf, "frac": tf / FP64_MFMA_PEAK_TFLOPS,
+                       "share_of_step": ms / (ms_step * stage_steps)})
+        if name == "factor_inverse":
+            stages[-1]["ms_step_launches"] = pm / pn
+            stages[-1]["ms_after_last_step"] = tm / pn
+    return stages
+
+
+def chain_us(stage_ms, n_obs):
+    """time of the factorisation's step launches per 128-column block step"""
+    pm, pn = stage_ms["potrf"]
+    return (pm / pn * 1e3 / math.ceil(n_obs / 128.0)) if pn else None
+
+
+# ------------------------------------------------------------------------------------------------
 # the other single-GPU configs (driver-verified throughputs for DESIGN.md section 4)
 # ------------------------------------------------------------------------------------------------
 def _settle_interpreter():
@@ -256,6 +314,36 @@ def _settle_interpreter():
     import gc
     gc.collect()
     gc.freeze()
+
+
+def c4_against_oracle(bo):
+    """The timed C4 instance itself (README.md:71-106 of the reference: 25x25, np.random.seed(42), 4 seed points, EI,
+    30 exploration steps x 1000 Adam iterations) against the oracle's boptimizer on the host: the sequence of queried
+    indices must be EQUAL, the hyper-parameters after every training agree to `hyper_max_rel`."""
+    from oracle import gpim_oracle as O
+    from problems import notebook_problem
+    torch.set_num_threads(min(os.cpu_count() or 1, 8))
+    trial_func, Z = notebook_problem(4)
+    tmp = tempfile.mkdtemp()
+    t0 = time.perf_counter()
+    ob = O.boptimizer(O.get_sparse_grid(Z), Z, O.get_full_grid(Z), trial_func, acquisition_function="ei",
+                      exploration_steps=30, verbose=0, filename=os.path.join(tmp, "bo_oracle"))
+    ob.run()
+    t_orc = time.perf_counter() - t0
+    ih, io = [tuple(int(v) for v in i) for i in bo.indices_all], [tuple(int(v) for v in i) for i in ob.indices_all]
+    hh, ho = bo.surrogate_model.hyperparams, ob.surrogate_model.hyperparams
+    rel = 0.0
+    for key in ("variance", "lengthscale", "noise"):
+        a, b = np.asarray(hh[key], dtype=float), np.asarray(ho[key], dtype=float)
+        if a.shape != b.shape:
+            rel = float("inf")
+            break
+        rel = max(rel, float(np.max(np.abs(a - b) / np.abs(b))))
+    return {"indices_equal_oracle": ih == io, "n_queries": len(ih), "hyper_max_rel": rel,
+            "hyper_rows_compared": int(np.asarray(hh["noise"]).shape[0]),
+            "oracle_seconds": t_orc,
+            "oracle": "oracle boptimizer (torch CPU fp64) on the same instance, same seed; every one of the 31 x 1000 "
+                      "hyper-parameter rows compared"}
 
 
 def extra_configs(gpim):
@@ -269,22 +357,64 @@ def extra_configs(gpim):
     X, Xf = gpim.utils.get_sparse_grid(R), gpim.utils.get_full_grid(R)
     gpim.reconstructor(X, R, Xf, **dict(C1, iterations=3, verbose=0)).run()          # workspace / plan warm-up
     sync(); t0 = time.perf_counter()
-    gpim.reconstructor(X, R, Xf, verbose=0, **C1).run()
+    rec1 = gpim.reconstructor(X, R, Xf, verbose=0, **C1)
+    rec1.run()
     sync(); dt = time.perf_counter() - t0
     n1 = int(np.isfinite(R).sum())
+    flop1 = 300 * float(n1) ** 3 + 2 * float(n1) ** 3 / 3 + float(n1) ** 2 * R.size
     out["C1"] = {"workload": "128x128 PFM spiral scan (expdata/spiral_s_00010_2019.npy), N=%d, M=%d, RBF, T=300, "
                              "reconstructor.run()" % (n1, R.size),
                  "seconds": dt, "grid_points_per_s": R.size / dt, "ms_per_adam_iteration": dt / 300 * 1e3,
-                 "mfma_frac": (300 * n1 ** 3 + 2 * n1 ** 3 / 3 + n1 ** 2 * R.size) / dt / 1e12 / FP64_MFMA_PEAK_TFLOPS}
+                 "mfma_frac": flop1 / dt / 1e12 / FP64_MFMA_PEAK_TFLOPS}
+    # per-stage rooflines of C1: one more (untimed) fit + predict on the same object with the stage timers on
+    lib1, h1 = rec1._handle.lib, rec1._handle.h
+    lib1.gpimhip_timing_enable(h1, 1)
+    timers_clear(lib1, h1)
+    sync(); t0 = time.perf_counter()
+    rec1.train()
+    rec1.predict()
+    sync(); dts = time.perf_counter() - t0
+    lib1.gpimhip_timing_enable(h1, 0)
+    sm1 = timers_read(lib1, h1)
+    out["C1"]["roofline"] = {"bound": "mfma", "achieved": flop1 / dt / 1e12, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": out["C1"]["mfma_frac"],
+                             "stages": stage_breakdown(sm1, n1, 1, R.size, dts * 1e3, 1),
+                             "stages_from": "one extra fit + predict after the timed one, stage timers on (%.1f ms: launch by "
+                                            "launch, the timed run replays a captured iteration)" % (dts * 1e3),
+                             "chain_us_per_128": chain_us(sm1, n1)}
+    del rec1
     # C3: 64 slices of 64x64, RBF, T = 250: four lock-step batches of 16 at a time on one GPU
     cube, _ = hyperspectral_cube()
     gdist.reconstruct_slices(cube, axis=-1, batch=16, batch_concurrency=4, **dict(C3, iterations=3))
     sync(); t0 = time.perf_counter()
     gdist.reconstruct_slices(cube, axis=-1, batch=16, batch_concurrency=4, **C3)
     sync(); dt = time.perf_counter() - t0
+    n3_ = int(np.isfinite(cube[..., 0]).sum())
+    flop3 = 64 * (250 * float(n3_) ** 3 + 2 * float(n3_) ** 3 / 3 + float(n3_) ** 2 * 4096)
     out["C3"] = {"workload": "64x64x64 cube twin, 64 per-slice GPs (N=%d, M=4096), RBF, T=250, "
-                             "dist.reconstruct_slices(batch=16, batch_concurrency=4) on one GPU" % int(np.isfinite(cube[..., 0]).sum()),
-                 "seconds": dt, "grid_points_per_s": cube.size / dt}
+                             "dist.reconstruct_slices(batch=16, batch_concurrency=4) on one GPU" % n3_,
+                 "seconds": dt, "grid_points_per_s": cube.size / dt, "mfma_frac": flop3 / dt / 1e12 / FP64_MFMA_PEAK_TFLOPS}
+    # per-stage rooflines of C3: one more (untimed) step with all 64 slices as ONE lock-step batch on one handle and the
+    # stage timers on (the timers need one handle and stream; share_of_step is relative to that serial step)
+    from gpim_amd import _lib as _l
+    H3 = _l.Handle()
+    gdist.reconstruct_slices(cube, axis=-1, batch=64, handle=H3, **dict(C3, iterations=2))
+    H3.lib.gpimhip_timing_enable(H3.h, 1)
+    timers_clear(H3.lib, H3.h)
+    sync(); t0 = time.perf_counter()
+    gdist.reconstruct_slices(cube, axis=-1, batch=64, handle=H3, **C3)
+    sync(); dts = time.perf_counter() - t0
+    H3.lib.gpimhip_timing_enable(H3.h, 0)
+    sm3 = timers_read(H3.lib, H3.h)
+    out["C3"]["roofline"] = {"bound": "mfma", "achieved": flop3 / dt / 1e12, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": out["C3"]["mfma_frac"],
+                             "stages": stage_breakdown(sm3, n3_, 64, 4096, dts * 1e3, 1),
+                             "stages_from": "one extra step with the 64 slices as ONE lock-step batch per launch, stage timers "
+                                            "on (%.1f ms; the timed step runs 4 concurrent batches of 16 and replays captured "
+                                            "iterations)" % (dts * 1e3),
+                             "chain_us_per_128": chain_us(sm3, n3_)}
+    H3.close()
+    del H3
     # the per-rank share of C3 on an 8-GPU node: 8 of the 64 slices (round-robin shard of rank 0) on ONE GPU, the
     # batch split dist.reconstruct_slices picks by itself
     sub = cube[..., 0::8]
@@ -311,6 +441,7 @@ def extra_configs(gpim):
     out["C4"] = {"workload": "BO 25x25, EI, 30 steps x (1000 Adam its + acquisition sweep), boptimizer.run()",
                  "seconds": dt, "grid_points_per_s": 625 * 30 / dt, "steps_per_s": 30 / dt,
                  "us_per_adam_iteration": dt / (31 * 1000) * 1e6}
+    out["C4"].update(c4_against_oracle(bo))
     # C5: 4D cKPFM twin 10x10x64x5, one GP per Ns slice (N = 6400 points in 3-D, fully observed), T = 200:
     # (i) the reference's model for it -- sparse VFE with indpoints=512 (534 inducing inputs);
     # (ii) the same slices as EXACT GPs through the Kronecker solver (possible because the slices are complete grids)
@@ -541,33 +672,28 @@ def main():
     for _ in range(args.warmup):
         step()
     _settle_interpreter()          # (a full pass of the cyclic collector inside the timed region is harness time, see there)
-    tot, cnt = ctypes.c_double(), ctypes.c_int64()
-    # c2 (large N) is enqueued launch by launch, never graph-captured: its stage timers sit inside the timed region.  c1 / c3 replay one captured iteration per Adam step, which the timers would switch off: their
-    # stage breakdown comes from ONE extra step after the timed ones.
-    timers_inside = args.workload == "c2"
-    if lib is not None and timers_inside:
-        lib.gpimhip_timing_enable(h, 1)
-        for s in range(4):
-            lib.gpimhip_timing_read(h, s, ctypes.byref(tot), ctypes.byref(cnt))     # clear
+    # The timed steps run with the stage timers OFF for every workload: c1 / c3 replay one captured iteration per Adam
+    # step (which the timers would switch off), and the headline (c2, enqueued launch by launch) must not carry
+    # instrumentation the other lines do not.  The per-stage breakdown comes from ONE extra step after the timed ones,
+    # with the timers on (HIP events on the handle's stream around every stage).
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = step()
     fence()
     elapsed = time.perf_counter() - t0
-    stage_steps = args.steps
+    stage_steps = 1
+    ms_stage_step = None
     if lib is not None:
-        if not timers_inside:
-            lib.gpimhip_timing_enable(h, 1)
-            for s in range(4):
-                lib.gpimhip_timing_read(h, s, ctypes.byref(tot), ctypes.byref(cnt))
-            step(True) if args.workload == "c3" else step()
-            fence()
-            stage_steps = 1
+        lib.gpimhip_timing_enable(h, 1)
+        timers_clear(lib, h)
+        fence()
+        t1 = time.perf_counter()
+        step(True) if args.workload == "c3" else step()
+        fence()
+        ms_stage_step = (time.perf_counter() - t1) * 1e3
         lib.gpimhip_timing_enable(h, 0)
-        for s, name in enumerate(["potrf", "trtri", "lauum", "predict_var"]):
-            lib.gpimhip_timing_read(h, s, ctypes.byref(tot), ctypes.byref(cnt))
-            stage_ms[name] = (tot.value, cnt.value)
+        stage_ms = timers_read(lib, h)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -584,36 +710,6 @@ def main():
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
         }
-        def stage_breakdown(n_obs, nprob_):
-            """roofline.stages from the HIP-event stage timers: per blocked-algorithm stage the calls, ms per call,
-            flop per call (all `nprob_` problems of a lock-step batch), TFLOP/s, fraction of the fp64 MFMA peak and
-            share of the time of the step(s) the timers covered."""
-            n3 = float(n_obs) ** 3 * nprob_
-            # The triangular inverse rides in the launches of the factorisation (cholstep.hip: plan_inverse); the two
-            # timers are "the step launches" (timer 0) and "what is left of the inverse afterwards" (timer 1), so the
-            # stage that can be priced is their sum: 2 N^3 / 3 flop.
-            pm, pn = stage_ms["potrf"]
-            tm, tn = stage_ms["trtri"]
-            per_call = {"factor_inverse": 2 * n3 / 3, "lauum": n3 / 3}
-            label = {"factor_inverse": "potrf + trtri (L^-1 in one pass: inverse tiles hosted by the factorisation's launches)",
-                     "lauum": "lauum (K^-1 = L^-T L^-1)", "predict_var": "predict_var (L^-1 K*)"}
-            stage_ms_ = dict(stage_ms, factor_inverse=(pm + tm, pn))
-            stages = []
-            for name in ("factor_inverse", "lauum", "predict_var"):
-                ms, n = stage_ms_[name]
-                if not n:
-                    continue
-                # predict_var: one launch per slab of test points, N^2*M flop per problem over all slabs of a step
-                fl = per_call.get(name, float(n_obs) ** 2 * M * nprob_ * stage_steps / n)
-                tf = fl / (ms / n * 1e-3) / 1e12
-                stages.append({"stage": label[name], "calls": n, "ms_per_call": ms / n, "flop_per_call": fl,
-                               "tflops": tf, "frac": tf / FP64_MFMA_PEAK_TFLOPS,
-                               "share_of_step": ms / (ms_step * stage_steps)})
-                if name == "factor_inverse":
-                    stages[-1]["ms_step_launches"] = pm / pn
-                    stages[-1]["ms_after_last_step"] = tm / pn
-            return stages
-
         if args.workload in ("c2", "c1"):
             # sanity: the timed output is finite and shaped (units, 2, M)
             assert res.shape == (world, 2, M) and bool(torch.isfinite(res).all())
@@ -632,7 +728,7 @@ def main():
             n3 = float(N) ** 3
             flop_step = T * n3 + 2.0 * n3 / 3.0 + float(N) ** 2 * M       # per GPU
             achieved = flop_step / (ms_step * 1e-3) / 1e12
-            stages = stage_breakdown(N, 1)
+            stages = stage_breakdown(stage_ms, N, 1, M, ms_step, stage_steps)
             lau_ms, lau_n = stage_ms["lauum"]
             pot_ms, pot_n = stage_ms["potrf"]
             traffic = None
@@ -650,9 +746,9 @@ def main():
                 "kernel": "chol_step_kernel / gemm_tiles_kernel (fp64 MFMA tile engine, every O(N^3) stage); largest "
                           "share of the step: factorisation + inverse (chol_step_kernel launches)",
                 "stages": stages,
-                "stages_from": "the timed steps" if timers_inside else "one extra step after the timed ones (timers off "
-                               "in the timed steps: they replay a captured iteration)",
-                "chain_us_per_128": (pot_ms / pot_n * 1e3 / math.ceil(N / 128.0)) if pot_n else None,
+                "stages_from": "one extra step after the timed ones, stage timers on (%.1f ms; the timed steps run with "
+                               "the timers off)" % ms_stage_step,
+                "chain_us_per_128": chain_us(stage_ms, N),
                 "dominant_launch": {
                     "kernel": lauum_kernel + " (K^-1 = L^-T L^-1: exactly one launch per Adam iteration, N^3/3 flop)",
                     "launches": lau_n, "avg_launch_ms": lau_ms / max(lau_n, 1),
@@ -710,10 +806,10 @@ def main():
                                "scope": "whole step per GPU: 64 x (T*N^3 + 2N^3/3 + N^2*M) flop / ms_per_step / n_gpus; "
                                         "stages: one extra step with rank 0's slices as ONE lock-step batch of %d problems per launch "
                                         "(share_of_step is relative to the concurrent timed step)" % nprob,
-                               "stages": stage_breakdown(N, nprob),
+                               "stages": stage_breakdown(stage_ms, N, nprob, M, ms_step, stage_steps),
                                "stages_from": "one extra step after the timed ones (timers off in the timed steps: they "
                                               "replay a captured iteration)",
-                               "chain_us_per_128": (pot_ms / pot_n * 1e3 / math.ceil(N / 128.0)) if pot_n else None}
+                               "chain_us_per_128": chain_us(stage_ms, N)}
             out["stages_ms_per_call"] = {k: (v[0] / v[1] if v[1] else None) for k, v in stage_ms.items()}
         if world == 1:
             if args.no_cpu_baseline:

@@ -80,6 +80,87 @@ def test_notebook_trace(gpim, which, nsteps, golden_dir, tmp_path):
     check_rows(rows, trace)
 
 
+def test_c4_readme_instance_vs_oracle(gpim, tmp_path):
+    """Config C4 exactly as bench.py times it (README.md:71-106 of the reference: 25x25, np.random.seed(42), 4 seed points,
+    EI with xi = 0.01, 30 exploration steps x 1000 Adam iterations, lr 0.05, jitter 1e-6, seed 0) against the oracle's
+    boptimizer: the sequence of queried indices is EQUAL and the hyper-parameters after each of the 31 000 Adam iterations
+    agree to rel 1e-7 (the bar of the other BO traces: 31 warm-started trainings in a row)."""
+    from problems import notebook_problem
+    trial_func, Z = notebook_problem(4)
+    bo = gpim.boptimizer(gpim.utils.get_sparse_grid(Z), Z.copy(), gpim.utils.get_full_grid(Z), trial_func,
+                         acquisition_function="ei", exploration_steps=30, verbose=0, filename=str(tmp_path / "bo"))
+    bo.run()
+    torch.set_num_threads(8)
+    ob = O.boptimizer(O.get_sparse_grid(Z), Z.copy(), O.get_full_grid(Z), trial_func, acquisition_function="ei",
+                      exploration_steps=30, verbose=0, filename=str(tmp_path / "bo_oracle"))
+    ob.run()
+    torch.set_num_threads(1)
+    assert len(bo.indices_all) == 30
+    assert [tuple(int(v) for v in i) for i in bo.indices_all] == [tuple(int(v) for v in i) for i in ob.indices_all]
+    hh, ho = bo.surrogate_model.hyperparams, ob.surrogate_model.hyperparams
+    for key in ("variance", "lengthscale", "noise"):
+        a, b = np.asarray(hh[key], dtype=float), np.asarray(ho[key], dtype=float)
+        assert a.shape == b.shape and a.shape[0] == 31000
+        assert_allclose(a, b, rtol=1e-7, atol=0)
+    assert_allclose(bo.target_func_vals[-1], ob.target_func_vals[-1], equal_nan=True)
+
+
+def test_long_campaign_across_the_regime_switch(gpim, tmp_path):
+    """One long BO campaign of the shape of examples/contributed/GPIM_BEPS.ipynb:650 (50x50 grid, ~100 seed points, EI,
+    dscale=10, exit_strategy=1, a border mask, RBF with ONE shared lengthscale in [0.5, 2], gp_iterations=300, batch_size=500;
+    60 exploration steps instead of 401): the surrogate starts in the fused small-N trainer (N <= 128, smalln.hip), and
+    leaves it mid-run for the general engine with its hipGraph-replayed iterations, with warm-started hyper-parameters all
+    along.  Against the oracle's boptimizer: the index sequence is equal and the hyper-parameters after every training
+    agree."""
+    rng = np.random.RandomState(7)
+    ii, jj = np.meshgrid(np.arange(50), np.arange(50), indexing="ij")
+
+    noise_tab = 0.03 * rng.standard_normal((50, 50))         # measurement noise, fixed per pixel (both runs see the same data)
+
+    def surface(i, j):
+        return (np.exp(-((i - 14) ** 2 + (j - 33) ** 2) / 60.0) + 0.7 * np.exp(-((i - 36) ** 2 + (j - 12) ** 2) / 90.0)
+                + 0.2 * np.sin(i / 5.0) * np.cos(j / 7.0) + noise_tab[i, j])
+
+    def func(idx):
+        return surface(idx[0], idx[1])
+    Z = np.ones((50, 50)) * np.nan
+    seeds = rng.choice(2500, size=100, replace=False)
+    for q in seeds:
+        Z[q // 50, q % 50] = surface(q // 50, q % 50)
+    mask = np.full((50, 50), np.nan)
+    mask[3:-3, 3:-3] = 1.0
+    mask[~np.isnan(Z)] = np.nan
+    nsteps = 60
+    kw = dict(acquisition_function="ei", exploration_steps=nsteps, dscale=10., exit_strategy=1, mask=mask, kernel="RBF",
+              batch_size=500, gp_iterations=300, lengthscale=[.5, 2.], verbose=0)
+
+    def campaign(mod, name):
+        bo = mod.boptimizer(mod.utils.get_sparse_grid(Z) if hasattr(mod, "utils") else mod.get_sparse_grid(Z), Z.copy(),
+                            mod.utils.get_full_grid(Z) if hasattr(mod, "utils") else mod.get_full_grid(Z), func,
+                            filename=str(tmp_path / name), **kw)
+        rows, sizes = [], []
+        train = bo.surrogate_model.train
+
+        def recording_train(**k):
+            train(**k)
+            hp = bo.surrogate_model.hyperparams
+            rows.append([hp["variance"][-1], hp["lengthscale"][-1], hp["noise"][-1]])
+            sizes.append(int(np.count_nonzero(~np.isnan(bo.y_sparse))))
+        bo.surrogate_model.train = recording_train
+        bo.run()
+        return bo, np.array(rows, dtype=float), sizes
+    bo, rows, sizes = campaign(gpim, "bo")
+    torch.set_num_threads(8)
+    ob, rows_o, sizes_o = campaign(O, "bo_oracle")
+    torch.set_num_threads(1)
+    assert sizes == sizes_o and sizes[0] == 100 and sizes[0] <= 128 < sizes[-1]          # the run crosses the regime switch
+    assert len(bo.indices_all) == nsteps
+    assert [tuple(int(v) for v in i) for i in bo.indices_all] == [tuple(int(v) for v in i) for i in ob.indices_all]
+    assert rows.shape == rows_o.shape == (nsteps + 1, 3)
+    assert_allclose(rows, rows_o, rtol=1e-7, atol=0)
+    assert_allclose(bo.target_func_vals[-1], ob.target_func_vals[-1], equal_nan=True)
+
+
 def test_run_medium_vs_oracle(gpim):
     """64x64 spiral image (N ~ 1000, M = 4096), 30 Adam steps, RBF: outputs vs the oracle."""
     R, _ = spiral_image(size=64, keep=0.25, seed=5)
