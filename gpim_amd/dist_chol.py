@@ -39,6 +39,7 @@ needs the GPU -- there is no CPU fallback in the product path.
 import contextlib
 import ctypes
 import math
+import os
 
 import numpy as np
 import torch
@@ -47,6 +48,14 @@ import torch.distributed as dist
 NB = 128
 PANEL = 4            # 128-blocks per panel (OUTER_W of csrc/api.hip)
 PW = NB * PANEL
+
+
+def _force_collectives():
+    """Test mode (GPIM_DIST_FORCE_COLLECTIVES=1): issue every broadcast / all-reduce of the schedule at world size 1 too.
+    A one-rank RCCL communicator is legal, so a one-GPU box can run the collectives' REAL stream semantics (the
+    collective on RCCL's own stream, ``async_op=True`` Work handles consumed on another stream), which gloo -- blocking the
+    host -- cannot show (tests/tools/nccl1_worker.py)."""
+    return os.environ.get("GPIM_DIST_FORCE_COLLECTIVES", "0") not in ("", "0")
 
 
 def _world():
@@ -109,6 +118,17 @@ class HipTileEngine:
         self.logdet = torch.zeros((layout.npanel, PANEL), dtype=torch.float64, device=self.device)
         self._ev = torch.cuda.Event()
         self._own = None
+        # fault injection (tests/tools/dist2_worker.py): GPIM_DIST_FAULT_DELAY_US > 0 puts a spin kernel of that length in
+        # front of EVERY engine launch, on the stream the launch goes to -- producers on the side stream (panel chain, pack,
+        # vector solves) and consumers on the main stream alike.  Every ordering between the two streams and the broadcasts
+        # is an explicit event / Work edge; with the launches pushed apart, a missing edge reads or overwrites a buffer
+        # at the wrong time and the result differs from the undelayed run.
+        self._delay_cycles = int(float(os.environ.get("GPIM_DIST_FAULT_DELAY_US", "0")) * 2000)
+
+    def _inject(self, side):
+        if self._delay_cycles:
+            with torch.cuda.stream(self.side if side else torch.cuda.current_stream(self.device)):
+                torch.cuda._sleep(self._delay_cycles)
 
     def empty(self, rows, cols):
         return torch.zeros((rows, cols), dtype=torch.float64, device=self.device)
@@ -134,12 +154,14 @@ class HipTileEngine:
         return _W()
 
     def panel_factor(self, Aloc, p):
+        self._inject(True)
         L, lib = self.layout, self.Hs.lib
         self._lib.check(lib.gpimhip_dist_panel_factor(
             self.Hs.h, self._lib.ptr(Aloc), Aloc.stride(0), L.local_col0(p) // NB, p * PANEL,
             ctypes.c_void_p(self.logdet[p].data_ptr()), self._lib.ptr(self.info)))
 
     def pack(self, Aloc, p, buf):
+        self._inject(True)
         L, lib = self.layout, self.Hs.lib
         self._lib.check(lib.gpimhip_dist_panel_pack(
             self.Hs.h, self._lib.ptr(Aloc), Aloc.stride(0), L.local_col0(p) // NB, p * PANEL, self._lib.ptr(buf),
@@ -148,23 +170,27 @@ class HipTileEngine:
     # ---- main stream
     def update(self, buf, p, Aloc, first, last):
         """Trailing update of the owned panels c, first <= c < last, with the packed panel p: one launch."""
+        self._inject(False)
         lib = self.H.lib
         self._lib.check(lib.gpimhip_dist_update(self.H.h, self._lib.ptr(buf), buf.stride(0), p * PANEL,
                                                 self._lib.ptr(Aloc), Aloc.stride(0), first, last))
 
     def solve_update(self, buf, p, B, Wt, q, col_tiles=0):
+        self._inject(False)
         lib = self.H.lib
         self._lib.check(lib.gpimhip_dist_solve_update(self.H.h, self._lib.ptr(buf), buf.stride(0), p * PANEL,
                                                       self._lib.ptr(B), B.stride(0), B.shape[1], self._lib.ptr(Wt),
                                                       Wt.stride(0), self._lib.ptr(q), col_tiles))
 
     def solve_update2(self, wide, p, B, Wt2, q, col_tiles, second):
+        self._inject(False)
         lib = self.H.lib
         self._lib.check(lib.gpimhip_dist_solve_update2(self.H.h, self._lib.ptr(wide), wide.stride(0), p * PANEL,
                                                        self._lib.ptr(B), B.stride(0), B.shape[1], self._lib.ptr(Wt2),
                                                        Wt2.stride(0), self._lib.ptr(q), col_tiles, int(second)))
 
     def kinv_update(self, xbuf, c, Xloc, Kinv):
+        self._inject(False)
         lib = self.H.lib
         self._lib.check(lib.gpimhip_dist_kinv_update(self.H.h, self._lib.ptr(xbuf), xbuf.stride(0), c * PANEL,
                                                      self._lib.ptr(Xloc), Xloc.stride(0), self._lib.ptr(Kinv),
@@ -172,12 +198,14 @@ class HipTileEngine:
 
     # ---- O(N^2) vector solves on the owner of a panel: the side handle factored it and holds its diagonal-block inverses
     def vec_forward(self, Aloc, p, y_p, t, piece, acc):
+        self._inject(True)
         L, lib = self.layout, self.Hs.lib
         self._lib.check(lib.gpimhip_dist_vec_forward(self.Hs.h, self._lib.ptr(Aloc), Aloc.stride(0), L.local_col0(p) // NB,
                                                      p * PANEL, ctypes.c_void_p(y_p.data_ptr()),
                                                      ctypes.c_void_p(t.data_ptr()), self._lib.ptr(piece), self._lib.ptr(acc)))
 
     def vec_backward(self, Aloc, p, z_p, a, work, piece):
+        self._inject(True)
         L, lib = self.layout, self.Hs.lib
         self._lib.check(lib.gpimhip_dist_vec_backward(self.Hs.h, self._lib.ptr(Aloc), Aloc.stride(0), L.local_col0(p) // NB,
                                                       p * PANEL, ctypes.c_void_p(z_p.data_ptr()), self._lib.ptr(a),
@@ -215,6 +243,7 @@ class DistributedCholesky:
         self._X = self._Wt = None                      # workspaces of ``inverse``
         self._wide = None                              # two panels side by side (``_stream_pairs``), two such buffers
         self._factored = False                         # ``local`` holds a factor (set by factor(), cleared by kinv(out=local))
+        self._coll = self.layout.world > 1 or (_force_collectives() and dist.is_available() and dist.is_initialized())
 
     def _need_factor(self, what):
         """``kinv(X, out=self.local)`` writes K^-1's lower tiles over the factor (tiles above the diagonal keep what
@@ -253,7 +282,7 @@ class DistributedCholesky:
             with self._side():
                 eng.panel_factor(self.local, p)
                 eng.pack(self.local, p, buf)
-                if L.world > 1:
+                if self._coll:
                     return dist.broadcast(self._wire(buf, p), src=L.rank, group=self.group, async_op=True)
             return self._side_done()
         return dist.broadcast(self._wire(buf, p), src=L.owner(p), group=self.group, async_op=True)
@@ -334,13 +363,13 @@ class DistributedCholesky:
         for p in range(L.npanel):
             r0 = p * PW
             t.copy_(acc[r0:r0 + PW])
-            if L.world > 1:
+            if self._coll:
                 dist.all_reduce(t, group=self.group)
             if L.owner(p) == L.rank:
                 with self._side():
                     eng.vec_forward(self.local, p, rhs_full[r0:r0 + PW], t, piece, acc)
                 self._side_done().wait()
-            if L.world > 1:
+            if self._coll:
                 dist.broadcast(piece, src=L.owner(p), group=self.group)
             z[r0:r0 + PW].copy_(piece)
         # backward, alpha = L^-T z: the owner of panel p holds L(rows below, panel p) and alpha of the rows
@@ -352,7 +381,7 @@ class DistributedCholesky:
                 with self._side():
                     eng.vec_backward(self.local, p, z[r0:r0 + PW], a, work, piece)
                 self._side_done().wait()
-            if L.world > 1:
+            if self._coll:
                 dist.broadcast(piece, src=L.owner(p), group=self.group)
             a[r0:r0 + PW].copy_(piece)
         self._z = z[:L.np]
@@ -389,7 +418,7 @@ class DistributedCholesky:
         if L.owner(p) == L.rank:
             with self._side():
                 fill(buf)
-                if L.world > 1:
+                if self._coll:
                     return dist.broadcast(self._wire(buf, p), src=L.rank, group=self.group, async_op=True)
             return self._side_done()
         return dist.broadcast(self._wire(buf, p), src=L.owner(p), group=self.group, async_op=True)

@@ -38,6 +38,18 @@ def test_two_ranks_one_gpu_product_paths(ensure_built):
     assert r.returncode == 0 and "DIST2 OK" in r.stdout, r.stdout[-4000:]
 
 
+def test_rccl_world1(ensure_built):
+    """One rank under the nccl backend (RCCL) on the one GPU: the device-tensor collectives of gpim_amd.dist and the
+    distributed Cholesky with every broadcast / all-reduce issued on RCCL's own stream, launches pushed apart by spin
+    kernels -- bitwise equal to the plain run (tests/tools/nccl1_worker.py)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    env.pop("GPIM_DIST_BACKEND", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "nccl1_worker.py")], cwd=ROOT, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0 and "NCCL1 OK" in r.stdout, r.stdout[-4000:]
+
+
 @pytest.mark.parametrize("workload,extra", [("c3", ["--iterations", "5"]), ("c2", ["--iterations", "2"]),
                                             ("c1", ["--iterations", "5"]), ("c2full", [])])
 def test_bench_two_ranks(ensure_built, workload, extra):

@@ -171,6 +171,38 @@ def main():
         ul = [torch.empty_like(us.cpu()) for _ in range(world)]
         dist.all_gather(ul, us.cpu())
         check("sharded blocks %s: every rank holds the same parameters" % (shape,), all(torch.equal(ul[0], t) for t in ul))
+    # 7. fault injection: a 300 us spin kernel in front of EVERY engine launch -- the panel chain, pack and vector solves on
+    #    the side stream, every consumer on the main stream (GPIM_DIST_FAULT_DELAY_US, gpim_amd/dist_chol.py).  The two
+    #    streams, the two broadcast buffers and the pair buffers are ordered by explicit event / Work edges only; with the
+    #    launches pushed apart a missing edge reads or overwrites a buffer at the wrong time.  Every product of the schedule
+    #    must come out BITWISE as in the undelayed run.
+    def schedule_products(n, seed):
+        rng7 = np.random.default_rng(seed)
+        Bm = rng7.standard_normal((n, n // 3))
+        A7 = torch.from_numpy(Bm @ Bm.T + n * np.eye(n)).to(dev)
+        y7 = torch.from_numpy(rng7.standard_normal(n)).to(dev)
+        Bq = torch.from_numpy(rng7.standard_normal((n, 200)))
+        ch = DistributedCholesky(n)
+        ch.set_from_function(lambda c0, c1: A7[:, c0:c1]).factor()
+        Lg = ch.gather_lower().clone()
+        al = ch.solve(y7).clone()
+        Bp = torch.zeros((ch.layout.np, 200), dtype=torch.float64, device=dev)
+        Bp[:n] = Bq.to(dev)
+        q = ch.solve_colsumsq(Bp).clone()
+        Xl = ch.inverse()
+        Xc = Xl.clone()
+        Kl = ch.kinv(Xl).clone()
+        torch.cuda.synchronize()
+        return Lg, al, q, Xc, Kl
+    for n in (2600, 3300):
+        os.environ["GPIM_DIST_FAULT_DELAY_US"] = "0"
+        base = schedule_products(n, n)
+        os.environ["GPIM_DIST_FAULT_DELAY_US"] = "300"
+        slow = schedule_products(n, n)
+        os.environ["GPIM_DIST_FAULT_DELAY_US"] = "0"
+        for name, a, b in zip(("factor", "solve", "colsumsq", "inverse", "kinv"), base, slow):
+            check("fault injection n=%d: %s unchanged under 300 us delays" % (n, name), torch.equal(a, b),
+                  "%.3e" % (a - b).abs().max().item())
     flag = torch.tensor([0 if ok else 1], dtype=torch.int64)
     dist.all_reduce(flag)
     for m in msgs:
