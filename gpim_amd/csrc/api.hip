@@ -28,6 +28,11 @@ int launch_grad_reduce(gpimhip_ctx* h, const gpimhip_model_t* m, const double* K
 int launch_kres(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X, int64_t x_bs, int64_t N, double* scratch,
                 int S, double* res);
 int launch_axpy(gpimhip_ctx* h, double* x, const double* d, int64_t n);
+int launch_gemv_t_tri(gpimhip_ctx* h, const double* A, int64_t ld, int64_t np, const double* x, double* part, double* out);
+int launch_grad_reduce_fin(gpimhip_ctx* h, const gpimhip_model_t* m, const double* Kinv, int64_t ld, const double* X,
+                           int64_t N, int nb, const double* alpha, int64_t x_bs, const double* alpha_part, double* u,
+                           int do_adam, AdamStep st, double* loss_out, double* grad_out, double* hist_row, int32_t* iter,
+                           const double* bc, int T, double* hist_base, double* loss_base, int carry_theta);
 int launch_finalize(gpimhip_ctx* h, const gpimhip_model_t* m, int64_t N, int64_t np, double* u, int do_adam,
                     AdamStep st, double* loss_out, double* grad_out, double* hist_row, int32_t* iter,
                     const double* bc, int T, double* hist_base, double* loss_base);
@@ -101,7 +106,8 @@ static void ws_release_matrix(gpimhip_ctx* h) {
     dev_free(h, &h->alpha, B * np);
     dev_free(h, &h->logdet_part, B * nb);
     dev_free(h, &h->grad_part, B * nb * (nb + 1) / 2 * 8);
-    dev_free(h, &h->gemv_part, B * 8 * np);
+    dev_free(h, &h->gemv_part, B * std::max<int64_t>(8, gemv_tri_chunks(np)) * np);
+    dev_free(h, &h->fin_counter, (int64_t)B);
     dev_free(h, &h->theta, B);
     dev_free(h, &h->adam_m, B * MAXP);
     dev_free(h, &h->adam_v, B * MAXP);
@@ -139,12 +145,13 @@ static int ws_ensure_b(gpimhip_ctx* h, int64_t N, int B, int padded, bool matric
         (rc = dev_alloc(h, &h->pcopy, (int64_t)B * NB * NB)) ||
         (rc = dev_alloc(h, &h->ypad, B * np)) || (rc = dev_alloc(h, &h->z, B * np)) ||
         (rc = dev_alloc(h, &h->alpha, B * np)) || (rc = dev_alloc(h, &h->logdet_part, B * nb)) ||
-        (rc = dev_alloc(h, &h->grad_part, B * nb * (nb + 1) / 2 * 8)) || (rc = dev_alloc(h, &h->gemv_part, B * 8 * np)) || (rc = dev_alloc(h, &h->theta, (int64_t)B)) ||
+        (rc = dev_alloc(h, &h->grad_part, B * nb * (nb + 1) / 2 * 8)) || (rc = dev_alloc(h, &h->gemv_part, B * std::max<int64_t>(8, gemv_tri_chunks(np)) * np)) || (rc = dev_alloc(h, &h->fin_counter, (int64_t)B)) || (rc = dev_alloc(h, &h->theta, (int64_t)B)) ||
         (rc = dev_alloc(h, &h->adam_m, (int64_t)B * MAXP)) || (rc = dev_alloc(h, &h->adam_v, (int64_t)B * MAXP)) ||
         (rc = dev_alloc(h, &h->iter, (int64_t)B))) {
         ws_release_matrix(h);
         return rc;
     }
+    HIP_TRY(hipMemsetAsync(h->fin_counter, 0, (size_t)B * sizeof(uint32_t), h->stream));   // (the last workgroups reset them)
     if (matrices) {
         // Tm / B: a ragged last block (GemmArgs::rag) never writes the rows of its identity padding
         HIP_TRY(hipMemsetAsync(h->Tm, 0, (size_t)mat_doubles(h, B * np * ld) * sizeof(double), h->stream));
@@ -471,10 +478,15 @@ static int refine_passes() {
     static const int v = 1;
     return v;
 }
-static int solve_vectors(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X, int64_t x_bs, int64_t N) {
+// defer_alpha (double precision only): alpha stays as the row-chunk partial sums in h->gemv_part -- the gradient
+// contraction adds up the entries it needs itself (launch_grad_reduce_fin), one launch less per iteration; h->alpha is
+// then NOT valid.
+static bool alpha_deferrable(const gpimhip_ctx* h) { return !h->fp32 && !h->refl.mask && h->np <= 8192 && !getenv("GPIMHIP_NO_FUSED_FINALIZE"); }
+static int solve_vectors(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X, int64_t x_bs, int64_t N,
+                         bool defer_alpha = false) {
     const int64_t np = h->np, ld = h->ld;
     GP_TRY(launch_trmv_lower(h, h->A, ld, np, h->ypad, h->z));
-    GP_TRY(launch_gemv_t(h, h->A, ld, np, np, h->z, h->alpha, 1, np * ld, np, np, h->gemv_part));
+    GP_TRY(launch_gemv_t_tri(h, h->A, ld, np, h->z, h->gemv_part, defer_alpha && !h->fp32 ? nullptr : h->alpha));
     if (!h->fp32) return GPIMHIP_OK;
     const int B = h->nbatch, nb = (int)(np / NB);
     const int S = std::max(1, std::min(8, 512 / std::max(1, nb * B)));        // >= ~512 workgroups per launch
@@ -482,32 +494,40 @@ static int solve_vectors(gpimhip_ctx* h, const gpimhip_model_t* m, const double*
     for (int pass = 0; pass < refine_passes(); ++pass) {
         GP_TRY(launch_kres(h, m, X, x_bs, N, scratch, S, res));
         GP_TRY(launch_trmv_lower(h, h->A, ld, np, res, h->z));
-        GP_TRY(launch_gemv_t(h, h->A, ld, np, np, h->z, delta, 1, np * ld, np, np, h->gemv_part));
+        GP_TRY(launch_gemv_t_tri(h, h->A, ld, np, h->z, h->gemv_part, delta));
         GP_TRY(launch_axpy(h, h->alpha, delta, (int64_t)B * np));
     }
     return GPIMHIP_OK;
 }
 
 // K(u) -> L -> L^-1 (in h->A), then z = L^-1 y and alpha = L^-T z
+// theta_current: h->theta already holds theta(u) -- the previous iteration's finalize step wrote it (fit_impl)
 static int factor_at_u(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X, int64_t x_bs, int64_t N,
-                       const double* u) {
+                       const double* u, bool theta_current = false, bool defer_alpha = false) {
     const int64_t np = h->np, ld = h->ld;
-    GP_TRY(launch_theta(h, m, u));
+    if (!theta_current) GP_TRY(launch_theta(h, m, u));
     if (h->refl.mask)      // symmetry-reduced model: problem b of the batch is the block of sign pattern b (engine.hip)
         GP_TRY(launch_kmat_refl(h, m, X, N, nullptr, N, h->theta, h->A, ld, np, np, 1, x_bs, x_bs, np * ld, 1.0));
     else
         GP_TRY(launch_kmat(h, m, X, N, nullptr, N, h->theta, 0.0, 1, h->A, ld, np, np, 1, 1, x_bs, x_bs, np * ld));
     GP_TRY(launch_potrf_inv(h, h->A, h->Tm, np, ld, h->info, rag_of(N, np)));
-    return solve_vectors(h, m, X, x_bs, N);
+    return solve_vectors(h, m, X, x_bs, N, defer_alpha);
 }
 
-struct IterTable { int32_t* iter; const double* bc; int T; double* hist_base; double* loss_base; };
+// theta_carried: the training loop launched theta(u) once before its first iteration; every finalize step then leaves the
+// theta of the stepped parameters in h->theta (no theta launch inside the loop)
+struct IterTable { int32_t* iter; const double* bc; int T; double* hist_base; double* loss_base; bool theta_carried; };
 
 static int loss_grad_at_u(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X, int64_t x_bs, int64_t N,
                           double* u, int do_adam, AdamStep st, double* loss_out, double* grad_out,
                           double* hist_row, const IterTable* tab = nullptr) {
     const int64_t np = h->np;
-    GP_TRY(factor_at_u(h, m, X, x_bs, N, u));
+    // One launch for the gradient contraction and the finalize step (round 6; GPIMHIP_NO_FUSED_FINALIZE: the two launches
+    // of rounds 1-5 -- the same reductions in the same order, the same bits)
+    const bool fused = !h->refl.mask && !getenv("GPIMHIP_NO_FUSED_FINALIZE");
+    const bool carried = fused && tab && tab->theta_carried;
+    const bool defer = fused && alpha_deferrable(h);
+    GP_TRY(factor_at_u(h, m, X, x_bs, N, u, carried, defer));
     { StageTimer t(h, 2); GP_TRY(launch_lauum(h, h->A, h->B, np, h->ld, rag_of(N, np))); }
     if (h->refl.mask) {
         GP_TRY(launch_grad_reduce_refl(h, m, h->B, h->ld, X, N, (int)(np / NB), h->alpha, x_bs));
@@ -516,6 +536,15 @@ static int loss_grad_at_u(gpimhip_ctx* h, const gpimhip_model_t* m, const double
                                            tab->hist_base, tab->loss_base);
         return launch_finalize_coupled(h, m, N, np, u, do_adam, st, loss_out, grad_out, hist_row, nullptr, nullptr, 0, nullptr,
                                        nullptr);
+    }
+    if (fused) {
+        const double* ap = defer ? h->gemv_part : nullptr;
+        if (tab)
+            return launch_grad_reduce_fin(h, m, h->B, h->ld, X, N, (int)(np / NB), h->alpha, x_bs, ap, u, do_adam, st, nullptr,
+                                          nullptr, nullptr, tab->iter, tab->bc, tab->T, tab->hist_base, tab->loss_base,
+                                          carried ? 1 : 0);
+        return launch_grad_reduce_fin(h, m, h->B, h->ld, X, N, (int)(np / NB), h->alpha, x_bs, ap, u, do_adam, st, loss_out,
+                                      grad_out, hist_row, nullptr, nullptr, 0, nullptr, nullptr, 0);
     }
     GP_TRY(launch_grad_reduce(h, m, h->B, h->ld, X, N, (int)(np / NB), h->alpha, x_bs));
     if (tab)
@@ -764,8 +793,13 @@ static int fit_impl(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X, i
     HIP_TRY(hipMemsetAsync(h->adam_m, 0, (size_t)B * MAXP * sizeof(double), h->stream));
     HIP_TRY(hipMemsetAsync(h->adam_v, 0, (size_t)B * MAXP * sizeof(double), h->stream));
     HIP_TRY(hipMemsetAsync(h->iter, 0, (size_t)B * sizeof(int32_t), h->stream));     // iteration counters
+    HIP_TRY(hipMemsetAsync(h->fin_counter, 0, (size_t)B * sizeof(uint32_t), h->stream));   // (zero already, unless a launch was cut short)
     GP_TRY(launch_pad_copy(h, y, N, h->ypad, h->np));
-    IterTable tab{h->iter, h->bc, T, hist_out, loss_out};
+    // theta(u) once; after that every iteration's finalize step leaves the next theta behind (not for the symmetry-reduced
+    // model, whose coupled finalize step is a launch of its own)
+    const bool carry = !h->refl.mask && !getenv("GPIMHIP_NO_FUSED_FINALIZE");
+    if (carry) GP_TRY(launch_theta(h, m, u));
+    IterTable tab{h->iter, h->bc, T, hist_out, loss_out, carry};
     AdamStep st;
     st.beta1 = 0.9; st.beta2 = 0.999; st.eps = 1e-8; st.lr_over_bc1 = 0.0; st.bc2_sqrt = 1.0;
     // Every iteration enqueues the same launches (the iteration index lives on the device), so one

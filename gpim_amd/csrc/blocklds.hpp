@@ -529,8 +529,17 @@ template <class Lay>
 __device__ __forceinline__ d4 fi_xfrag(const double* T, int r, int kq) {
     return Lay::XT ? fi_frag<Lay>(T, r, kq) : fi_fragT<Lay>(T, r, kq);
 }
+// the lane index, opaque to the optimiser: address arithmetic derived from it is redone where it is used instead of being
+// hoisted out of the step loop and kept live across it (chol_step_kernel at 128 registers spilled two such offsets)
+__device__ __forceinline__ int fi_lane_opaque() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
 template <class Lay>
-__device__ __forceinline__ void fi_inv_pair(const double* D, const double* Xp, int p, int j1, int j2, int lane, d4& x1, d4& x2) {
+__device__ __forceinline__ void fi_inv_pair(const double* D, const double* Xp, int p, int j1, int j2, int lane_, d4& x1, d4& x2) {
+    const int lane = fi_lane_opaque();
+    (void)lane_;
     const int r = lane & 15, kq = lane >> 4;
     d4 xa;
     {

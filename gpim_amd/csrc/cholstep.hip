@@ -63,7 +63,7 @@ struct StepArgs {
 // the role from 35 to 50 us (its serial fp64 chain shares the SIMD's fp64 pipe with the neighbour's MFMAs), and what
 // such a launch hosts for free is one quadrant per CU anyway.
 template <int FTM, int FTN, bool ALONE, bool RAG = false>
-__global__ __launch_bounds__(NTH, 4) void chol_step_kernel(StepArgs a) {
+__global__ __launch_bounds__(NTH, ALONE ? 2 : 4) void chol_step_kernel(StepArgs a) {
     constexpr int SM0 = POTF2_SMEM_DOUBLES > gemm_smem_doubles<FTM, FTN, 2>() ? POTF2_SMEM_DOUBLES : gemm_smem_doubles<FTM, FTN, 2>();
     static_assert(SM0 * 8 <= 80 * 1024, "two workgroups per CU");
     constexpr int SM = ALONE ? 84 * 128 : SM0;
@@ -99,8 +99,8 @@ __global__ __launch_bounds__(NTH, 4) void chol_step_kernel(StepArgs a) {
     // beside hosted neighbours on its CU the serial chain competes with their MFMA blocks (raised to priority 3 in the
     // tile engine): the role runs at that priority throughout (chain-bound launches: 1.93 -> 1.90 ms at N = 4212)
     if (!ALONE) __builtin_amdgcn_s_setprio(3);
-    potf2_body<double>(smem, by + a.pb_off, a.A, a.ld, a.kblk, a.dinv_all, a.dinvB_all, a.logdet, a.info, a.nb, a.col_off,
-                       a.Tm != nullptr);
+    potf2_body<double, ALONE && FI_LOOKAHEAD>(smem, by + a.pb_off, a.A, a.ld, a.kblk, a.dinv_all, a.dinvB_all, a.logdet, a.info, a.nb,
+                                              a.col_off, a.Tm != nullptr);
 }
 
 // Panel solve, one workgroup (4 waves) per 32-row strip of the block column below the diagonal block:

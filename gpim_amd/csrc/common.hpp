@@ -141,7 +141,9 @@ struct gpimhip_ctx {
     double* alpha = nullptr;        // np  (K^-1 y)
     double* logdet_part = nullptr;  // nb
     double* grad_part = nullptr;    // ntiles_lower x 8
-    double* gemv_part = nullptr;    // 8 x np: row-chunk partial sums of the mat-vec over L^-1 (engine.hip: launch_gemv_t)
+    double* gemv_part = nullptr;    // max(8, gemv_tri_chunks(np)) x np: row-chunk partial sums of the mat-vecs over L^-1 (engine.hip)
+    uint32_t* fin_counter = nullptr;   // per problem: workgroups of grad_reduce_kernel that have finished (engine.hip: FinFused; the last
+                                       // one runs the finalize step and resets it)
     ThetaDev* theta = nullptr;      // [ws_batch]
     ThetaDev* theta1 = nullptr;     // single struct for the operator-level gpimhip_kmat
     int32_t* iter = nullptr;        // [ws_batch] device-side iteration counters
@@ -217,6 +219,13 @@ struct StageTimer {
 };
 
 // ---- drivers shared between translation units ----
+// row chunks of the triangular transposed mat-vec alpha = L^-T z (engine.hip: gemv_t_tri_kernel): ~np / 32 rows, a multiple
+// of 128 between 128 and 1024; a function of the matrix order alone (a problem gives the same bits alone and in a batch)
+static inline int gemv_tri_rc(int64_t np) {
+    const int64_t rc = ((np / 32 + NB - 1) / NB) * NB;
+    return (int)(rc < NB ? NB : (rc > 1024 ? 1024 : rc));
+}
+static inline int gemv_tri_chunks(int64_t np) { return (int)((np + gemv_tri_rc(np) - 1) / gemv_tri_rc(np)); }
 int ws_ensure(gpimhip_ctx* h, int64_t N);
 int ws_ensure_predict(gpimhip_ctx* h, int64_t np, int64_t mc);
 int plan_ensure(gpimhip_ctx* h, int nb);

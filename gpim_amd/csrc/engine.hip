@@ -9,6 +9,7 @@
 // Row labels refer to SURVEY.md section 8(a).  All reductions use fixed-shape trees so results are
 // bit-reproducible run to run.
 #include "kfun.hpp"
+#include <cstring>
 #include "theta.hpp"
 
 typedef double d2 __attribute__((ext_vector_type(2)));
@@ -374,6 +375,91 @@ int launch_gemv_t(gpimhip_ctx* h, const double* A, int64_t ld, int64_t nrows, in
 }
 
 // ------------------------------------------------------------------------------------------
+// alpha = L^-T z over the lower-triangular L^-1 (round 6).  The strip of a 64-column block starts at its diagonal
+// block, so strips run from np rows down to 128: cutting every strip into the SAME number of chunks (the kernel above)
+// leaves the launch waiting for the first strips' workgroups -- 1.5 TB/s at np = 16384.  Here the ROWS are cut into
+// chunks of rc (gemv_tri_rc: ~np / 32, a multiple of 128, 128 ... 1024): workgroup (column block, chunk) handles what
+// lies at or below the block's diagonal block -- equal work per workgroup, thousands of workgroups of four waves --
+// and writes 64 partial sums to part[chunk][column].  A wave reads two rows x 512 bytes per instruction (lane: row
+// parity, column pair), four instructions in flight.  alpha_j = sum over the chunks r >= r0(j) in increasing order:
+// gemv_tri_sum_kernel, or the consumer itself (grad_reduce_kernel sums the 256 entries it needs: gemv_tri_alpha).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double gemv_tri_alpha(const double* __restrict__ part, int nR, int rc, int64_t np, int64_t j) {
+    double t = 0.0;
+    for (int r = (int)(((j / NB) * NB) / rc); r < nR; ++r) t += part[(int64_t)r * np + j];
+    return t;
+}
+template <typename R>
+__global__ __launch_bounds__(256) void gemv_t_tri_kernel(const R* __restrict__ A, int64_t ld, int64_t np,
+                                                         const double* __restrict__ x, double* __restrict__ part, int rc,
+                                                         int nR, int64_t a_bs) {
+    __shared__ d2 red[4][32];
+    const int cb = blockIdx.x / nR, r = blockIdx.x % nR;
+    const int64_t diag0 = ((int64_t)cb * 64 / NB) * NB;
+    int64_t i0 = (int64_t)r * rc, i1 = i0 + rc < np ? i0 + rc : np;
+    if (i1 <= diag0) return;                                   // structurally zero: never read by the sum
+    if (i0 < diag0) i0 = diag0;
+    A += blockIdx.y * a_bs;
+    x += blockIdx.y * np;
+    part += ((int64_t)blockIdx.y * nR + r) * np;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, cp = lane & 31, rp = lane >> 5;
+    typedef typename Vec2<R>::T RV;
+    const R* col = A + (int64_t)cb * 64 + 2 * cp;
+    d2 s0 = (d2){0.0, 0.0}, s1 = s0, s2 = s0, s3 = s0;
+    int64_t i = i0 + 2 * wave + rp;                             // rows i, i + 8, i + 16, ... (8 = 4 waves x 2 rows)
+    for (; i + 24 < i1; i += 32) {
+        const RV a0 = *reinterpret_cast<const RV*>(col + i * ld), a1 = *reinterpret_cast<const RV*>(col + (i + 8) * ld);
+        const RV a2 = *reinterpret_cast<const RV*>(col + (i + 16) * ld), a3 = *reinterpret_cast<const RV*>(col + (i + 24) * ld);
+        const double x0 = x[i], x1 = x[i + 8], x2 = x[i + 16], x3 = x[i + 24];
+        s0[0] = fma((double)a0[0], x0, s0[0]); s0[1] = fma((double)a0[1], x0, s0[1]);
+        s1[0] = fma((double)a1[0], x1, s1[0]); s1[1] = fma((double)a1[1], x1, s1[1]);
+        s2[0] = fma((double)a2[0], x2, s2[0]); s2[1] = fma((double)a2[1], x2, s2[1]);
+        s3[0] = fma((double)a3[0], x3, s3[0]); s3[1] = fma((double)a3[1], x3, s3[1]);
+    }
+    for (; i < i1; i += 8) {
+        const RV a0 = *reinterpret_cast<const RV*>(col + i * ld);
+        const double x0 = x[i];
+        s0[0] = fma((double)a0[0], x0, s0[0]); s0[1] = fma((double)a0[1], x0, s0[1]);
+    }
+    d2 v;
+    v[0] = (s0[0] + s1[0]) + (s2[0] + s3[0]);
+    v[1] = (s0[1] + s1[1]) + (s2[1] + s3[1]);
+    v[0] += __shfl_xor(v[0], 32);                               // the two row parities (both halves end with the same sum)
+    v[1] += __shfl_xor(v[1], 32);
+    if (rp == 0) red[wave][cp] = v;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        d2 t = red[0][cp];
+        t[0] = ((t[0] + red[1][cp][0]) + red[2][cp][0]) + red[3][cp][0];
+        t[1] = ((t[1] + red[1][cp][1]) + red[2][cp][1]) + red[3][cp][1];
+        *reinterpret_cast<d2*>(part + (int64_t)cb * 64 + 2 * cp) = t;
+    }
+}
+__global__ __launch_bounds__(256) void gemv_tri_sum_kernel(const double* __restrict__ part, int nR, int rc, int64_t np,
+                                                           double* __restrict__ out) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= np) return;
+    out[blockIdx.y * np + j] = gemv_tri_alpha(part + (int64_t)blockIdx.y * nR * np, nR, rc, np, j);
+}
+// part: gemv_tri_chunks(np) * np doubles per problem (h->gemv_part); out == nullptr: the consumer sums the partials itself
+int launch_gemv_t_tri(gpimhip_ctx* h, const double* A, int64_t ld, int64_t np, const double* x, double* part, double* out) {
+    const int rc = gemv_tri_rc(np), nR = gemv_tri_chunks(np);
+    const dim3 grid((unsigned)((np / 64) * nR), h->nbatch);
+    if (h->fp32)
+        hipLaunchKernelGGL(gemv_t_tri_kernel<float>, grid, dim3(256), 0, h->stream, reinterpret_cast<const float*>(A), ld, np, x,
+                           part, rc, nR, np * ld);
+    else
+        hipLaunchKernelGGL(gemv_t_tri_kernel<double>, grid, dim3(256), 0, h->stream, A, ld, np, x, part, rc, nR, np * ld);
+    HIP_TRY(hipGetLastError());
+    if (out) {
+        hipLaunchKernelGGL(gemv_tri_sum_kernel, dim3((unsigned)((np + 255) / 256), h->nbatch), dim3(256), 0, h->stream,
+                           (const double*)part, nR, rc, np, out);
+        HIP_TRY(hipGetLastError());
+    }
+    return GPIMHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // residual r = y - (K + (jitter + noise) I) alpha with K generated on the fly in double (kmat_kernel's
 // arithmetic): the iterative-refinement step of single-precision handles.  alpha = K^-1 y through an fp32 factor
 // and its explicit fp32 inverse is off by eps32 * cond(K); one pass  alpha += K32^-1 (y - K alpha)  squares that
@@ -471,6 +557,183 @@ int launch_axpy(gpimhip_ctx* h, double* x, const double* d, int64_t n) {
 }
 
 // ------------------------------------------------------------------------------------------
+// finalize: sums the partials in a fixed tree, forms loss and d loss/du, then (fit mode) applies one torch.optim.Adam
+// step to u and records the constrained values.  Run by ONE workgroup of 256 threads: finalize_kernel, or (round 6) the
+// LAST workgroup of grad_reduce_kernel to finish (FinFused) -- the Adam step is then not a launch of its own, and the
+// theta of the stepped parameters is written for the next iteration's kmat_kernel (no theta launch either).
+// ------------------------------------------------------------------------------------------
+__device__ double block_sum_256(double v, double* red) {
+    const int tid = threadIdx.x;
+    red[tid] = v;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) red[tid] += red[tid + s];
+        __syncthreads();
+    }
+    const double r = red[0];
+    __syncthreads();
+    return r;
+}
+// The same tree for NQ quantities at once with three barriers: red[t] += red[t + 128], += red[t + 64] in LDS order, then
+// lane t += lane t + s for s = 32 ... 1 inside wave 0 -- what block_sum_256's steps compute for t < s, bit for bit.
+// arr: NQ x 256 doubles of LDS.  Results in out[0 .. NQ) (LDS), valid after the call for every thread.
+template <int NQ>
+__device__ __forceinline__ void block_sum_256_multi(const double* v, double* arr, double* out) {
+    const int tid = threadIdx.x;
+    __syncthreads();                                   // (arr may alias what the caller still read)
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) arr[q * 256 + tid] = v[q];
+    __syncthreads();
+    if (tid < 64) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const double* a = arr + q * 256;
+            double x = (a[tid] + a[tid + 128]) + (a[tid + 64] + a[tid + 192]);
+            x += __shfl_down(x, 32);
+            x += __shfl_down(x, 16);
+            x += __shfl_down(x, 8);
+            x += __shfl_down(x, 4);
+            x += __shfl_down(x, 2);
+            x += __shfl_down(x, 1);
+            if (tid == 0) out[q] = x;
+        }
+    }
+    __syncthreads();
+}
+
+// Iteration-indexed form: when `iter` is given the Adam bias corrections, the history row and the
+// loss slot are looked up by the device-resident iteration counter, which this kernel advances.  All
+// T iterations then enqueue byte-identical launches, i.e. one captured hipGraph can be replayed.
+struct FinalizeIter {
+    int32_t* iter;              // device counter (null: use the by-value arguments below)
+    const double* bc;           // [2*T]: lr/(1-beta1^t) then sqrt(1-beta2^t)
+    int32_t T;
+    double* hist_base;          // T x P or null
+    double* loss_base;          // T or null
+};
+
+// everything the finalize step of one problem needs (pointers already offset to the problem by the caller)
+struct FinProblem {
+    const double* grad_part; const double* z; const double* zb; const double* logdet_part;
+    ThetaDev* th; double* u; double* adam_m; double* adam_v;
+    FinalizeIter fi;
+};
+// COHERENT: the partial sums were written by other workgroups of the SAME launch (device-scope loads)
+template <bool COHERENT>
+__device__ __forceinline__ double fin_load(const double* p) {
+    return COHERENT ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+}
+// arr: 5 x 256 doubles of LDS, S: 9 doubles of LDS.  theta_next != nullptr: the theta of the stepped parameters goes there.
+template <bool COHERENT>
+__device__ __forceinline__ void finalize_block(const gpimhip_model_t& m, int64_t N, int64_t np, int nb, int ntile, FinProblem f,
+                                               int do_adam, AdamStep st, double* loss_out, double* grad_out, double* hist_row,
+                                               int32_t* info, ThetaDev* theta_next, double* arr, double* S) {
+    const int tid = threadIdx.x;
+    double v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // (four tiles' loads in flight, added in the order q = tid, tid + 256, ...: device-scope loads are round trips to
+    // memory, and one tile per trip made this loop 130 us at N = 16384)
+    for (int q0 = tid; q0 < ntile; q0 += 4 * 256) {
+        double t[4][7];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = q0 + 256 * i;
+            const double* g = f.grad_part + (int64_t)(q < ntile ? q : q0) * 8;
+#pragma unroll
+            for (int k = 0; k < 7; ++k) t[i][k] = fin_load<COHERENT>(g + k);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (q0 + 256 * i < ntile) {
+#pragma unroll
+                for (int k = 0; k < 7; ++k) v[k] += t[i][k];
+            }
+    }
+    for (int64_t i = tid; i < np; i += 256) v[7] = fma(f.z[i], f.zb[i], v[7]);     // |L^-1 y|^2, or y^T alpha (refined, fp32 matrices)
+    for (int k = tid; k < nb; k += 256) v[8] += f.logdet_part[k];
+    block_sum_256_multi<5>(v, arr, S);
+    block_sum_256_multi<4>(v + 5, arr, S + 5);
+    if (tid != 0) return;
+    if (f.fi.iter) {
+        const int it = *f.fi.iter;
+        // A factorisation of this training loop has failed (this iteration's, or an earlier one of any
+        // problem of the batch): the reference raises here (gpr.py:192), with u, the Adam state and the
+        // history as the previous iteration left them.  Freeze them; record how far the loop got.
+        if (*info != 0) {
+            atomicMin(info + 1, it);
+            return;
+        }
+        const int P = 2 + m.n_ls + (m.kernel == GPIMHIP_KERNEL_RQ ? 1 : 0);
+        st.lr_over_bc1 = f.fi.bc[it];
+        st.bc2_sqrt = f.fi.bc[f.fi.T + it];
+        loss_out = f.fi.loss_base ? f.fi.loss_base + it : nullptr;
+        hist_row = f.fi.hist_base ? f.fi.hist_base + (int64_t)it * P : nullptr;
+        *f.fi.iter = it + 1;
+    }
+    // working storage in LDS (arr is free again): gradient, the current theta (theta_next may be f.th itself), the next one
+    double* g = arr;
+    ThetaDev* told = reinterpret_cast<ThetaDev*>(arr + 16);
+    ThetaDev* tn = reinterpret_cast<ThetaDev*>(arr + 48);
+    *told = *f.th;
+    finalize_step_ws(m, N, S, S[7], S[8], *told, f.u, f.adam_m, f.adam_v, do_adam, st, loss_out, grad_out, hist_row,
+                     prior_constant(m), theta_next, g, *tn);
+}
+__device__ __forceinline__ FinProblem fin_problem(const gpimhip_model_t& m, int64_t b, int64_t np, int nb, int ntile,
+                                                  const double* grad_part, const double* z, const double* zb,
+                                                  const double* logdet_part, ThetaDev* th, double* u, double* adam_m,
+                                                  double* adam_v, FinalizeIter fi) {
+    const int P = 2 + m.n_ls + (m.kernel == GPIMHIP_KERNEL_RQ ? 1 : 0);
+    FinProblem f;
+    f.grad_part = grad_part + b * ntile * 8;
+    f.z = z + b * np;
+    f.zb = zb + b * np;
+    f.logdet_part = logdet_part + b * nb;
+    f.th = th + b;
+    f.u = u + b * P;
+    f.adam_m = adam_m + b * MAXP;
+    f.adam_v = adam_v + b * MAXP;
+    f.fi = fi;
+    if (fi.iter) {
+        f.fi.iter += b;
+        if (fi.hist_base) f.fi.hist_base += b * fi.T * P;
+        if (fi.loss_base) f.fi.loss_base += b * fi.T;
+    }
+    return f;
+}
+
+__global__ __launch_bounds__(256) void finalize_kernel(gpimhip_model_t m, int64_t N, int64_t np, int nb,
+                                                       int ntile, const double* __restrict__ grad_part,
+                                                       const double* __restrict__ z, const double* __restrict__ zb,
+                                                       const double* __restrict__ logdet_part,
+                                                       ThetaDev* __restrict__ th, double* __restrict__ u,
+                                                       double* __restrict__ adam_m, double* __restrict__ adam_v,
+                                                       int do_adam, AdamStep st, double* __restrict__ loss_out,
+                                                       double* __restrict__ grad_out,
+                                                       double* __restrict__ hist_row, FinalizeIter fi,
+                                                       int32_t* __restrict__ info) {
+    __shared__ double arr[5 * 256];
+    __shared__ double S[9];
+    const FinProblem f = fin_problem(m, blockIdx.y, np, nb, ntile, grad_part, z, zb, logdet_part, th, u, adam_m, adam_v, fi);
+    finalize_block<false>(m, N, np, nb, ntile, f, do_adam, st, loss_out, grad_out, hist_row, info, nullptr, arr, S);
+}
+
+// the finalize step as the tail of grad_reduce_kernel
+struct FinFused {
+    int enabled;
+    int do_adam;
+    int carry_theta;            // write the theta of the stepped parameters over the current one
+    int nb;
+    uint32_t* counter;          // per problem, 0 between launches
+    gpimhip_model_t m;
+    int64_t N;
+    const double* z; const double* zb; const double* logdet_part;
+    double* u; double* adam_m; double* adam_v;
+    AdamStep st;
+    double* loss_out; double* grad_out; double* hist_row;
+    FinalizeIter fi;
+    int32_t* info;
+};
+
+// ------------------------------------------------------------------------------------------
 // gradient reduction over the lower tiles of K^-1:
 //   w_ij = (2 - delta_ij) * (Kinv_ij - alpha_i alpha_j)
 //   S[0]      += w * k/s2                       -> d/d s2
@@ -478,22 +741,30 @@ int launch_axpy(gpimhip_ctx* h, double* x, const double* d, int64_t n) {
 //   S[5]      += delta_ij * (Kinv_ii - alpha_i^2) -> d/d noise
 //   S[6]      += w * s2 * dk/dalpha / s2        -> d/d alpha (RQ)
 // ------------------------------------------------------------------------------------------
+// alpha_part != nullptr: alpha is given as the row-chunk partial sums of gemv_t_tri_kernel (nR chunks of rc rows) and
+// every workgroup adds up the 256 entries it needs itself (no sum launch).  fin.enabled: the last workgroup of a problem to
+// finish runs the finalize step (FinFused).
 template <int KIND, typename R>
 __global__ __launch_bounds__(256) void grad_reduce_kernel(const R* __restrict__ Kinv, int64_t ld,
                                                           const double* __restrict__ X, int64_t N, int d,
                                                           const double* __restrict__ alpha,
-                                                          const ThetaDev* __restrict__ th,
+                                                          ThetaDev* __restrict__ th,
                                                           double* __restrict__ part, int64_t x_bs, int64_t np,
-                                                          const TileDesc* __restrict__ tiles) {
-    __shared__ double xa[128][5];
-    __shared__ double xz[128][5];
-    __shared__ double al_r[128], al_c[128];
-    __shared__ double red[4][8];
+                                                          const TileDesc* __restrict__ tiles,
+                                                          const double* __restrict__ alpha_part, int nR, int rc, FinFused fin) {
+    // one buffer, carved: the staging of the tile phase, then (last workgroup only) the reduction scratch of the finalize step
+    __shared__ double sh[2 * 128 * 5 + 2 * 128 + 4 * 8 + 16];
+    double (*xa)[5] = reinterpret_cast<double (*)[5]>(sh);
+    double (*xz)[5] = reinterpret_cast<double (*)[5]>(sh + 128 * 5);
+    double* al_r = sh + 2 * 128 * 5;
+    double* al_c = al_r + 128;
+    double (*red)[8] = reinterpret_cast<double (*)[8]>(al_c + 128);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double* part_all = part;
     Kinv += blockIdx.y * np * ld;
     X += blockIdx.y * x_bs;
-    alpha += blockIdx.y * np;
-    th += blockIdx.y;
+    if (alpha) alpha += blockIdx.y * np;
+    if (alpha_part) alpha_part += (int64_t)blockIdx.y * nR * np;
     part += (int64_t)blockIdx.y * gridDim.x * 8;
     // tiles == nullptr: workgroup q is lower tile q of a full np x np matrix.  Otherwise (distributed layouts:
     // a rank holds some block columns side by side) tile (ci, cj) of the matrix lives at block column kb0 of Kinv.
@@ -506,7 +777,7 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const R* __restrict__ 
         lower_tile_from_linear(blockIdx.x, ci, cj);
         ccol = (int64_t)cj * 128;
     }
-    const ThetaDev t = *th;
+    const ThetaDev t = th[blockIdx.y];
     {
         const bool isrow = tid < 128;
         const int loc = tid & 127;
@@ -520,7 +791,9 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const R* __restrict__ 
             s2 += a * a;
         }
         dst[loc][4] = s2;
-        (isrow ? al_r : al_c)[loc] = (g < N) ? alpha[g] : 0.0;
+        double av = 0.0;
+        if (g < N) av = alpha_part ? gemv_tri_alpha(alpha_part, nR, rc, np, g) : alpha[g];
+        (isrow ? al_r : al_c)[loc] = av;
     }
     __syncthreads();
     double S[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -567,22 +840,55 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const R* __restrict__ 
     if (tid < 8) {
         double v = 0.0;
         if (tid < 7) v = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
-        part[(int64_t)blockIdx.x * 8 + tid] = v;
+        // fused finalize: a device-scope (write-through) store -- the reader may sit on another XCD, whose L2 is not
+        // coherent with this one.  A release FENCE here instead (__threadfence: write back + invalidate the whole L2, once
+        // per workgroup) was measured at 1.87 ms for this launch at N = 16384 (0.40 without).
+        if (fin.enabled) __hip_atomic_store(part + (int64_t)blockIdx.x * 8 + tid, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else part[(int64_t)blockIdx.x * 8 + tid] = v;
     }
+    if (!fin.enabled) return;
+    // ---- the last workgroup of this problem runs the finalize step (loss, gradient, Adam, next theta)
+    int* flag = reinterpret_cast<int*>(sh + 2 * 128 * 5 + 2 * 128 + 4 * 8);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       // s_waitcnt: this workgroup's partial sums have been written ...
+    __syncthreads();
+    if (tid == 0) {
+        // ... before it counts as finished (one counter per problem; a two-level count -- groups of 32 workgroups -- measured the
+        // same at 8256 workgroups: the adds are spread over the launch)
+        const unsigned int done = atomicAdd(fin.counter + blockIdx.y, 1u);
+        *flag = (done == gridDim.x - 1);
+        if (*flag) fin.counter[blockIdx.y] = 0;        // ready for the next launch (every other workgroup has passed)
+    }
+    __syncthreads();
+    if (!*flag) return;
+    // (the other workgroups' partial sums are read with device-scope loads: finalize_block<true>)
+    const int ntile = (int)gridDim.x;
+    const FinProblem f = fin_problem(fin.m, blockIdx.y, np, fin.nb, ntile, part_all, fin.z, fin.zb, fin.logdet_part, th, fin.u,
+                                     fin.adam_m, fin.adam_v, fin.fi);
+    // (sh: 1584 doubles; the reduction scratch takes the first 1280, the nine sums sit behind the flag)
+    finalize_block<true>(fin.m, fin.N, np, fin.nb, ntile, f, fin.do_adam, fin.st, fin.loss_out, fin.grad_out, fin.hist_row,
+                         fin.info, fin.carry_theta ? th + blockIdx.y : nullptr, sh, sh + 2 * 128 * 5 + 2 * 128 + 4 * 8 + 2);
 }
 
-int launch_grad_reduce(gpimhip_ctx* h, const gpimhip_model_t* m, const double* Kinv, int64_t ld,
-                       const double* X, int64_t N, int nb, const double* alpha, int64_t x_bs) {
+// alpha_part: nullptr (alpha is a vector) or the row-chunk partial sums of launch_gemv_t_tri.  fin: nullptr, or the finalize
+// step to run in the launch's last workgroup (launch_grad_reduce_fin).
+static int launch_grad_reduce_impl(gpimhip_ctx* h, const gpimhip_model_t* m, const double* Kinv, int64_t ld,
+                                   const double* X, int64_t N, int nb, const double* alpha, int64_t x_bs,
+                                   const double* alpha_part, const FinFused* fin) {
     const int ntile = nb * (nb + 1) / 2;
+    const int64_t np = (int64_t)nb * NB;
     dim3 grid(ntile, h->nbatch), block(256);
+    FinFused ff;
+    memset(&ff, 0, sizeof(ff));
+    if (fin) ff = *fin;
+    const int nR = alpha_part ? gemv_tri_chunks(np) : 0, rc = alpha_part ? gemv_tri_rc(np) : 0;
 #define GR_LAUNCH(KIND)                                                                                   \
     do {                                                                                                  \
         if (h->fp32)                                                                                      \
             hipLaunchKernelGGL((grad_reduce_kernel<KIND, float>), grid, block, 0, h->stream, reinterpret_cast<const float*>(Kinv), \
-                               ld, X, N, m->dim, alpha, h->theta, h->grad_part, x_bs, (int64_t)nb * NB, (const TileDesc*)nullptr);  \
+                               ld, X, N, m->dim, alpha, h->theta, h->grad_part, x_bs, np, (const TileDesc*)nullptr, alpha_part, nR, rc, ff);  \
         else                                                                                              \
             hipLaunchKernelGGL((grad_reduce_kernel<KIND, double>), grid, block, 0, h->stream, Kinv, ld, X, N, m->dim, alpha, \
-                               h->theta, h->grad_part, x_bs, (int64_t)nb * NB, (const TileDesc*)nullptr);  \
+                               h->theta, h->grad_part, x_bs, np, (const TileDesc*)nullptr, alpha_part, nR, rc, ff);  \
     } while (0)
     switch (m->kernel) {
         case GPIMHIP_KERNEL_RBF: GR_LAUNCH(GPIMHIP_KERNEL_RBF); break;
@@ -594,97 +900,35 @@ int launch_grad_reduce(gpimhip_ctx* h, const gpimhip_model_t* m, const double* K
     HIP_TRY(hipGetLastError());
     return GPIMHIP_OK;
 }
-
-// ------------------------------------------------------------------------------------------
-// finalize: one workgroup.  Sums the partials in a fixed tree, forms loss and d loss/du, then
-// (fit mode) applies one torch.optim.Adam step to u and records the constrained values.
-// ------------------------------------------------------------------------------------------
-__device__ double block_sum_256(double v, double* red) {
-    const int tid = threadIdx.x;
-    red[tid] = v;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (tid < s) red[tid] += red[tid + s];
-        __syncthreads();
-    }
-    const double r = red[0];
-    __syncthreads();
-    return r;
+int launch_grad_reduce(gpimhip_ctx* h, const gpimhip_model_t* m, const double* Kinv, int64_t ld,
+                       const double* X, int64_t N, int nb, const double* alpha, int64_t x_bs) {
+    return launch_grad_reduce_impl(h, m, Kinv, ld, X, N, nb, alpha, x_bs, nullptr, nullptr);
 }
-
-// Iteration-indexed form: when `iter` is given the Adam bias corrections, the history row and the
-// loss slot are looked up by the device-resident iteration counter, which this kernel advances.  All
-// T iterations then enqueue byte-identical launches, i.e. one captured hipGraph can be replayed.
-struct FinalizeIter {
-    int32_t* iter;              // device counter (null: use the by-value arguments below)
-    const double* bc;           // [2*T]: lr/(1-beta1^t) then sqrt(1-beta2^t)
-    int32_t T;
-    double* hist_base;          // T x P or null
-    double* loss_base;          // T or null
-};
-
-__global__ __launch_bounds__(256) void finalize_kernel(gpimhip_model_t m, int64_t N, int64_t np, int nb,
-                                                       int ntile, const double* __restrict__ grad_part,
-                                                       const double* __restrict__ z, const double* __restrict__ zb,
-                                                       const double* __restrict__ logdet_part,
-                                                       const ThetaDev* __restrict__ th, double* __restrict__ u,
-                                                       double* __restrict__ adam_m, double* __restrict__ adam_v,
-                                                       int do_adam, AdamStep st, double* __restrict__ loss_out,
-                                                       double* __restrict__ grad_out,
-                                                       double* __restrict__ hist_row, FinalizeIter fi,
-                                                       int32_t* __restrict__ info) {
-    __shared__ double red[256];
-    __shared__ double S[8];
-    const int tid = threadIdx.x;
-    {
-        const int64_t b = blockIdx.y;
-        const int P = 2 + m.n_ls + (m.kernel == GPIMHIP_KERNEL_RQ ? 1 : 0);
-        grad_part += b * ntile * 8;
-        z += b * np;
-        zb += b * np;
-        logdet_part += b * nb;
-        th += b;
-        u += b * P;
-        adam_m += b * MAXP;
-        adam_v += b * MAXP;
-        if (fi.iter) {
-            fi.iter += b;
-            if (fi.hist_base) fi.hist_base += b * fi.T * P;
-            if (fi.loss_base) fi.loss_base += b * fi.T;
-        }
-    }
-    for (int k = 0; k < 7; ++k) {
-        double v = 0.0;
-        for (int q = tid; q < ntile; q += 256) v += grad_part[(int64_t)q * 8 + k];
-        v = block_sum_256(v, red);
-        if (tid == 0) S[k] = v;
-    }
-    double q2 = 0.0;
-    for (int64_t i = tid; i < np; i += 256) q2 = fma(z[i], zb[i], q2);     // |L^-1 y|^2, or y^T alpha (refined, fp32 matrices)
-    q2 = block_sum_256(q2, red);
-    double lg = 0.0;
-    for (int k = tid; k < nb; k += 256) lg += logdet_part[k];
-    lg = block_sum_256(lg, red);
-    if (tid != 0) return;
-
-    if (fi.iter) {
-        const int it = *fi.iter;
-        // A factorisation of this training loop has failed (this iteration's, or an earlier one of any
-        // problem of the batch): the reference raises here (gpr.py:192), with u, the Adam state and the
-        // history as the previous iteration left them.  Freeze them; record how far the loop got.
-        if (*info != 0) {
-            atomicMin(info + 1, it);
-            return;
-        }
-        const int P = 2 + m.n_ls + (m.kernel == GPIMHIP_KERNEL_RQ ? 1 : 0);
-        st.lr_over_bc1 = fi.bc[it];
-        st.bc2_sqrt = fi.bc[fi.T + it];
-        loss_out = fi.loss_base ? fi.loss_base + it : nullptr;
-        hist_row = fi.hist_base ? fi.hist_base + (int64_t)it * P : nullptr;
-        *fi.iter = it + 1;
-    }
-    finalize_step(m, N, S, q2, lg, *th, u, adam_m, adam_v, do_adam, st, loss_out, grad_out, hist_row,
-                  prior_constant(m));
+// The gradient contraction AND the finalize step (loss, gradient, Adam step, history row, next theta) in one launch: the
+// arguments of launch_finalize, run by the last workgroup of every problem.  alpha_part: see launch_grad_reduce_impl.
+// carry_theta: the theta of the stepped parameters replaces h->theta (the next iteration skips its theta launch).
+int launch_grad_reduce_fin(gpimhip_ctx* h, const gpimhip_model_t* m, const double* Kinv, int64_t ld, const double* X,
+                           int64_t N, int nb, const double* alpha, int64_t x_bs, const double* alpha_part, double* u,
+                           int do_adam, AdamStep st, double* loss_out, double* grad_out, double* hist_row, int32_t* iter,
+                           const double* bc, int T, double* hist_base, double* loss_base, int carry_theta) {
+    FinFused ff;
+    memset(&ff, 0, sizeof(ff));
+    ff.enabled = 1;
+    ff.do_adam = do_adam;
+    ff.carry_theta = carry_theta;
+    ff.nb = nb;
+    ff.counter = h->fin_counter;
+    ff.m = *m;
+    ff.N = N;
+    ff.z = h->fp32 ? h->ypad : h->z;
+    ff.zb = h->fp32 ? h->alpha : h->z;
+    ff.logdet_part = h->logdet_part;
+    ff.u = u; ff.adam_m = h->adam_m; ff.adam_v = h->adam_v;
+    ff.st = st;
+    ff.loss_out = loss_out; ff.grad_out = grad_out; ff.hist_row = hist_row;
+    ff.fi = FinalizeIter{iter, bc, T, hist_base, loss_base};
+    ff.info = h->info;
+    return launch_grad_reduce_impl(h, m, Kinv, ld, X, N, nb, alpha, x_bs, alpha_part, &ff);
 }
 
 int launch_finalize(gpimhip_ctx* h, const gpimhip_model_t* m, int64_t N, int64_t np, double* u, int do_adam,
@@ -875,18 +1119,20 @@ int launch_topk(gpimhip_ctx* h, const double* x, int64_t M, int k, int keep_nan,
 int launch_grad_reduce_tiles(gpimhip_ctx* h, const gpimhip_model_t* m, const double* Kinv, int64_t ld, const double* X,
                              int64_t N, int64_t np, const double* alpha, const TileDesc* tiles, int ntile, double* part) {
     dim3 grid(ntile, 1), block(256);
+    FinFused ff0;
+    memset(&ff0, 0, sizeof(ff0));
     switch (m->kernel) {
         case GPIMHIP_KERNEL_RBF:
             hipLaunchKernelGGL((grad_reduce_kernel<GPIMHIP_KERNEL_RBF, double>), grid, block, 0, h->stream, Kinv, ld, X, N, m->dim,
-                               alpha, h->theta, part, (int64_t)0, np, tiles);
+                               alpha, h->theta, part, (int64_t)0, np, tiles, (const double*)nullptr, 0, 0, ff0);
             break;
         case GPIMHIP_KERNEL_MATERN52:
             hipLaunchKernelGGL((grad_reduce_kernel<GPIMHIP_KERNEL_MATERN52, double>), grid, block, 0, h->stream, Kinv, ld, X, N,
-                               m->dim, alpha, h->theta, part, (int64_t)0, np, tiles);
+                               m->dim, alpha, h->theta, part, (int64_t)0, np, tiles, (const double*)nullptr, 0, 0, ff0);
             break;
         case GPIMHIP_KERNEL_RQ:
             hipLaunchKernelGGL((grad_reduce_kernel<GPIMHIP_KERNEL_RQ, double>), grid, block, 0, h->stream, Kinv, ld, X, N, m->dim,
-                               alpha, h->theta, part, (int64_t)0, np, tiles);
+                               alpha, h->theta, part, (int64_t)0, np, tiles, (const double*)nullptr, 0, 0, ff0);
             break;
         default: gpim_set_error("unknown kernel kind"); return GPIMHIP_E_BADARG;
     }

@@ -23,9 +23,17 @@
 #ifndef FI_BURST
 #define FI_BURST 8
 #endif
+// tools only (FI_ROLE_VARIANTS): the schedules of tools/r6_role_variants.hpp, measured in round 6 and not kept
+#ifdef FI_ROLE_VARIANTS
+#include "../../tools/r6_role_variants.hpp"
+#endif
+#ifndef FI_LOOKAHEAD
+#define FI_LOOKAHEAD 0
+#endif
 #define POTF2_SMEM_DOUBLES (LayTri::DOUBLES + NB + 32 * XS_LD + 4)
 typedef LayTri PL;
-template <typename R>
+// LA (tools only): the look-ahead schedule of tools/r6_role_variants.hpp
+template <typename R, bool LA = false>
 __device__ __forceinline__ void potf2_body(double* __restrict__ smem, const int by, R* __restrict__ A, int64_t ld, int kblk,
                                            R* __restrict__ dinv_all, double* __restrict__ dinvB_all,
                                            double* __restrict__ logdet_out, int32_t* __restrict__ info, int nb PROF_ARG,
@@ -35,6 +43,9 @@ __device__ __forceinline__ void potf2_body(double* __restrict__ smem, const int 
     double* Xs = invd + NB;
     double* red = Xs + 32 * XS_LD;
     int& s_bad = *reinterpret_cast<int*>(red + 2);
+#ifdef FI_ROLE_VARIANTS
+    int* fi_flags = reinterpret_cast<int*>(red + 2) + 1;        // three ints: the flags of lds_factor_inv_la
+#endif
     A += (int64_t)by * nb * NB * ld;
     dinv_all += (int64_t)by * nb * NB * NB;
     logdet_out += (int64_t)by * nb;
@@ -42,6 +53,9 @@ __device__ __forceinline__ void potf2_body(double* __restrict__ smem, const int 
     typedef R RV2 __attribute__((ext_vector_type(2)));
     R* Ablk = A + ((int64_t)kblk * NB) * ld + (int64_t)kblk * NB;
     if (tid == 0) s_bad = 0;
+#ifdef FI_ROLE_VARIANTS
+    if (tid < 3) fi_flags[tid] = 0;
+#endif
     __syncthreads();
     STAMP(0);
     load_block_chol0(D, invd, &s_bad, Ablk, ld, tid, Xs);
@@ -122,6 +136,10 @@ __device__ __forceinline__ void potf2_body(double* __restrict__ smem, const int 
         }
     };
     const Sink sink{Ablk, ld, D, invd};
+#ifdef FI_ROLE_VARIANTS
+    if (LA) lds_factor_inv_la<Sink>(D, invd, Xs, &s_bad, fi_flags, tid, sink);
+    else
+#endif
     lds_factor_inv<Sink, true, PL>(D, invd, Xs, 8, &s_bad, tid, sink);
     STAMP(2);
     // log-determinant partial (fixed order) from the reciprocal pivots

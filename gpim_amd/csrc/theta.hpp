@@ -51,13 +51,16 @@ __device__ inline double prior_constant(const gpimhip_model_t& m) {
     return prior;
 }
 
-__device__ inline void finalize_step(const gpimhip_model_t& m, int64_t N, const double* S, double q2, double lg,
-                                     const ThetaDev& t, double* u, double* adam_m, double* adam_v, int do_adam,
-                                     const AdamStep& st, double* loss_out, double* grad_out, double* hist_row,
-                                     double prior) {
+// g (MAXP doubles) and tn: working storage -- private arrays in finalize_step, LDS where the step is the tail of a kernel
+// whose other waves must not pay for scratch memory (grad_reduce_kernel).
+// theta_next (optional): theta of the STEPPED parameters -- what the next iteration's theta launch would compute from u
+// (the same theta_from_u); `t` must not alias it.
+__device__ __forceinline__ void finalize_step_ws(const gpimhip_model_t& m, int64_t N, const double* S, double q2, double lg,
+                                                 const ThetaDev& t, double* u, double* adam_m, double* adam_v, int do_adam,
+                                                 const AdamStep& st, double* loss_out, double* grad_out, double* hist_row,
+                                                 double prior, ThetaDev* theta_next, double* g, ThetaDev& tn) {
     const int P = 2 + m.n_ls + (m.kernel == GPIMHIP_KERNEL_RQ ? 1 : 0);
     const double loss = 0.5 * q2 + lg + 0.5 * (double)N * 1.8378770664093453 + prior;
-    double g[MAXP];
     g[0] = 0.5 * S[0] * t.dvar_du;
     if (m.n_ls == 1) {
         double s = 0.0;
@@ -81,15 +84,25 @@ __device__ inline void finalize_step(const gpimhip_model_t& m, int64_t N, const 
             adam_m[k] = mm;
             adam_v[k] = vv;
         }
-        if (hist_row) {
-            ThetaDev tn;
+        if (hist_row || theta_next) {
             theta_from_u(m, u, tn);
-            hist_row[0] = tn.var;
-            for (int k = 0; k < m.n_ls; ++k) hist_row[1 + k] = tn.ls[k];
-            hist_row[1 + m.n_ls] = tn.noise;
-            if (m.kernel == GPIMHIP_KERNEL_RQ) hist_row[2 + m.n_ls] = tn.alpha;
+            if (hist_row) {
+                hist_row[0] = tn.var;
+                for (int k = 0; k < m.n_ls; ++k) hist_row[1 + k] = tn.ls[k];
+                hist_row[1 + m.n_ls] = tn.noise;
+                if (m.kernel == GPIMHIP_KERNEL_RQ) hist_row[2 + m.n_ls] = tn.alpha;
+            }
+            if (theta_next) *theta_next = tn;
         }
     }
+}
+__device__ inline void finalize_step(const gpimhip_model_t& m, int64_t N, const double* S, double q2, double lg,
+                                     const ThetaDev& t, double* u, double* adam_m, double* adam_v, int do_adam,
+                                     const AdamStep& st, double* loss_out, double* grad_out, double* hist_row,
+                                     double prior, ThetaDev* theta_next = nullptr) {
+    double g[MAXP];
+    ThetaDev tn;
+    finalize_step_ws(m, N, S, q2, lg, t, u, adam_m, adam_v, do_adam, st, loss_out, grad_out, hist_row, prior, theta_next, g, tn);
 }
 
 // Lane-parallel form of finalize_step for the fused small-N trainer: lane p of one wave owns

@@ -408,3 +408,37 @@ def test_graph_replay_equals_eager_launches(gpim, monkeypatch):
     assert np.isfinite(a[0]).all() and np.isfinite(a[1]).all()
     for x, y_ in zip(a, b):
         assert np.array_equal(x, y_)
+
+
+@pytest.mark.parametrize("n,T,kernel,prec", [(300, 40, "RBF", "double"), (700, 12, "Matern52", "double"),
+                                             (2100, 8, "RationalQuadratic", "double"), (8300, 3, "Matern52", "double"),
+                                             (700, 8, "RBF", "single")])
+def test_fused_finalize_equals_two_launches(gpim, monkeypatch, n, T, kernel, prec):
+    """Round 6: the finalize step (loss, chain rule, Adam step, history row, the NEXT iteration's theta) runs in the last
+    workgroup of the gradient-contraction launch, alpha reaches that launch as the row-chunk partial sums of the triangular
+    mat-vec (np <= 8192), and no theta launch remains inside the loop -- against the separate launches of rounds 1-5
+    (GPIMHIP_NO_FUSED_FINALIZE=1): the same reductions in the same order, hence the same bits in the hyper-parameter history,
+    the loss history and the posterior; sizes on both sides of the graph-replay / eager switch and of the partial-sums
+    switch; a second run must repeat the first (the partial sums cross XCDs through device-scope stores and loads: a stale
+    read would show here)."""
+    side = int(np.ceil(np.sqrt(n * 4)))
+    rng = np.random.default_rng(n)
+    ii, jj = np.meshgrid(np.arange(side), np.arange(side), indexing="ij")
+    R = np.sin(ii / 7.0) * np.cos(jj / 5.0) + 0.05 * rng.standard_normal((side, side))
+    R.ravel()[rng.permutation(side * side)[n:]] = np.nan            # exactly n observations
+    X, Xf = gpim.utils.get_sparse_grid(R), gpim.utils.get_full_grid(R)
+    kw = dict(kernel=kernel, lengthscale=[[1., 1.], [20., 20.]], learning_rate=0.1, iterations=T, verbose=0, precision=prec)
+    outs = []
+    for knob in (None, None, "1"):
+        if knob:
+            monkeypatch.setenv("GPIMHIP_NO_FUSED_FINALIZE", knob)
+        else:
+            monkeypatch.delenv("GPIMHIP_NO_FUSED_FINALIZE", raising=False)
+        rec = gpim.reconstructor(X, R, Xf, **kw)
+        mean, sd, hyper = rec.run()
+        outs.append((mean, sd, np.asarray(hyper["lengthscale"]), np.asarray(hyper["noise"]), np.asarray(hyper["variance"]),
+                     np.asarray(rec.loss_all)))
+    assert int(np.isfinite(R).sum()) == n and np.isfinite(outs[0][0]).all()
+    for a, b in ((outs[0], outs[1]), (outs[0], outs[2])):
+        for x, y_ in zip(a, b):
+            assert np.array_equal(x, y_)

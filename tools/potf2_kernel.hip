@@ -26,9 +26,9 @@ __global__ __launch_bounds__(NTH, POTF2_WAVES_PER_EU) void potf2_kernel(R* __res
                                                        int32_t* __restrict__ info, int nb PROF_ARG) {
     __shared__ __attribute__((aligned(16))) double smem[POTF2_SMEM_DOUBLES];
 #ifdef POTF2_PROFILE
-    potf2_body<R>(smem, (int)blockIdx.y, A, ld, kblk, dinv_all, nullptr, logdet_out, info, nb, prof);
+    potf2_body<R, FI_LOOKAHEAD != 0>(smem, (int)blockIdx.y, A, ld, kblk, dinv_all, nullptr, logdet_out, info, nb, prof);
 #else
-    potf2_body<R>(smem, (int)blockIdx.y, A, ld, kblk, dinv_all, nullptr, logdet_out, info, nb);
+    potf2_body<R, FI_LOOKAHEAD != 0>(smem, (int)blockIdx.y, A, ld, kblk, dinv_all, nullptr, logdet_out, info, nb);
 #endif
 }
 

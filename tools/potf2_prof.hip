@@ -2,6 +2,7 @@
 #define POTF2_PROFILE
 #include "potf2_kernel.hip"
 #include <stdio.h>
+#include <string.h>
 #include <vector>
 void gpim_set_error(const std::string&) {}
 int main() {
@@ -23,6 +24,27 @@ int main() {
         printf("rep %d: %.1f us total; cycles: load %lld | factor %lld | write L + logdet %lld | inverse %lld | write inverse %lld | all %lld\n",
                rep, ms * 1e3, hp[1] - hp[0], hp[2] - hp[1], hp[3] - hp[2], hp[4] - hp[3], hp[5] - hp[4], hp[5] - hp[0]);
     }
+#if FI_LOOKAHEAD
+    {
+        long long wp[256], fp[128];
+        hipMemcpyFromSymbol(wp, HIP_SYMBOL(g_wprof), sizeof(wp));
+        hipMemcpyFromSymbol(fp, HIP_SYMBOL(g_fprof), sizeof(fp));
+        printf("look-ahead schedule (lds_factor_inv_la): wave 0 per iteration q: [chol16_lp(q) | wait flag_u | solve (q+1,q) | update (q+1,q+1)], iteration total = start of q+1 - start of q\n");
+        for (int q = 0; q < 8; ++q)
+            printf("  q %d: %5lld | %5lld | %5lld | %5lld   (iteration %lld)\n", q, fp[8 * q + 1] - fp[8 * q], q < 7 ? fp[8 * q + 2] - fp[8 * q + 1] : 0,
+                   q < 7 ? fp[8 * q + 3] - fp[8 * q + 2] : 0, q < 7 ? fp[8 * q + 4] - fp[8 * q + 3] : 0, q < 7 ? fp[8 * q + 8] - fp[8 * q] : 0);
+        printf("every wave, cycles since wave 0 left the iteration's barrier: [wave 4: export done | trailing done | inverse row done | solves done]\n");
+        for (int q = 0; q < 7; ++q) {
+            printf("  q %d:", q);
+            for (int w = 1; w < 8; ++w) {
+                const long long t0 = fp[8 * q];
+                if (w == 4) printf("  w4 %5lld |", wp[(w * 8 + q) * 4] - t0);
+                else printf("  w%d %5lld %5lld %5lld |", w, wp[(w * 8 + q) * 4 + 2] - t0, wp[(w * 8 + q) * 4 + 1] - t0, wp[(w * 8 + q) * 4 + 3] - t0);
+            }
+            printf("\n");
+        }
+    }
+#else
     {
         long long fp[128];
         hipMemcpyFromSymbol(fp, HIP_SYMBOL(g_fprof), sizeof(fp));
@@ -45,6 +67,7 @@ int main() {
             printf("\n");
         }
     }
+#endif
     std::vector<double> L(n * n);
     hipMemcpy(L.data(), dA, n * n * 8, hipMemcpyDeviceToHost);
     // residual check L L^T - A
@@ -56,5 +79,13 @@ int main() {
     double e2 = 0;
     for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) { double s2 = 0; for (int k = 0; k < n; ++k) s2 += L[i * n + k] * Xi[k * n + j]; e2 = fmax(e2, fabs(s2 - (i == j))); }
     printf("max |L Linv - I| = %.3e\n", e2);
+    {   // bit pattern of the two outputs (to compare schedules: the same operations in the same order give the same hash)
+        unsigned long long hL = 1469598103934665603ull, hX = hL;
+        for (int i = 0; i < n; ++i) for (int j = 0; j <= i; ++j) {
+            unsigned long long b; memcpy(&b, &L[i * n + j], 8); hL = (hL ^ b) * 1099511628211ull;
+            memcpy(&b, &Xi[i * n + j], 8); hX = (hX ^ b) * 1099511628211ull;
+        }
+        printf("hash L %016llx  hash Linv %016llx\n", hL, hX);
+    }
     return 0;
 }
