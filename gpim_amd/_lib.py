@@ -100,6 +100,8 @@ _PROTOS = {
                                               ctypes.c_int64, ctypes.c_int64, c_dp, ctypes.c_int64]),
     "gpimhip_dist_kinv_update": (ctypes.c_int, [ctypes.c_void_p, c_dp, ctypes.c_int64, ctypes.c_int32, c_dp,
                                                 ctypes.c_int64, c_dp, ctypes.c_int64]),
+    "gpimhip_dist_kinv_update_n": (ctypes.c_int, [ctypes.c_void_p, c_dp, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, c_dp,
+                                                  ctypes.c_int64, c_dp, ctypes.c_int64]),
     "gpimhip_dist_grad_sums": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ModelStruct), c_dp, ctypes.c_int64, c_dp,
                                               c_dp, ctypes.c_int64, c_dp, c_dp]),
     "gpimhip_dist_finalize": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ModelStruct), ctypes.c_int64, c_dp, c_dp,

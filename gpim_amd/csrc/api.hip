@@ -1396,24 +1396,31 @@ int gpimhip_dist_kmat_cols(gpimhip_handle h, const gpimhip_model_t* m, const dou
     return launch_add_diag_theta(h, out, ld, col0, M, std::min(ncols_pad, h->np - col0));
 }
 
-int gpimhip_dist_kinv_update(gpimhip_handle h, const double* xbuf, int64_t ldx, int32_t panel_glob_blk0,
-                             const double* Xloc, int64_t ldloc, double* Kinv, int64_t ldk) {
+int gpimhip_dist_kinv_update_n(gpimhip_handle h, const double* xbuf, int64_t ldx, int32_t panel_glob_blk0, int32_t npanels,
+                               const double* Xloc, int64_t ldloc, double* Kinv, int64_t ldk) {
     FP64_ONLY(h);
     if (!h || !xbuf || !Xloc || !Kinv || !dist_plan_ok(h) || panel_glob_blk0 < 0 || panel_glob_blk0 % OUTER_W ||
-        panel_glob_blk0 >= h->dplan.nb)
+        panel_glob_blk0 >= h->dplan.nb || npanels < 1)
         return GPIMHIP_E_BADARG;
     HIP_TRY(hipSetDevice(h->device));
     h->nbatch = 1;
     const DistPlan& D = h->dplan;
-    const PlanRange r = D.kinv_panel[panel_glob_blk0 / OUTER_W];
+    const int p0 = panel_glob_blk0 / OUTER_W, p1 = std::min<int>(p0 + npanels, (int)D.kinv_panel.size());
+    // the tile lists of consecutive panels are adjacent in the plan (dist_plan_build): one launch for all of them
+    PlanRange r = D.kinv_panel[p0];
+    for (int p = p0 + 1; p < p1; ++p) r.n += D.kinv_panel[p].n;
     if (!r.n) return GPIMHIP_OK;
-    // K^-1[ci, cj] = sum_{kb >= ci} X[kb, ci]^T X[kb, cj]: A = the broadcast column panel of X (block column
+    // K^-1[ci, cj] = sum_{kb >= ci} X[kb, ci]^T X[kb, cj]: A = the broadcast column panels of X side by side (block column
     // ci - panel_glob_blk0 of xbuf), B = the owned columns
     GemmArgs g = gemm_args(xbuf, ldx, Xloc, ldloc, Kinv, ldk, 1.0, 0.0, D.d_tiles + r.off, r.n, h->np);
     g.a_coff = -panel_glob_blk0;
     g.krev = 1;
     g.chunk = 64;
     return launch_gemm(h, true, true, EPI_STORE, g);
+}
+int gpimhip_dist_kinv_update(gpimhip_handle h, const double* xbuf, int64_t ldx, int32_t panel_glob_blk0,
+                             const double* Xloc, int64_t ldloc, double* Kinv, int64_t ldk) {
+    return gpimhip_dist_kinv_update_n(h, xbuf, ldx, panel_glob_blk0, 1, Xloc, ldloc, Kinv, ldk);
 }
 
 int gpimhip_dist_grad_sums(gpimhip_handle h, const gpimhip_model_t* m, const double* X, int64_t N, const double* u,

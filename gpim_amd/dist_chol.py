@@ -48,6 +48,7 @@ import torch.distributed as dist
 NB = 128
 PANEL = 4            # 128-blocks per panel (OUTER_W of csrc/api.hip)
 PW = NB * PANEL
+KINV_GROUP = int(os.environ.get("GPIM_DIST_KINV_GROUP", "8"))      # panels per launch of the K^-1 pass (1: one at a time)
 
 
 def _force_collectives():
@@ -102,6 +103,8 @@ class HipTileEngine:
     """The product engine: hand-written HIP behind the C ABI (include/gpimhip.h, gpimhip_dist_*).  Two library
     handles: one on the caller's (main) stream for the updates and solves, one on a high-priority side stream
     for the panel chain, so that factoring panel p+1 overlaps the rest of round p's updates."""
+
+    grouped_kinv = True          # kinv_update takes several panels side by side (DistributedCholesky.kinv)
 
     def __init__(self, layout, handle=None):
         from . import _lib
@@ -189,12 +192,14 @@ class HipTileEngine:
                                                        self._lib.ptr(B), B.stride(0), B.shape[1], self._lib.ptr(Wt2),
                                                        Wt2.stride(0), self._lib.ptr(q), col_tiles, int(second)))
 
-    def kinv_update(self, xbuf, c, Xloc, Kinv):
+    def kinv_update(self, xbuf, c, Xloc, Kinv, npanels=1):
+        """Rows of the panels c ... c + npanels - 1 of K^-1 = X^T X (xbuf: those block columns of X side by side) against the
+        owned columns: one launch."""
         self._inject(False)
         lib = self.H.lib
-        self._lib.check(lib.gpimhip_dist_kinv_update(self.H.h, self._lib.ptr(xbuf), xbuf.stride(0), c * PANEL,
-                                                     self._lib.ptr(Xloc), Xloc.stride(0), self._lib.ptr(Kinv),
-                                                     Kinv.stride(0)))
+        self._lib.check(lib.gpimhip_dist_kinv_update_n(self.H.h, self._lib.ptr(xbuf), xbuf.stride(0), c * PANEL, int(npanels),
+                                                       self._lib.ptr(Xloc), Xloc.stride(0), self._lib.ptr(Kinv),
+                                                       Kinv.stride(0)))
 
     # ---- O(N^2) vector solves on the owner of a panel: the side handle factored it and holds its diagonal-block inverses
     def vec_forward(self, Aloc, p, y_p, t, piece, acc):
@@ -242,6 +247,7 @@ class DistributedCholesky:
         self._panel = [self.engine.empty(self.layout.np + NB, PW) for _ in range(2)]
         self._X = self._Wt = None                      # workspaces of ``inverse``
         self._wide = None                              # two panels side by side (``_stream_pairs``), two such buffers
+        self._group = None                             # KINV_GROUP panels side by side (``_stream_groups``), two such buffers
         self._factored = False                         # ``local`` holds a factor (set by factor(), cleared by kinv(out=local))
         self._coll = self.layout.world > 1 or (_force_collectives() and dist.is_available() and dist.is_initialized())
 
@@ -452,6 +458,20 @@ class DistributedCholesky:
             wide[p * PW:, second * PW:(second + 1) * PW].copy_(buf[p * PW:])
             yield p, wide, second
 
+    def _stream_groups(self, fill_of, G):
+        """Yields (p0, wide, count): the panels in order, G at a time side by side in one buffer of G * 512 columns (two such
+        buffers take turns), copied from their broadcast buffers as they arrive -- the next panel's broadcast is in flight
+        meanwhile, as in ``_stream``.  The last group may be shorter."""
+        L = self.layout
+        if self._group is None or self._group[0].shape[1] != G * PW:
+            self._group = [self.engine.empty(L.np + NB, G * PW) for _ in range(2)]
+        for p, buf in self._stream(fill_of):
+            g, slot = p // G, p % G
+            wide = self._group[g & 1]
+            wide[p * PW:, slot * PW:(slot + 1) * PW].copy_(buf[p * PW:])
+            if slot == G - 1 or p == L.npanel - 1:
+                yield g * G, wide, slot + 1
+
     def _stream_factor_pairs(self):
         self._need_factor("_stream_factor_pairs")
         return self._stream_pairs(lambda p: (lambda buf: self.engine.pack(self.local, p, buf)))
@@ -506,8 +526,16 @@ class DistributedCholesky:
                 l0, r0 = L.local_col0(c), c * PW
                 buf[r0:L.np, :L.width(c)].copy_(Xl[r0:, l0:l0 + L.width(c)])
             return fill
-        for c, buf in self._stream(fill_of):
-            eng.kinv_update(buf, c, Xl, Kl)
+        # Several panels per launch (round 6): the first panels have few tiles -- 16 c of them for panel c on one GPU, an
+        # eighth of that on eight -- each as deep as the whole matrix, and one panel at a time they leave most of the chip idle
+        # (the pass ran at 57 TFLOP/s at N = 65536 where the single-GPU K^-1 launch reaches 68)
+        G = KINV_GROUP if hasattr(eng, "kinv_update") and getattr(eng, "grouped_kinv", False) else 1
+        if G > 1:
+            for c0, wide, cnt in self._stream_groups(fill_of, G):
+                eng.kinv_update(wide, c0, Xl, Kl, cnt)
+        else:
+            for c, buf in self._stream(fill_of):
+                eng.kinv_update(buf, c, Xl, Kl)
         return Kl
 
     def nll(self, y):

@@ -349,6 +349,11 @@ int gpimhip_matvec_t(gpimhip_handle h, const double* A, int64_t ld, int64_t nrow
                      double* out);
 int gpimhip_dist_kinv_update(gpimhip_handle h, const double* xbuf, int64_t ldx, int32_t panel_glob_blk0,
                              const double* Xloc, int64_t ldloc, double* Kinv, int64_t ldk);
+/* ... for `npanels` consecutive panels in ONE launch: xbuf holds them side by side (np rows x 512 * npanels, the first one
+ * with global block index panel_glob_blk0).  Early panels have few tiles, each as deep as the whole matrix: one at a time
+ * they leave most of the chip idle (round 6: four per launch). */
+int gpimhip_dist_kinv_update_n(gpimhip_handle h, const double* xbuf, int64_t ldx, int32_t panel_glob_blk0, int32_t npanels,
+                               const double* Xloc, int64_t ldloc, double* Kinv, int64_t ldk);
 int gpimhip_dist_grad_sums(gpimhip_handle h, const gpimhip_model_t* m, const double* X, int64_t N, const double* u,
                            const double* Kinv, int64_t ldk, const double* alpha, double* S_out);
 int gpimhip_dist_finalize(gpimhip_handle h, const gpimhip_model_t* m, int64_t N, double* u, const double* S,
