@@ -35,7 +35,7 @@ int launch_grad_reduce_fin(gpimhip_ctx* h, const gpimhip_model_t* m, const doubl
                            const double* bc, int T, double* hist_base, double* loss_base, int carry_theta);
 int launch_finalize(gpimhip_ctx* h, const gpimhip_model_t* m, int64_t N, int64_t np, double* u, int do_adam,
                     AdamStep st, double* loss_out, double* grad_out, double* hist_row, int32_t* iter,
-                    const double* bc, int T, double* hist_base, double* loss_base);
+                    const double* bc, int T, double* hist_base, double* loss_base, int carry_theta = 0);
 int launch_predict_var(gpimhip_ctx* h, int64_t ldp, int nb, int64_t m0, int64_t mcount, double* var_out, int64_t M);
 int launch_copy_slice(gpimhip_ctx* h, const double* src, double* dst, int64_t n, int64_t s_bs, int64_t d_bs);
 int launch_acq(gpimhip_ctx* h, int kind, const double* mean, const double* sd, int64_t M, double p0, double p1,
@@ -524,8 +524,11 @@ static int loss_grad_at_u(gpimhip_ctx* h, const gpimhip_model_t* m, const double
     const int64_t np = h->np;
     // One launch for the gradient contraction and the finalize step (round 6; GPIMHIP_NO_FUSED_FINALIZE: the two launches
     // of rounds 1-5 -- the same reductions in the same order, the same bits)
-    const bool fused = !h->refl.mask && !getenv("GPIMHIP_NO_FUSED_FINALIZE");
-    const bool carried = fused && tab && tab->theta_carried;
+    // ... up to np = 8192; beyond, the finalize step is a launch of its own again (the tail's device-scope loads of 8256 tiles'
+    // sums take longer than a launch boundary costs: 530 us against 400 + 20 at N = 16384) -- it still leaves the next theta
+    const bool modern = !h->refl.mask && !getenv("GPIMHIP_NO_FUSED_FINALIZE");
+    const bool fused = modern && np <= 8192;
+    const bool carried = modern && tab && tab->theta_carried;
     const bool defer = fused && alpha_deferrable(h);
     GP_TRY(factor_at_u(h, m, X, x_bs, N, u, carried, defer));
     { StageTimer t(h, 2); GP_TRY(launch_lauum(h, h->A, h->B, np, h->ld, rag_of(N, np))); }
@@ -549,7 +552,7 @@ static int loss_grad_at_u(gpimhip_ctx* h, const gpimhip_model_t* m, const double
     GP_TRY(launch_grad_reduce(h, m, h->B, h->ld, X, N, (int)(np / NB), h->alpha, x_bs));
     if (tab)
         GP_TRY(launch_finalize(h, m, N, np, u, do_adam, st, nullptr, nullptr, nullptr, tab->iter, tab->bc, tab->T,
-                               tab->hist_base, tab->loss_base));
+                               tab->hist_base, tab->loss_base, carried ? 1 : 0));
     else
         GP_TRY(launch_finalize(h, m, N, np, u, do_adam, st, loss_out, grad_out, hist_row, nullptr, nullptr, 0,
                                nullptr, nullptr));

@@ -709,11 +709,12 @@ __global__ __launch_bounds__(256) void finalize_kernel(gpimhip_model_t m, int64_
                                                        int do_adam, AdamStep st, double* __restrict__ loss_out,
                                                        double* __restrict__ grad_out,
                                                        double* __restrict__ hist_row, FinalizeIter fi,
-                                                       int32_t* __restrict__ info) {
+                                                       int32_t* __restrict__ info, int carry_theta) {
     __shared__ double arr[5 * 256];
     __shared__ double S[9];
     const FinProblem f = fin_problem(m, blockIdx.y, np, nb, ntile, grad_part, z, zb, logdet_part, th, u, adam_m, adam_v, fi);
-    finalize_block<false>(m, N, np, nb, ntile, f, do_adam, st, loss_out, grad_out, hist_row, info, nullptr, arr, S);
+    finalize_block<false>(m, N, np, nb, ntile, f, do_adam, st, loss_out, grad_out, hist_row, info,
+                          carry_theta ? th + blockIdx.y : nullptr, arr, S);
 }
 
 // the finalize step as the tail of grad_reduce_kernel
@@ -931,15 +932,16 @@ int launch_grad_reduce_fin(gpimhip_ctx* h, const gpimhip_model_t* m, const doubl
     return launch_grad_reduce_impl(h, m, Kinv, ld, X, N, nb, alpha, x_bs, alpha_part, &ff);
 }
 
+// carry_theta: the theta of the stepped parameters replaces h->theta (the next iteration skips its theta launch)
 int launch_finalize(gpimhip_ctx* h, const gpimhip_model_t* m, int64_t N, int64_t np, double* u, int do_adam,
                     AdamStep st, double* loss_out, double* grad_out, double* hist_row, int32_t* iter,
-                    const double* bc, int T, double* hist_base, double* loss_base) {
+                    const double* bc, int T, double* hist_base, double* loss_base, int carry_theta) {
     const int nb = (int)(np / NB);
     FinalizeIter fi{iter, bc, T, hist_base, loss_base};
     hipLaunchKernelGGL(finalize_kernel, dim3(1, h->nbatch), dim3(256), 0, h->stream, *m, N, np, nb, nb * (nb + 1) / 2,
                        h->grad_part, h->fp32 ? h->ypad : h->z, h->fp32 ? h->alpha : h->z, h->logdet_part, h->theta, u, h->adam_m,
                        h->adam_v, do_adam, st,
-                       loss_out, grad_out, hist_row, fi, h->info);
+                       loss_out, grad_out, hist_row, fi, h->info, carry_theta);
     HIP_TRY(hipGetLastError());
     return GPIMHIP_OK;
 }
