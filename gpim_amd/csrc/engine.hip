@@ -10,6 +10,7 @@
 // bit-reproducible run to run.
 #include "kfun.hpp"
 #include <cstring>
+#include <type_traits>
 #include "theta.hpp"
 
 typedef double d2 __attribute__((ext_vector_type(2)));
@@ -114,32 +115,41 @@ __global__ __launch_bounds__(256) void kmat_kernel(const double* __restrict__ X,
     __syncthreads();
     const double dadd = use_theta_diag ? t.diag_add : diag_add;
     const int ty = tid >> 4, tx = tid & 15;
+    // a tile that lies inside the matrix and off its diagonal (all but 2 nb - 1 of the nb (nb + 1) / 2 lower tiles) needs
+    // no per-entry bounds / diagonal tests (64-bit compares: a tenth of the entry's instructions)
+    const bool interior = (int64_t)ci * 128 + 128 <= N && (int64_t)cj * 128 + 128 <= M && !(sym && ci == cj);
+    auto body = [&](auto INTERIOR) {
 #pragma unroll 2
-    for (int rr = 0; rr < 8; ++rr) {
-        const int r = ty + 16 * rr;
-        const int64_t gi = (int64_t)ci * 128 + r;
-        const double a0 = xa[r][0], a1 = xa[r][1], a2 = xa[r][2], a3 = xa[r][3], an = xa[r][4];
+        for (int rr = 0; rr < 8; ++rr) {
+            const int r = ty + 16 * rr;
+            const int64_t gi = (int64_t)ci * 128 + r;
+            const double a0 = xa[r][0], a1 = xa[r][1], a2 = xa[r][2], a3 = xa[r][3], an = xa[r][4];
 #pragma unroll
-        for (int cc = 0; cc < 4; ++cc) {
-            typename Vec2<R>::T v;
+            for (int cc = 0; cc < 4; ++cc) {
+                typename Vec2<R>::T v;
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int c = tx * 2 + 32 * cc + e;
-                const int64_t gj = (int64_t)cj * 128 + c;
-                double dot = a0 * xz[c][0];
-                dot = fma(a1, xz[c][1], dot);
-                dot = fma(a2, xz[c][2], dot);
-                dot = fma(a3, xz[c][3], dot);
-                double r2 = (an - 2.0 * dot) + xz[c][4];
-                r2 = clamp0_nan(r2);
-                double k = t.var * kfun_value<KIND>(r2, t.alpha);
-                if (gi >= N || gj >= M) k = (sym && gi == gj) ? 1.0 : 0.0;
-                else if (sym && gi == gj) k += dadd;
-                v[e] = (R)k;
+                for (int e = 0; e < 2; ++e) {
+                    const int c = tx * 2 + 32 * cc + e;
+                    const int64_t gj = (int64_t)cj * 128 + c;
+                    double dot = a0 * xz[c][0];
+                    dot = fma(a1, xz[c][1], dot);
+                    dot = fma(a2, xz[c][2], dot);
+                    dot = fma(a3, xz[c][3], dot);
+                    double r2 = (an - 2.0 * dot) + xz[c][4];
+                    r2 = clamp0_nan(r2);
+                    double k = t.var * kfun_value<KIND>(r2, t.alpha);
+                    if (!decltype(INTERIOR)::value) {
+                        if (gi >= N || gj >= M) k = (sym && gi == gj) ? 1.0 : 0.0;
+                        else if (sym && gi == gj) k += dadd;
+                    }
+                    v[e] = (R)k;
+                }
+                *reinterpret_cast<typename Vec2<R>::T*>(out + gi * ld + (int64_t)cj * 128 + tx * 2 + 32 * cc) = v;
             }
-            *reinterpret_cast<typename Vec2<R>::T*>(out + gi * ld + (int64_t)cj * 128 + tx * 2 + 32 * cc) = v;
         }
-    }
+    };
+    if (interior) body(std::true_type{});
+    else body(std::false_type{});
 }
 
 int launch_kmat(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X, int64_t N, const double* Z,
@@ -799,6 +809,9 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const R* __restrict__ 
     __syncthreads();
     double S[7] = {0, 0, 0, 0, 0, 0, 0};
     const int ty = tid >> 4, tx = tid & 15;
+    // strictly lower tiles inside the matrix: every entry counts twice, none is skipped (no per-entry 64-bit compares)
+    const bool interior = ci > cj && (int64_t)ci * 128 + 128 <= N;
+    auto body = [&](auto INTERIOR) {
     for (int rr = 0; rr < 8; ++rr) {
         const int r = ty + 16 * rr;
         const int64_t gi = (int64_t)ci * 128 + r;
@@ -811,9 +824,9 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const R* __restrict__ 
             for (int e = 0; e < 2; ++e) {
                 const int c = tx * 2 + 32 * cc + e;
                 const int64_t gj = (int64_t)cj * 128 + c;
-                if (gi >= N || gj > gi) continue;
+                if (!decltype(INTERIOR)::value && (gi >= N || gj > gi)) continue;
                 const double g = (double)kv[e] - ali * al_c[c];
-                const double w = (gi == gj) ? g : 2.0 * g;
+                const double w = (!decltype(INTERIOR)::value && gi == gj) ? g : 2.0 * g;
                 double dot = a0 * xz[c][0];
                 dot = fma(a1, xz[c][1], dot);
                 dot = fma(a2, xz[c][2], dot);
@@ -827,11 +840,14 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const R* __restrict__ 
                 S[2] = fma(wh, d1 * d1, S[2]);
                 S[3] = fma(wh, d2_ * d2_, S[3]);
                 S[4] = fma(wh, d3 * d3, S[4]);
-                if (gi == gj) S[5] += g;
+                if (!decltype(INTERIOR)::value && gi == gj) S[5] += g;
                 if (KIND == GPIMHIP_KERNEL_RQ) S[6] = fma(w, kvv.ga, S[6]);
             }
         }
     }
+    };
+    if (interior) body(std::true_type{});
+    else body(std::false_type{});
 #pragma unroll
     for (int k = 0; k < 7; ++k) {
         const double v = wave_sum(S[k]);

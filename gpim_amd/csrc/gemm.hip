@@ -47,7 +47,8 @@ static int launch_one(gpimhip_ctx* h, const GemmArgs& g) {
     // up to 640 tiles: 64x64 quadrants, four co-resident workgroups per CU.  A launch of a few hundred tiles whose
     // k-ranges differ by an order of magnitude (triangular inverse, K^-1 product at N ~ 4000) lasts as long as its
     // longest tile; dealt longest-first over 4 x 256 slots, every CU gets a mix (N = 4206: inverse 0.92 -> 0.80 ms,
-    // K^-1 product 0.57 -> 0.48; 1200 / 2400 measure the same)
+    // K^-1 product 0.57 -> 0.48; 1200 / 2400 measure the same; round 6: 128x64 halves with 8 waves instead of quadrants
+    // 2.303 against 2.292 ms per Adam iteration at N = 4212, 1.144 against 1.084 at N = 2560, the same at 6000)
     const int tile64_max = 640;
     const bool small = total <= tile64_max;
     if (EPI == EPI_STORE && small && !g.inplace)
