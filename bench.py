@@ -805,7 +805,7 @@ def main():
             assert mean_c.shape == cube.shape and np.isfinite(mean_c).all() and np.isfinite(sd_c).all()
             out["config"] = {"workload": ("C3: 64x64x64 synthetic hyperspectral cube, 30%% of the (x,y) columns "
                                           "observed, 64 per-slice 2-D exact GPs (N=%d, M=%d), RBF, T=%d Adam its + "
-                                          "predict; slices dealt to the GPUs, concurrent lock-step batches per GPU (batch='auto': 4 x 16 slices on one GPU, 2 x 4 on each of eight)")
+                                          "predict; slices dealt to the GPUs, concurrent lock-step batches per GPU (batch='auto': four batches of 16 slices on one GPU, four batches of 2 on each of eight)")
                                          % (N, M, T), "N": N, "M": M, "iterations": T, "kernel": "RBF", "slices": 64}
             flop_step = 64 * (T * float(N) ** 3 + 2.0 * float(N) ** 3 / 3.0 + float(N) ** 2 * M)
             achieved = flop_step / (ms_step * 1e-3) / 1e12 / world

@@ -274,7 +274,9 @@ def reconstruct_slices(cube, axis=-1, batch=16, return_hyperparams=False, handle
     if batch == "auto":
         # measured on one MI355X (N = 1207 per slice, tools/r3_c3c.py): 8 slices 4 x 2 concurrent 0.27 s (one batch of
         # 8: 0.32), 16 slices 4 x 4 0.35 (0.45), 32 slices 16 x 2 0.64 (0.68), 64 slices 16 x 4 0.99 (1.11)
-        batch = 4 if len(owned) <= 16 else 16
+        # (round 6, tools/r6_c3_queues.py: 8 slices 2 x 4 0.209 s, 4 x 2 0.216-0.226, 1 x 8 0.34; more than four concurrent
+        # batches are slower whatever GPU_MAX_HW_QUEUES says: 64 slices 8 x 8 1.12, 4 x 16 1.19 against 16 x 4 0.889)
+        batch = 2 if len(owned) <= 8 else (4 if len(owned) <= 16 else 16)
         batch_concurrency = min(4, max(1, (len(owned) + batch - 1) // batch))
     groups = []
     for n_obs, idxs in sorted(by_n.items()):
