@@ -65,9 +65,9 @@ def hbm_row(label, pred, statname):
     return "| %s | %.2f GB | %.0f us | %.1f TB/s |" % (label, byts / 1e9, ns / 1e3, byts / ns / 1e3)
 hbm = ["| kernel | bytes moved (FETCH x2 + WRITE) | duration | rate (peak ~ 8 TB/s) |", "|---|---|---|---|",
        hbm_row("`trmv_lower_kernel` (z = L^-1 y)", lambda k: "trmv_lower" in k, "trmv_lower_kernel"),
-       hbm_row("`kmat_kernel<1, double>` (lower tiles of K; one fp64 `exp` per entry)", lambda k: "kmat_kernel" in k, "kmat_kernel<1"),
+       hbm_row("`kmat_kernel<1, double>` (lower tiles of K; one `kf_sqrt` + `kf_exp_neg` per entry, round 6)", lambda k: "kmat_kernel" in k, "kmat_kernel<1"),
        hbm_row("`gemv_t_tri_kernel` (alpha = L^-T z; round 6: row chunks of ~np/32 rows, equal work per workgroup)", lambda k: "gemv_t_tri" in k, "gemv_t_tri_kernel"),
-       hbm_row("`grad_reduce_kernel<1, double>` (K^-1 . dK/dtheta sums; kernel derivative recomputed per entry; its last workgroup runs the finalize step)", lambda k: "grad_reduce" in k, "grad_reduce_kernel<1")]
+       hbm_row("`grad_reduce_kernel<1, double>` (K^-1 . dK/dtheta sums; kernel derivative recomputed per entry; ALU-bound: ~65 fp64 instructions per entry)", lambda k: "grad_reduce" in k, "grad_reduce_kernel<1")]
 
 readme = open(os.path.join(P, "README.md")).read()
 readme = re.sub(r"<!-- MFMA_TABLE -->.*?<!-- /MFMA_TABLE -->", "<!-- MFMA_TABLE -->\n" + mfma_table + "\n<!-- /MFMA_TABLE -->", readme, flags=re.S)
