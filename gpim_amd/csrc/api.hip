@@ -22,7 +22,7 @@ int launch_pad_matrix_in(gpimhip_ctx* h, const double* src, int64_t n, int64_t l
 int launch_pad_matrix_out_lower(gpimhip_ctx* h, const double* src, int64_t np, double* dst, int64_t n, int64_t ld);
 int launch_trmv_lower(gpimhip_ctx* h, const double* L, int64_t ld, int64_t np, const double* y, double* z);
 int launch_gemv_t(gpimhip_ctx* h, const double* A, int64_t ld, int64_t nrows, int64_t ncols, const double* x,
-                  double* out, int tri, int64_t a_bs, int64_t x_bs, int64_t o_bs, double* part = nullptr);
+                  double* out, int tri, int64_t a_bs, int64_t x_bs, int64_t o_bs);
 int launch_grad_reduce(gpimhip_ctx* h, const gpimhip_model_t* m, const double* Kinv, int64_t ld,
                        const double* X, int64_t N, int nb, const double* alpha, int64_t x_bs);
 int launch_kres(gpimhip_ctx* h, const gpimhip_model_t* m, const double* X, int64_t x_bs, int64_t N, double* scratch,
@@ -106,7 +106,7 @@ static void ws_release_matrix(gpimhip_ctx* h) {
     dev_free(h, &h->alpha, B * np);
     dev_free(h, &h->logdet_part, B * nb);
     dev_free(h, &h->grad_part, B * nb * (nb + 1) / 2 * 8);
-    dev_free(h, &h->gemv_part, B * std::max<int64_t>(8, gemv_tri_chunks(np)) * np);
+    dev_free(h, &h->gemv_part, B * (int64_t)gemv_tri_chunks(np) * np);
     dev_free(h, &h->fin_counter, (int64_t)B);
     dev_free(h, &h->theta, B);
     dev_free(h, &h->adam_m, B * MAXP);
@@ -145,7 +145,7 @@ static int ws_ensure_b(gpimhip_ctx* h, int64_t N, int B, int padded, bool matric
         (rc = dev_alloc(h, &h->pcopy, (int64_t)B * NB * NB)) ||
         (rc = dev_alloc(h, &h->ypad, B * np)) || (rc = dev_alloc(h, &h->z, B * np)) ||
         (rc = dev_alloc(h, &h->alpha, B * np)) || (rc = dev_alloc(h, &h->logdet_part, B * nb)) ||
-        (rc = dev_alloc(h, &h->grad_part, B * nb * (nb + 1) / 2 * 8)) || (rc = dev_alloc(h, &h->gemv_part, B * std::max<int64_t>(8, gemv_tri_chunks(np)) * np)) || (rc = dev_alloc(h, &h->fin_counter, (int64_t)B)) || (rc = dev_alloc(h, &h->theta, (int64_t)B)) ||
+        (rc = dev_alloc(h, &h->grad_part, B * nb * (nb + 1) / 2 * 8)) || (rc = dev_alloc(h, &h->gemv_part, B * (int64_t)gemv_tri_chunks(np) * np)) || (rc = dev_alloc(h, &h->fin_counter, (int64_t)B)) || (rc = dev_alloc(h, &h->theta, (int64_t)B)) ||
         (rc = dev_alloc(h, &h->adam_m, (int64_t)B * MAXP)) || (rc = dev_alloc(h, &h->adam_v, (int64_t)B * MAXP)) ||
         (rc = dev_alloc(h, &h->iter, (int64_t)B))) {
         ws_release_matrix(h);

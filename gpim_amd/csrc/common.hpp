@@ -141,7 +141,7 @@ struct gpimhip_ctx {
     double* alpha = nullptr;        // np  (K^-1 y)
     double* logdet_part = nullptr;  // nb
     double* grad_part = nullptr;    // ntiles_lower x 8
-    double* gemv_part = nullptr;    // max(8, gemv_tri_chunks(np)) x np: row-chunk partial sums of the mat-vecs over L^-1 (engine.hip)
+    double* gemv_part = nullptr;    // gemv_tri_chunks(np) x np: row-chunk partial sums of alpha = L^-T z (engine.hip: gemv_t_tri_kernel)
     uint32_t* fin_counter = nullptr;   // per problem: workgroups of grad_reduce_kernel that have finished (engine.hip: FinFused; the last
                                        // one runs the finalize step and resets it)
     ThetaDev* theta = nullptr;      // [ws_batch]

@@ -297,9 +297,7 @@ __global__ __launch_bounds__(256) void trmv_lower_kernel(const R* __restrict__ L
 // diagonal block of the column (A lower triangular), else at row 0.  HBM-bound (8 B per entry of
 // A): 16 waves per workgroup, each with four 512-byte row segments in flight; fixed summation order.
 #define GEMVT_WAVES 16
-// gridDim.z = S > 1: the rows of a column block are cut into S contiguous chunks, chunk s writes its sums to
-// part[s][.] (part: S x o_bs-strided vectors per problem) and gemv_t_sum_kernel adds the S rows in order -- a
-// mat-vec over a mid-size matrix has only ncols / 64 column blocks, far fewer than the chip has CUs.
+// (one workgroup per 64-column strip; the row-chunked form that alpha = L^-T z used until round 5 is gemv_t_tri_kernel below)
 template <typename R>
 __global__ __launch_bounds__(GEMVT_WAVES * 64) void gemv_t_kernel(const R* __restrict__ A, int64_t ld,
                                                                  int64_t nrows, const double* __restrict__ x,
@@ -308,16 +306,10 @@ __global__ __launch_bounds__(GEMVT_WAVES * 64) void gemv_t_kernel(const R* __res
     __shared__ double red[GEMVT_WAVES][64];
     A += blockIdx.y * a_bs;
     x += blockIdx.y * x_bs;
-    const int S = gridDim.z;
-    out += (blockIdx.y * S + blockIdx.z) * o_bs;
+    out += blockIdx.y * o_bs;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t j = (int64_t)blockIdx.x * 64 + lane;
-    int64_t i0 = tri ? ((int64_t)blockIdx.x * 64 / NB) * NB : 0, i1 = nrows;
-    if (S > 1) {
-        const int64_t chunk = ((i1 - i0 + S - 1) / S + GEMVT_WAVES - 1) / GEMVT_WAVES * GEMVT_WAVES;
-        i0 += blockIdx.z * chunk;
-        i1 = i0 + chunk < i1 ? i0 + chunk : i1;
-    }
+    const int64_t i0 = tri ? ((int64_t)blockIdx.x * 64 / NB) * NB : 0, i1 = nrows;
     const R* col = A + j;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     int64_t i = i0 + wave;
@@ -339,15 +331,6 @@ __global__ __launch_bounds__(GEMVT_WAVES * 64) void gemv_t_kernel(const R* __res
         out[j] = t;
     }
 }
-__global__ __launch_bounds__(256) void gemv_t_sum_kernel(const double* __restrict__ part, int S, int64_t n, double* __restrict__ out,
-                                                         int64_t o_bs) {
-    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (j >= n) return;
-    part += (int64_t)blockIdx.y * S * o_bs;
-    double t = 0.0;
-    for (int s = 0; s < S; ++s) t += part[(int64_t)s * o_bs + j];
-    out[blockIdx.y * o_bs + j] = t;
-}
 
 int launch_trmv_lower(gpimhip_ctx* h, const double* L, int64_t ld, int64_t np, const double* y, double* z) {
     if (h->fp32)
@@ -359,34 +342,22 @@ int launch_trmv_lower(gpimhip_ctx* h, const double* L, int64_t ld, int64_t np, c
     HIP_TRY(hipGetLastError());
     return GPIMHIP_OK;
 }
-// part: optional scratch of 8 * o_bs doubles per problem (h->gemv_part); with it, a launch of few column blocks is
-// cut along the rows into up to 8 chunks (~512 workgroups) and summed in a fixed order by a second kernel
 int launch_gemv_t(gpimhip_ctx* h, const double* A, int64_t ld, int64_t nrows, int64_t ncols, const double* x,
-                  double* out, int tri, int64_t a_bs, int64_t x_bs, int64_t o_bs, double* part) {
-    const int64_t cb = ncols / 64;
-    int S = 1;
-    // (a function of the matrix size alone, not of the batch: a problem gives the same bits alone and in a lock-step batch)
-    if (part && o_bs >= ncols && nrows >= 1024) S = (int)std::max<int64_t>(1, std::min<int64_t>(8, 512 / std::max<int64_t>(1, cb)));
-    double* dst = S > 1 ? part : out;
-    const dim3 grid((unsigned)cb, h->nbatch, S);
+                  double* out, int tri, int64_t a_bs, int64_t x_bs, int64_t o_bs) {
+    const dim3 grid((unsigned)(ncols / 64), h->nbatch);
     if (h->fp32)
         hipLaunchKernelGGL(gemv_t_kernel<float>, grid, dim3(GEMVT_WAVES * 64), 0, h->stream,
-                           reinterpret_cast<const float*>(A), ld, nrows, x, dst, tri, a_bs, x_bs, o_bs);
+                           reinterpret_cast<const float*>(A), ld, nrows, x, out, tri, a_bs, x_bs, o_bs);
     else
         hipLaunchKernelGGL(gemv_t_kernel<double>, grid, dim3(GEMVT_WAVES * 64), 0, h->stream, A, ld, nrows,
-                       x, dst, tri, a_bs, x_bs, o_bs);
+                       x, out, tri, a_bs, x_bs, o_bs);
     HIP_TRY(hipGetLastError());
-    if (S > 1) {
-        hipLaunchKernelGGL(gemv_t_sum_kernel, dim3((unsigned)((ncols + 255) / 256), h->nbatch), dim3(256), 0, h->stream,
-                           (const double*)part, S, ncols, out, o_bs);
-        HIP_TRY(hipGetLastError());
-    }
     return GPIMHIP_OK;
 }
 
 // ------------------------------------------------------------------------------------------
 // alpha = L^-T z over the lower-triangular L^-1 (round 6).  The strip of a 64-column block starts at its diagonal
-// block, so strips run from np rows down to 128: cutting every strip into the SAME number of chunks (the kernel above)
+// block, so strips run from np rows down to 128: cutting every strip into the SAME number of chunks (round 5's form of the kernel above)
 // leaves the launch waiting for the first strips' workgroups -- 1.5 TB/s at np = 16384.  Here the ROWS are cut into
 // chunks of rc (gemv_tri_rc: ~np / 32, a multiple of 128, 128 ... 1024): workgroup (column block, chunk) handles what
 // lies at or below the block's diagonal block -- equal work per workgroup, thousands of workgroups of four waves --

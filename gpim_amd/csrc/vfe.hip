@@ -45,7 +45,7 @@ hipStream_t ensure_capture_stream(gpimhip_ctx* h);
 void capture_lock(gpimhip_ctx* h);
 void capture_unlock(gpimhip_ctx* h);
 int launch_gemv_t(gpimhip_ctx* h, const double* A, int64_t ld, int64_t nrows, int64_t ncols, const double* x,
-                  double* out, int tri, int64_t a_bs, int64_t x_bs, int64_t o_bs, double* part = nullptr);
+                  double* out, int tri, int64_t a_bs, int64_t x_bs, int64_t o_bs);
 int launch_pad_copy(gpimhip_ctx* h, const double* src, int64_t n, double* dst, int64_t np);
 int ws_ensure(gpimhip_ctx* h, int64_t N);
 int vfe_finish_and_check(gpimhip_ctx* h);
