@@ -45,6 +45,28 @@ def test_p1_factor_vs_potrf(ensure_built, n):
     H.close()
 
 
+def test_grouped_kinv_pass_equals_one_panel_per_launch(ensure_built, monkeypatch):
+    """K^-1 = X^T X with eight panels per launch (gpimhip_dist_kinv_update_n, DistributedCholesky._stream_groups) against one
+    panel per launch: the same tiles with the same k-ranges, hence the same bits; against torch to 1e-10.  n = 5300: eleven
+    panels, a group of eight and a ragged group of three."""
+    from gpim_amd import dist_chol
+    from gpim_amd.dist_chol import DistributedCholesky
+    n = 5300
+    rng = np.random.default_rng(n)
+    Bm = rng.standard_normal((n, n // 3))
+    Ah = torch.from_numpy(Bm @ Bm.T + n * np.eye(n))
+    A = Ah.cuda()
+    outs = []
+    for G in (1, 8, 3):
+        monkeypatch.setattr(dist_chol, "KINV_GROUP", G)
+        ch = DistributedCholesky(n)
+        ch.set_from_function(lambda c0, c1: A[:, c0:c1]).factor()
+        outs.append(torch.tril(ch.kinv(ch.inverse())[:n, :n]).clone())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    ref = torch.linalg.inv(Ah)
+    assert (outs[1].cpu() - torch.tril(ref)).abs().max().item() <= 1e-10 * ref.abs().max().item()
+
+
 def test_not_pd_raises(ensure_built):
     from gpim_amd.dist_chol import DistributedCholesky
     A = torch.eye(900, dtype=torch.float64, device="cuda")

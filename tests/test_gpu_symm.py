@@ -6,6 +6,7 @@ agree with the dense model to rounding.
 """
 import numpy as np
 import pytest
+import torch
 from numpy.testing import assert_allclose
 
 pytestmark = pytest.mark.gpu
@@ -134,3 +135,33 @@ def test_symmetry_reduced_needs_a_symmetric_axis(gpim):
     X[1] = X[1] ** 1.5
     with pytest.raises(NotImplementedError):
         gpim.reconstructor(X, R, X, structured=True, kernel="Matern52", verbose=0)
+
+
+def test_rank_without_a_block_runs_the_replicated_step(gpim):
+    """World size > number of reflection blocks (a 2-D image has four, a node eight GPUs): a rank that owns no block never
+    builds a matrix workspace, yet runs the replicated chain rule + Adam step of every iteration on the all-reduced sums
+    (gpimhip_dist_finalize_dev used to refuse a handle without workspace: that rank raised while the others hung in the
+    next all-reduce).  Single process: the shard of rank 5 of 8, whose sums are zero -- the step must run and keep the
+    parameters finite; the dead-factor guard of DistributedCholesky rides along."""
+    from gpim_amd.dist_symm import _Shard, symm_gp_fit, symm_gp_posterior
+    from gpim_amd.kernels import KernelSpec
+    R = _image((12, 10), 5)
+    X = gpim.utils.get_full_grid(R)
+    kw = dict(kernel="Matern52", lengthscale=[[1., 1.], [6., 6.]])
+    spec = KernelSpec("Matern52", 2, kw["lengthscale"], jitter=1e-5)
+    sh = _Shard(X, R, spec, 5, 8)
+    assert sh.B == 4 and sh.mine == []
+    hyper, u = symm_gp_fit(X, R, learning_rate=0.1, iterations=3, shard=sh, **kw)
+    assert np.isfinite(hyper["loss"]).all() and np.isfinite(np.asarray(hyper["lengthscale"])).all() and torch.isfinite(u).all()
+    mean, sd = symm_gp_posterior(X, R, None, u, shard=sh, **kw)          # this rank's share of the sums: zeros
+    assert np.all(mean == 0.0) and np.isfinite(sd).all()
+    from gpim_amd.dist_chol import DistributedCholesky
+    A = torch.eye(700, dtype=torch.float64, device="cuda") * 3.0
+    ch = DistributedCholesky(700).set_from_function(lambda c0, c1: A[:, c0:c1])
+    with pytest.raises(RuntimeError):
+        ch.solve(torch.ones(700, dtype=torch.float64, device="cuda"))      # no factor yet
+    ch.factor()
+    Xl = ch.inverse()
+    ch.kinv(Xl, out=ch.local)                                             # K^-1 over the dead factor ...
+    with pytest.raises(RuntimeError):
+        ch.logdet()                                                       # ... which is gone
