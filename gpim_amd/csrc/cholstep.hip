@@ -589,7 +589,13 @@ static int host_shape(int64_t update_kblocks, int quad_max = 2000) { return upda
 // tiles alone, so that the budget for the inverse's chunks is the one of the launch as it will run.
 // (>= 300 update quadrants of average depth >= 3; 420 / 3.5 before the planner knew: N = 8192 11.42 -> 11.31 ms per
 // iteration; 240 / 2.5, depth 2 and never pairing -- 12.15 ms -- are slower)
-static bool pair_rule(size_t ntiles, int64_t kblocks) { return 4 * ntiles >= 300 && 10 * kblocks >= 30 * (int64_t)ntiles; }
+#ifndef PAIR_MIN_QUADS
+#define PAIR_MIN_QUADS 300
+#endif
+#ifndef PAIR_MIN_DEPTH10
+#define PAIR_MIN_DEPTH10 30
+#endif
+static bool pair_rule(size_t ntiles, int64_t kblocks) { return 4 * ntiles >= PAIR_MIN_QUADS && 10 * kblocks >= PAIR_MIN_DEPTH10 * (int64_t)ntiles; }
 // returns false if the plan did not close (every launch completes at least one phase of one node, so this cannot happen
 // with the dependency rule as it stands; a caller must not run a partial plan: A would be left a half-inverted factor)
 static bool plan_inverse(int nb, std::vector<std::vector<TileDesc>>& fill, std::vector<std::vector<TileDesc>>& post,
@@ -621,7 +627,13 @@ static bool plan_inverse(int nb, std::vector<std::vector<TileDesc>>& fill, std::
         // constants matter little: 1.5 ... 2.0 and 1.3 ... 1.6 measure the same)
         const bool two = hosted && q == 4 && pair_rule(out.size(), upd);
         if (hosted) pair[L] = two;
-        const double slow = two ? 1.7 : 1.0, chain = two ? CHAIN + 0.3 : CHAIN;
+#ifndef PLAN_PAIR_SLOW
+#define PLAN_PAIR_SLOW 1.7
+#endif
+#ifndef PLAN_PAIR_CHAIN
+#define PLAN_PAIR_CHAIN 0.3
+#endif
+        const double slow = two ? PLAN_PAIR_SLOW : 1.0, chain = two ? CHAIN + PLAN_PAIR_CHAIN : CHAIN;
         HostSim sim(q == 1 || two ? HOST_SLOTS : HOST_SLOTS / 2);
         double target = 1e30;
         if (hosted) {
